@@ -1,0 +1,300 @@
+/* pbhc_hip.h — C ABI of libpbhc_hip.so: the MI355X (gfx950) hot path of the PBHC / KungfuBot
+ * humanoidverse motion-tracking agent.
+ *
+ * The reference (kyungminn/PBHC) is pure Python/PyTorch and has no FFI of its own; its plugin
+ * boundary is three Hydra `_target_` classes (simulator / env / algo).  This library is the native
+ * layer underneath our drop-in classes for those targets (pbhc_amd/...), and every entry point
+ * names the reference code it replaces.  Conventions:
+ *   - plain C, no torch types; all tensor arguments are raw DEVICE pointers owned by the caller
+ *     (fp32 row-major unless stated; int64 / bool where the reference's tensors are);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - return 0 on success, a negative PBHC_E* code otherwise; nothing throws across the boundary;
+ *   - quaternions are xyzw (Isaac Gym order) except MJCF / extend_config tables, which are wxyz.
+ */
+#ifndef PBHC_HIP_H
+#define PBHC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBHC_ABI_VERSION 1
+
+#define PBHC_OK 0
+#define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
+#define PBHC_ENOMEM (-12)
+#define PBHC_EHIP (-5)      /* a HIP runtime call failed; see pbhc_last_error() */
+
+#define PBHC_MAX_BODIES 40   /* bodies incl. extended (hands, head) */
+#define PBHC_MAX_DOF 32
+#define PBHC_MAX_FEET 2
+#define PBHC_MAX_TERMS 32    /* reward terms (vector-reward heads - 1) */
+#define PBHC_MAX_IDX 40
+#define PBHC_MAX_GROUPS 6    /* observation groups + the history write-back map */
+#define PBHC_MAX_QUEUE 8     /* control-delay queue depth */
+#define PBHC_NUM_SIGMA 10
+#define PBHC_NUM_GLOBALS 64
+#define PBHC_NUM_LOG 32
+
+/* ---- skeleton (reference: Humanoid_Batch.__init__/from_mjcf,
+ *      humanoidverse/utils/motion_lib/torch_humanoid_batch.py:44-165) ---------------------- */
+typedef struct PbhcSkeleton {
+  int32_t num_bodies;      /* B  : real bodies                                   */
+  int32_t num_bodies_ext;  /* Bx : B + extended bodies                           */
+  int32_t num_dof;         /* D  : dof d drives body d+1 (one hinge per body)    */
+  int32_t max_depth;
+  int32_t parent[PBHC_MAX_BODIES];
+  int32_t depth[PBHC_MAX_BODIES];
+  float offset[PBHC_MAX_BODIES][3];
+  float local_rot_wxyz[PBHC_MAX_BODIES][4];
+  float dof_axis[PBHC_MAX_DOF][3];
+} PbhcSkeleton;
+
+/* ---- reward term ids (reference: `_reward_<name>` in legged_robot_base.py:944-1087 and
+ *      envs/motion_tracking/motion_tracking.py:1154-1328) ------------------------------------ */
+enum PbhcRewardTerm {
+  PBHC_R_TELEOP_CONTACT_MASK = 0,
+  PBHC_R_TELEOP_MAX_JOINT_POSITION,
+  PBHC_R_TELEOP_BODY_POSITION_EXTEND,
+  PBHC_R_TELEOP_VR_3POINT,
+  PBHC_R_TELEOP_BODY_POSITION_FEET,
+  PBHC_R_TELEOP_BODY_ROTATION_EXTEND,
+  PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND,
+  PBHC_R_TELEOP_BODY_VELOCITY_EXTEND,
+  PBHC_R_TELEOP_JOINT_POSITION,
+  PBHC_R_TELEOP_JOINT_VELOCITY,
+  PBHC_R_PENALTY_TORQUES,
+  PBHC_R_PENALTY_DOF_VEL,
+  PBHC_R_PENALTY_DOF_ACC,
+  PBHC_R_PENALTY_ACTION_RATE,
+  PBHC_R_PENALTY_ORIENTATION,
+  PBHC_R_FEET_AIR_TIME,
+  PBHC_R_PENALTY_FEET_CONTACT_FORCES,
+  PBHC_R_PENALTY_STUMBLE,
+  PBHC_R_PENALTY_SLIPPAGE,
+  PBHC_R_FOOT_SLIP_PENALTY,
+  PBHC_R_LIMITS_DOF_POS,
+  PBHC_R_LIMITS_DOF_VEL,
+  PBHC_R_LIMITS_TORQUE,
+  PBHC_R_COLLISION,
+  PBHC_R_ALIVE,
+  PBHC_R_NUM_TERMS
+};
+
+/* ---- tracking-sigma slots (reference: rewards.reward_tracking_sigma keys) ------------------ */
+enum PbhcSigma {
+  PBHC_S_MAX_JOINT_POS = 0, PBHC_S_UPPER_BODY_POS, PBHC_S_LOWER_BODY_POS, PBHC_S_VR_3POINT_POS,
+  PBHC_S_FEET_POS, PBHC_S_BODY_ROT, PBHC_S_BODY_VEL, PBHC_S_BODY_ANG_VEL, PBHC_S_JOINT_POS, PBHC_S_JOINT_VEL
+};
+
+/* ---- feature ids: the per-env scalars/vectors an observation key can read
+ *      (reference getters `_get_obs_<key>`: legged_robot_base.py:1114-1215,
+ *      motion_tracking.py:944-1015).  feat_off[id] is the offset inside the feature row. ------- */
+enum PbhcFeature {
+  PBHC_F_BASE_LIN_VEL = 0, PBHC_F_BASE_ANG_VEL, PBHC_F_PROJECTED_GRAVITY, PBHC_F_DOF_POS, PBHC_F_DOF_VEL,
+  PBHC_F_ACTIONS, PBHC_F_REF_MOTION_PHASE, PBHC_F_DIF_LOCAL_RIGID_BODY_POS, PBHC_F_LOCAL_REF_RIGID_BODY_POS,
+  PBHC_F_VR_3POINT_POS, PBHC_F_DR_BASE_COM, PBHC_F_DR_LINK_MASS, PBHC_F_DR_KP, PBHC_F_DR_KD, PBHC_F_DR_FRICTION,
+  PBHC_F_DR_CTRL_DELAY, PBHC_F_RELYAW, PBHC_F_BASE_POS_Z, PBHC_F_DIF_JOINT_ANGLES, PBHC_F_DIF_JOINT_VELOCITIES,
+  PBHC_F_LOCAL_REF_RIGID_BODY_VEL, PBHC_F_GLOBAL_REF_RIGID_BODY_VEL, PBHC_F_HISTORY, PBHC_F_ZERO,
+  PBHC_F_NUM
+};
+
+/* ---- device-resident globals (what the reference keeps as Python floats on the env object:
+ *      adaptive sigma + EMA motion_tracking.py:1030-1048, penalty curriculum
+ *      legged_robot_base.py:882-900, average_episode_length :875-879, motion-far threshold
+ *      motion_tracking.py:309-317).  double[PBHC_NUM_GLOBALS]. -------------------------------- */
+enum PbhcGlobal {
+  PBHC_G_SIGMA = 0,                       /* [10] */
+  PBHC_G_EMA = 10,                        /* [10] */
+  PBHC_G_PENALTY_SCALE = 20,
+  PBHC_G_AVG_EP_LEN = 21,
+  PBHC_G_MOTION_FAR_THR = 22,
+  PBHC_G_SOFT_POS_VAL = 23,
+  PBHC_G_SOFT_VEL_VAL = 24,
+  PBHC_G_SOFT_TAU_VAL = 25,
+  PBHC_G_STEP_COUNTER = 26,
+  PBHC_G_NOISE_CURRICULUM = 27,
+  PBHC_G_LOG = 32                         /* [PBHC_NUM_LOG] per-step log means, see PbhcLog */
+};
+
+enum PbhcLog {
+  PBHC_L_UPPER_BODY_DIFF_NORM = 0, PBHC_L_LOWER_BODY_DIFF_NORM, PBHC_L_VR_3POINT_DIFF_NORM, PBHC_L_JOINT_POS_DIFF_NORM,
+  PBHC_L_ACTION_CLIP_FRAC, PBHC_L_RESET_FRAC, PBHC_L_TERM_GRAVITY, PBHC_L_TERM_MOTION_FAR, PBHC_L_TERM_TIME_OUT,
+  PBHC_L_TERM_MOTION_END, PBHC_L_END_TIME_RATIO, PBHC_L_END_TIME_RATIO_STD, PBHC_L_NUM_RESETS, PBHC_L_REW_MEAN,
+  PBHC_L_NUM
+};
+
+/* ---- one output map: out[n][j] = clip((feat[src[j]] + U(-1,1)*noise[j]) * scale[j]) --------
+ * (reference: helpers.parse_observation helpers.py:128-152 + sorted-key concat
+ *  legged_robot_base.py:787-793 + clip :326-328; group PBHC_MAX_GROUPS-1 is conventionally the
+ *  history write-back, history_handler.py:40-44, not clipped) */
+typedef struct PbhcOutMap {
+  int32_t dim;
+  int32_t clip;              /* 1: clip to +-clip_observations */
+  const int32_t* src;        /* device [dim] index into the feature row */
+  const float* scale;        /* device [dim] */
+  const float* noise;        /* device [dim] noise scale (0 = none) */
+} PbhcOutMap;
+
+/* ---- static configuration of the v1 env (LeggedRobotMotionTracking) ------------------------
+ * Filled by the host from the reference's YAML config tree (same keys); copied to the device by
+ * pbhc_env_create. */
+typedef struct PbhcEnvConfig {
+  int32_t abi_version;
+  int32_t num_envs;
+  PbhcSkeleton skel;
+  /* extended bodies: skel entries B..Bx-1 (parent, offset, local_rot) */
+  /* timing (base_task.py:37-39) */
+  float dt;
+  float max_episode_length;
+  /* control (legged_robot_base.py:795-838) */
+  float p_gains[PBHC_MAX_DOF], d_gains[PBHC_MAX_DOF], action_scale[PBHC_MAX_DOF], default_dof_pos[PBHC_MAX_DOF];
+  float torque_limits[PBHC_MAX_DOF], dof_vel_limits[PBHC_MAX_DOF];
+  float hard_dof_pos_limits[PBHC_MAX_DOF][2], soft_dof_pos_limits[PBHC_MAX_DOF][2];
+  float action_clip_value;
+  int32_t clip_torques, randomize_torque_rfi, use_rao, randomize_ctrl_delay, queue_len;
+  float rfi_lim;
+  /* domain randomisation ranges used on reset (legged_robot_base.py:599-635) */
+  int32_t randomize_pd_gain, randomize_rfi_lim;
+  float kp_range[2], kd_range[2], rfi_lim_range[2], rao_lim;
+  int32_t ctrl_delay_range[2];
+  /* body index sets (base_task.py:169-205, motion_tracking.py:203-232) */
+  int32_t num_feet, feet[PBHC_MAX_FEET];
+  int32_t num_penalised, penalised[PBHC_MAX_IDX];
+  int32_t num_upper, upper[PBHC_MAX_IDX];
+  int32_t num_lower, lower[PBHC_MAX_IDX];
+  int32_t num_track, track[PBHC_MAX_IDX];
+  int32_t body_flags[PBHC_MAX_BODIES];       /* bit0 upper, bit1 lower, bit2 tracked(vr 3-point), bit3 foot */
+  int32_t track_slot[PBHC_MAX_BODIES];       /* position of the body inside `track`, or -1 */
+  /* termination (legged_robot_base.py:408-489, motion_tracking.py:330-357) */
+  int32_t terminate_by_gravity, terminate_when_motion_far, terminate_when_motion_end, motion_far_curriculum;
+  float termination_gravity;
+  float motion_far_degree, motion_far_down, motion_far_up, motion_far_min, motion_far_max;
+  /* rewards (legged_robot_base.py:167-233,715-761) */
+  int32_t num_terms;                         /* columns 0..num_terms-1; rew_buf has num_terms+1 columns if use_vec_reward */
+  int32_t use_vec_reward, num_rew_cols;
+  int32_t term_id[PBHC_MAX_TERMS];
+  float term_scale[PBHC_MAX_TERMS];          /* reward_scales[name] * dt */
+  int32_t term_penalty[PBHC_MAX_TERMS];      /* in reward_penalty_reward_names and curriculum on */
+  int32_t term_sum_col[PBHC_MAX_TERMS];      /* column in episode_sums */
+  int32_t has_termination, termination_sum_col, only_positive_rewards, num_sum_cols;
+  float termination_scale;
+  float body_pos_lower_weight, body_pos_upper_weight, desired_feet_air_time, max_contact_force;
+  int32_t adaptive_sigma;                    /* rewards.adaptive_tracking_sigma.enable, type "origin" */
+  int32_t sigma_active[PBHC_NUM_SIGMA];      /* 1 if a configured reward term updates this sigma */
+  float adaptive_alpha;
+  int32_t penalty_curriculum;
+  float penalty_degree, penalty_down, penalty_up, penalty_min, penalty_max;
+  int32_t num_compute_average_epl;
+  int32_t soft_pos_curriculum, soft_vel_curriculum, soft_tau_curriculum;
+  float soft_dof_vel_limit, soft_torque_limit;
+  float max_episode_length_s;
+  /* observations */
+  float clip_observations;
+  int32_t feat_off[PBHC_F_NUM];
+  int32_t feat_dim;
+  int32_t hist_dim;                          /* floats of history state per env */
+  int32_t num_groups;
+  PbhcOutMap groups[PBHC_MAX_GROUPS];
+  int32_t has_contact_mask;
+  float ref_init_yaw;
+  int32_t dr_link_mass_dim;
+  uint64_t seed;
+} PbhcEnvConfig;
+
+/* ---- reference-motion table (reference: MotionLibBase.load_motions / get_motion_state,
+ *      motion_lib_base.py:123-259,261-391).  One packed row per frame:
+ *      [dof_pos D | dof_vel D | contact 2 | pos Bx*3 | rot Bx*4 | vel Bx*3 | ang Bx*3]. ---------- */
+typedef struct PbhcMotionTable {
+  const float* frames;          /* device [total_frames, row] */
+  int32_t row;                  /* 2D + 2 + 13 Bx */
+  int32_t num_motions;
+  const int32_t* length_starts; /* device [M] first row of each clip   */
+  const int32_t* num_frames;    /* device [M]                           */
+  const float* motion_dt;       /* device [M] 1/fps                     */
+  const float* motion_len;      /* device [M] (F-1)/fps                 */
+} PbhcMotionTable;
+
+/* ---- per-step tensors of the fused env step ------------------------------------------------ */
+typedef struct PbhcStepIO {
+  /* inputs */
+  const float* actions_in;        /* [N,D]   policy actions                                    */
+  const float* frame_root;        /* [N,13]  replay frame the sim switches to this step       */
+  const float* frame_dof_pos;     /* [N,D]                                                     */
+  const float* frame_dof_vel;     /* [N,D]                                                     */
+  const float* frame_contact;     /* [N,B,3] net contact forces                                */
+  /* optional injected random draws (NULL -> in-kernel Philox) */
+  const float* u_rfi;             /* [N,D] uniforms of the torque RFI noise                    */
+  const float* ovr_start_time;    /* [N]   values consumed by resetting envs                   */
+  const float* ovr_kp; const float* ovr_kd; const float* ovr_rfi_lim; const float* ovr_rao; /* [N,D] */
+  const int64_t* ovr_delay;       /* [N]                                                       */
+  /* simulator-surface state (reference names; simulator/isaacgym/isaacgym.py:574-618) */
+  float* root_states;             /* [N,13] */
+  float* dof_state;               /* [N,D,2] (pos, vel) */
+  float* rigid_body_state;        /* [N,B,13] pos3 rot4 vel3 ang3, may be NULL */
+  float* contact_forces;          /* [N,B,3], may be NULL */
+  /* env state (reference names; legged_robot_base.py:39-131, motion_tracking.py:251-263) */
+  float* actions; float* last_actions; float* actions_after_delay; float* action_queue; /* [N,D] x3, [N,Q,D] */
+  float* last_dof_pos; float* last_dof_vel; float* torques;                              /* [N,D] */
+  float* feet_air_time; float* contacts; float* contacts_filt; float* last_contacts; float* last_contacts_filt; /* [N,F] */
+  float* kp_scale; float* kd_scale; float* rfi_lim_scale; float* rao_scale;              /* [N,D] */
+  float* motion_start_times; float* motion_len; float* end_time_ratio_buf;               /* [N] */
+  float* episode_sums;            /* [N,num_sum_cols] */
+  float* hist;                    /* [N,hist_dim] */
+  int64_t* episode_length_buf; int64_t* last_episode_length_buf; int64_t* reset_buf; int64_t* action_delay_idx; /* [N] */
+  const int64_t* motion_ids;      /* [N] slot -> clip */
+  uint8_t* time_out_buf;          /* [N] bool */
+  const float* env_origins;       /* [N,3] */
+  const float* dr_base_com; const float* dr_link_mass; const float* dr_friction;        /* [N,3] [N,L] [N,1] */
+  /* outputs */
+  float* obs[PBHC_MAX_GROUPS];    /* [N,dim_g]; group num_groups-1 may alias `hist` semantics (see PbhcOutMap) */
+  float* rew_buf;                 /* [N,num_rew_cols] */
+  float* ref_body_pos_extend;     /* [N,Bx,3] may be NULL */
+  float* ref_body_rot_extend;     /* [N,Bx,4] may be NULL */
+  float* episode_rew_out;         /* [N,num_sum_cols] episode_sums / max_episode_length_s of envs reset this step (else unchanged), may be NULL */
+} PbhcStepIO;
+
+typedef struct PbhcEnv PbhcEnv;   /* opaque */
+
+int pbhc_abi_version(void);
+const char* pbhc_last_error(void);
+int pbhc_sizeof_env_config(void);
+int pbhc_sizeof_step_io(void);
+
+/* Load-time FK + filtered velocities of one clip -> packed frame rows.
+ * Replaces Humanoid_Batch.fk_batch / _compute_velocity / _compute_angular_velocity
+ * (torch_humanoid_batch.py:168-290).  pose_aa [F,Bx,3], trans [F,3], contact [F,2] or NULL (device);
+ * out_rows [F,row] device; scratch >= F*Bx*14 floats device. */
+int pbhc_motion_build(const PbhcSkeleton* skel, const float* pose_aa, const float* trans, const float* contact,
+                      int num_frames, float dt, float* out_rows, float* scratch, void* stream);
+
+/* Phase lookup + lerp/slerp.  Replaces MotionLibBase.get_motion_state (motion_lib_base.py:123-259).
+ * ids [N] int64, times [N], offset [N,3] or NULL -> out [N,row] packed like a frame row
+ * (positions include the offset). */
+int pbhc_motion_state(const PbhcMotionTable* tbl, int num_bodies_ext, int num_dof, const int64_t* ids, const float* times,
+                      const float* offset, int n, float* out, void* stream);
+
+/* Rigid-body pose + twist from (root state, q, q-dot): what Isaac Gym's rigid-body state tensor
+ * supplied in the reference (isaacgym.py:574-605).  out [N,B,13]. */
+int pbhc_sim_fk(const PbhcSkeleton* skel, const float* root_states, const float* dof_pos, const float* dof_vel,
+                int dof_stride, int n, float* out_body_state, void* stream);
+
+/* Env object: owns the device copy of the config, the globals and the reduction scratch. */
+/* `globals`: caller-owned device double[PBHC_NUM_GLOBALS] (see enum PbhcGlobal), initialised by the caller. */
+int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double* globals, PbhcEnv** out);
+void pbhc_env_destroy(PbhcEnv* env);
+/* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */
+int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
+
+/* GAE + returns + normalised advantages.  Replaces MHPPO._compute_returns (mh_ppo.py:348-395).
+ * rewards/values/returns [T,N,R], dones [T,N] bool, last_values [N,R], advantages [T,N].
+ * stats: device double[4] scratch. */
+int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int T, int N, int R,
+             float gamma, float lam, float* returns, float* advantages, double* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

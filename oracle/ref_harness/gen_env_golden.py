@@ -213,6 +213,19 @@ def dump_fixture_config(cfg_path, name, motion_file=None, extra=None):
     if motion_file:
         c["robot"]["motion"]["motion_file"] = motion_file
     m = c["robot"]["motion"]
+    # data fixtures that travel with the repo: the clip (arrays only) and the parsed skeleton tables
+    from pbhc_amd.motion_lib import load_motion_file, save_motion_npz
+    from pbhc_amd.skeleton import Skeleton
+    src = m["motion_file"]
+    clip_name = os.path.splitext(os.path.basename(src))[0] + ".npz"
+    os.makedirs(os.path.join(G.GOLD, "clips"), exist_ok=True)
+    save_motion_npz(os.path.join(G.GOLD, "clips", clip_name), [("clip0", cc) for _, cc in load_motion_file(src)])
+    sk = Skeleton.from_mjcf(os.path.join(m["asset"]["assetRoot"], m["asset"]["assetFileName"]), [dict(e) for e in m["extend_config"]])
+    sk_name = "skeleton_" + os.path.splitext(m["asset"]["assetFileName"])[0] + ".json"
+    sk.to_json(os.path.join(G.GOLD, sk_name))
+    m["motion_file"] = "tests/golden/clips/" + clip_name
+    m["asset"]["assetRoot"] = "tests/golden"
+    m["asset"]["assetFileName"] = sk_name
     for k in ["visualization", "smpl_pose_modifier", "joint_matches", "limb_weight_group"]:
         m.pop(k, None)
     c.pop("eval_overrides", None)
@@ -234,8 +247,9 @@ V1_CFG = "example/pretrained_horse_stance_pose/config.yaml"
 WALK_EXTRA = {"rewards.reward_scales.teleop_contact_mask": 0}
 
 
-def main():
-    run_trace(V1_CFG, "horse", N=32, T=12)
-    run_trace(V1_CFG, "walk", N=16, T=8, motion_file="motion_data/g1_walk_45cms_23dof.pkl", extra=WALK_EXTRA, seed=7)
+def main(traces=True):
+    if traces:
+        run_trace(V1_CFG, "horse", N=32, T=12)
+        run_trace(V1_CFG, "walk", N=16, T=8, motion_file="motion_data/g1_walk_45cms_23dof.pkl", extra=WALK_EXTRA, seed=7)
     dump_fixture_config(V1_CFG, "v1_g1_23dof_horse_stance.yaml")
     dump_fixture_config(V1_CFG, "v1_g1_23dof_walk.yaml", motion_file="motion_data/g1_walk_45cms_23dof.pkl", extra=WALK_EXTRA)

@@ -1,0 +1,154 @@
+"""ctypes binding of libpbhc_hip.so (include/pbhc_hip.h).
+
+The ctypes Structures are generated from the header text itself, so the Python view of the ABI
+cannot drift from the C one; sizes are cross-checked against `pbhc_sizeof_*()` at load.
+There is no fallback: if the library is missing or was built for another ABI, using the
+product raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(ROOT, "include", "pbhc_hip.h")
+LIB_PATH = os.path.join(_HERE, "libpbhc_hip.so")
+
+_CTYPES = {
+    "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+    "float": C.c_float, "double": C.c_double, "uint8_t": C.c_uint8, "int": C.c_int,
+}
+
+
+def _strip_comments(t):
+    t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    return re.sub(r"//[^\n]*", "", t)
+
+
+def _parse_header(path):
+    text = _strip_comments(open(path).read())
+    consts = {}
+    for m in re.finditer(r"#define\s+(PBHC_\w+)\s+\(?(-?\d+)\)?", text):
+        consts[m.group(1)] = int(m.group(2))
+    for m in re.finditer(r"enum\s+(\w+)\s*\{(.*?)\}", text, flags=re.S):
+        val = -1
+        for item in m.group(2).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, v = [x.strip() for x in item.split("=")]
+                val = int(eval(v, {}, consts))
+            else:
+                name, val = item, val + 1
+            consts[name] = val
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*\1\s*;", text, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            mm = re.match(r"^(const\s+)?(\w+)\s*(\*?)\s*(.*)$", decl)
+            base, first_ptr, rest = mm.group(2), mm.group(3), mm.group(4)
+            variables = [v.strip() for v in rest.split(",")]
+            variables[0] = first_ptr + variables[0]
+            for var in variables:
+                is_ptr = var.startswith("*")
+                var = var.lstrip("* ")
+                dims = [int(eval(d, {}, consts)) for d in re.findall(r"\[([^\]]+)\]", var)]
+                vname = re.match(r"^(\w+)", var).group(1)
+                if is_ptr:
+                    ct = C.c_void_p
+                elif base in _CTYPES:
+                    ct = _CTYPES[base]
+                elif base in structs:
+                    ct = structs[base]
+                else:
+                    raise ValueError(f"unknown type {base} in {name}")
+                for d in reversed(dims):
+                    ct = ct * d
+                fields.append((vname, ct))
+        structs[name] = type(name, (C.Structure,), {"_fields_": fields})
+    return consts, structs
+
+
+K, _S = _parse_header(HEADER)
+PbhcSkeleton = _S["PbhcSkeleton"]
+PbhcOutMap = _S["PbhcOutMap"]
+PbhcEnvConfig = _S["PbhcEnvConfig"]
+PbhcMotionTable = _S["PbhcMotionTable"]
+PbhcStepIO = _S["PbhcStepIO"]
+
+EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
+           "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae"]
+
+
+class PbhcError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise PbhcError(
+            f"{LIB_PATH} not found: the HIP extension is required (there is no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pbhc_amd/csrc`."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.pbhc_last_error.restype = C.c_char_p
+    if lib.pbhc_abi_version() != K["PBHC_ABI_VERSION"]:
+        raise PbhcError("libpbhc_hip.so ABI version does not match include/pbhc_hip.h")
+    if lib.pbhc_sizeof_env_config() != C.sizeof(PbhcEnvConfig) or lib.pbhc_sizeof_step_io() != C.sizeof(PbhcStepIO):
+        raise PbhcError("struct layout mismatch between libpbhc_hip.so and include/pbhc_hip.h — rebuild")
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    lib.pbhc_motion_build.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, f, vp, vp, vp]
+    lib.pbhc_motion_state.argtypes = [C.POINTER(PbhcMotionTable), i, i, vp, vp, vp, i, vp, vp]
+    lib.pbhc_sim_fk.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp]
+    lib.pbhc_env_create.argtypes = [C.POINTER(PbhcEnvConfig), C.POINTER(PbhcMotionTable), vp, C.POINTER(vp)]
+    lib.pbhc_env_destroy.argtypes = [vp]
+    lib.pbhc_env_destroy.restype = None
+    lib.pbhc_env_step.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
+    lib.pbhc_gae.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise PbhcError(f"{what} failed ({rc}): {lib().pbhc_last_error().decode()}")
+
+
+def ptr(t):
+    """raw device pointer of a torch tensor; None -> NULL"""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, name, dtype=None, shape=None):
+    """host-side shape/dtype/device check before a raw pointer crosses the ABI"""
+    import torch
+
+    if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous()):
+        raise PbhcError(f"{name}: expected a contiguous CUDA(HIP) tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise PbhcError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise PbhcError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t

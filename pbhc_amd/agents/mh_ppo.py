@@ -1,0 +1,411 @@
+"""MHPPO — drop-in for the reference's KungfuBot PPO (multi-head / vector-reward critic).
+
+Same class surface as the reference (reference: humanoidverse/agents/mh_ppo/mh_ppo.py:26-775 on the
+BaseAlgo API agents/base_algo/base_algo.py:15-47): `__init__(env, config, log_dir=None, device)`,
+`setup()`, `load(path)`, `save(path, infos)`, `learn()`, `evaluate_policy()`, `inference_model`;
+checkpoint dict and state_dict key names are the reference's, so trained policies still export and
+deploy through the reference's tooling.  Select with
+`algo._target_: pbhc_amd.agents.mh_ppo.MHPPO`.
+
+MI355X-first differences (same maths, pinned by tests/golden/ppo_v1.npz):
+  * no host synchronisation inside an iteration: the adaptive-KL learning rate, the loss meters and
+    the episode statistics live on the device (`torch.where`, capturable Adam with tensor lr);
+  * GAE / head-summed advantage / normalisation run in `pbhc_gae` (HIP) on the `[T,N,R]` slab;
+  * the minibatch gather moves only the keys the update reads;
+  * envs shard over ranks (one process per GPU): ONE flat-bucket RCCL all-reduce of the actor+critic
+    gradients per optimiser step, plus two tiny all-reduces (advantage moments, KL mean) so that
+    every rank takes the same normalisation and learning-rate branch as one big batch would.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import deque
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import _lib
+from .modules import PPOActor, PPOCritic, RolloutStorage
+
+
+class _NullWriter:
+    def __getattr__(self, n):
+        return lambda *a, **k: None
+
+
+def _make_writer(log_dir):
+    if log_dir is None:
+        return _NullWriter()
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+
+        return SummaryWriter(log_dir=log_dir, flush_secs=10)
+    except Exception:
+        return _NullWriter()
+
+
+class MHPPO:
+    def __init__(self, env, config, log_dir=None, device="cpu"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PbhcError("pbhc_amd.agents.mh_ppo.MHPPO runs on the GPU only")
+        self.env = env
+        self.config = config
+        self.log_dir = log_dir
+        self.writer = _make_writer(log_dir)
+        self.start_time = self.stop_time = 0
+        self.collection_time = self.learn_time = 0
+        self._init_config()
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.ep_infos = []
+        self.rewbuffer = deque(maxlen=100)
+        self.lenbuffer = deque(maxlen=100)
+        N = self.env.num_envs
+        self.cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
+        self.cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
+        # device-side episode statistics: [sum of returns, sum of lengths, count] of finished episodes
+        self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        _ = self.env.reset_all()
+
+    def _init_config(self):
+        c = self.config
+        self.num_envs = self.env.num_envs
+        self.algo_obs_dim_dict = self.env.config.robot.algo_obs_dim_dict
+        self.num_act = self.env.config.robot.actions_dim
+        self.save_interval = c.save_interval
+        self.logging_interval = c.get("logging_interval", 10)
+        self.num_steps_per_env = c.num_steps_per_env
+        self.load_optimizer = c.load_optimizer
+        self.num_learning_iterations = c.num_learning_iterations
+        self.init_at_random_ep_len = c.init_at_random_ep_len
+        self.desired_kl = c.desired_kl
+        self.schedule = c.schedule
+        self.actor_learning_rate = c.actor_learning_rate
+        self.critic_learning_rate = c.critic_learning_rate
+        self.clip_param = c.clip_param
+        self.num_learning_epochs = c.num_learning_epochs
+        self.num_mini_batches = c.num_mini_batches
+        self.gamma = c.gamma
+        self.lam = c.lam
+        self.value_loss_coef = c.value_loss_coef
+        self.entropy_coef = c.entropy_coef
+        self.max_grad_norm = c.max_grad_norm
+        self.use_clipped_value_loss = c.use_clipped_value_loss
+        self.cfg_l2c2 = c.l2c2 if "l2c2" in c else None
+        self.num_rew_fn = self.env.num_rew_fn
+
+    # ------------------------------------------------------------------------------------
+    def setup(self):
+        self._setup_models_and_optimizer()
+        self._setup_storage()
+
+    def _setup_models_and_optimizer(self):
+        c = self.config
+        if "phase_embed" in c and c.phase_embed.type != "Original":
+            raise NotImplementedError("phase_embed actors are outside the hot path")
+        c.module_dict.critic["output_dim"][-1] = self.num_rew_fn
+        self.actor = PPOActor(obs_dim_dict=self.algo_obs_dim_dict, module_config_dict=c.module_dict.actor, num_actions=self.num_act,
+                              init_noise_std=c.init_noise_std).to(self.device)
+        self.critic = PPOCritic(obs_dim_dict=self.algo_obs_dim_dict, module_config_dict=c.module_dict.critic).to(self.device)
+        if self.world_size > 1:      # replicas start from rank 0's weights
+            for p in list(self.actor.parameters()) + list(self.critic.parameters()):
+                dist.broadcast(p.data, src=0)
+        self._lr_a = torch.tensor(float(self.actor_learning_rate), device=self.device)
+        self._lr_c = torch.tensor(float(self.critic_learning_rate), device=self.device)
+        self.actor_optimizer = optim.Adam(self.actor.parameters(), lr=self._lr_a, capturable=True, foreach=True)
+        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self._lr_c, capturable=True, foreach=True)
+        self._params = list(self.actor.parameters()) + list(self.critic.parameters())
+        self._grad_bucket = torch.zeros(sum(p.numel() for p in self._params), device=self.device)
+
+    def _setup_storage(self):
+        st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
+        self._need_next = bool(self.cfg_l2c2 is not None and self.cfg_l2c2.enable)
+        for k, d in self.algo_obs_dim_dict.items():
+            st.register_key(k, shape=(d,), dtype=torch.float)
+            if self._need_next:
+                st.register_key("next_" + k, shape=(d,), dtype=torch.float)
+        st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
+        st.register_key("rewards", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("dones", shape=(1,), dtype=torch.bool)
+        st.register_key("values", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("returns", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("advantages", shape=(1,), dtype=torch.float)
+        st.register_key("actions_log_prob", shape=(1,), dtype=torch.float)
+        st.register_key("action_mean", shape=(self.num_act,), dtype=torch.float)
+        st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
+        T, N = self.num_steps_per_env, self.env.num_envs
+        self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
+
+    def _eval_mode(self):
+        self.actor.eval(); self.critic.eval()
+
+    def _train_mode(self):
+        self.actor.train(); self.critic.train()
+
+    # ---- checkpoints: the reference's dict (mh_ppo.py:176-204) -----------------------------
+    def load(self, ckpt_path):
+        if ckpt_path is None:
+            return None
+        d = torch.load(ckpt_path, map_location=self.device, weights_only=False)   # our own / user-trusted checkpoint
+        self.actor.load_state_dict(d["actor_model_state_dict"])
+        self.critic.load_state_dict(d["critic_model_state_dict"])
+        if self.load_optimizer:
+            self.actor_optimizer.load_state_dict(d["actor_optimizer_state_dict"])
+            self.critic_optimizer.load_state_dict(d["critic_optimizer_state_dict"])
+            self.set_learning_rate(float(d["actor_optimizer_state_dict"]["param_groups"][0]["lr"]),
+                                   float(d["critic_optimizer_state_dict"]["param_groups"][0]["lr"]))
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def _opt_state_for_save(self, opt, lr):
+        sd = opt.state_dict()
+        for g in sd["param_groups"]:
+            g["lr"] = float(lr)              # the reference stores a python float
+        return sd
+
+    def save(self, path, infos=None):
+        torch.save({
+            "actor_model_state_dict": self.actor.state_dict(),
+            "critic_model_state_dict": self.critic.state_dict(),
+            "actor_optimizer_state_dict": self._opt_state_for_save(self.actor_optimizer, self._lr_a),
+            "critic_optimizer_state_dict": self._opt_state_for_save(self.critic_optimizer, self._lr_c),
+            "iter": self.current_learning_iteration,
+            "infos": infos,
+        }, path)
+
+    def set_learning_rate(self, actor_learning_rate, critic_learning_rate):
+        self.actor_learning_rate, self.critic_learning_rate = actor_learning_rate, critic_learning_rate
+        self._lr_a.fill_(float(actor_learning_rate))
+        self._lr_c.fill_(float(critic_learning_rate))
+
+    # ---- learn loop (mh_ppo.py:206-250) ----------------------------------------------------
+    def learn(self, num_iterations=None):
+        if self.init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs_dict = self.env.reset_all()
+        self._train_mode()
+        n = self.num_learning_iterations if num_iterations is None else num_iterations
+        tot_iter = self.current_learning_iteration + n
+        for it in range(self.current_learning_iteration, tot_iter):
+            self.start_time = time.time()
+            obs_dict = self._rollout_step(obs_dict)
+            loss_dict = self._training_step()
+            self.stop_time = time.time()
+            self.learn_time = self.stop_time - self.start_time
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
+                                          num_learning_iterations=n))
+            if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
+                self.current_learning_iteration = it
+                self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+            self.ep_infos.clear()
+        self.current_learning_iteration = tot_iter
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def _actor_act_step(self, obs_dict):
+        return self.actor.act(obs_dict["actor_obs"])
+
+    def _critic_eval_step(self, obs_dict):
+        return self.critic.evaluate(obs_dict["critic_obs"])
+
+    def _rollout_step(self, obs_dict):
+        st = self.storage
+        with torch.inference_mode():
+            for _ in range(self.num_steps_per_env):
+                actions = self._actor_act_step(obs_dict)
+                values = self._critic_eval_step(obs_dict)
+                for k in obs_dict:
+                    st.update_key(k, obs_dict[k])
+                st.update_key("actions", actions)
+                st.update_key("action_mean", self.actor.action_mean)
+                st.update_key("action_sigma", self.actor.action_std)
+                st.update_key("actions_log_prob", self.actor.get_actions_log_prob(actions).unsqueeze(1))
+                st.update_key("values", values)
+                obs_dict, rewards, dones, infos = self.env.step({"actions": actions})
+                if self._need_next:
+                    for k in obs_dict:
+                        st.update_key("next_" + k, obs_dict[k])
+                rew = rewards.reshape(self.env.num_envs, self.num_rew_fn)
+                # bootstrap on time-outs (mh_ppo.py:300-305)
+                stored = rew + self.gamma * values * infos["time_outs"].unsqueeze(1)
+                st.update_key("rewards", stored)
+                st.update_key("dones", dones.unsqueeze(1))
+                st.increment_step()
+                # episode book-keeping on the device (reference: per-step .cpu() round trip, :311-323)
+                self.cur_reward_sum += rew.sum(dim=-1)
+                self.cur_episode_length += 1
+                done_f = (dones > 0).to(torch.float64)
+                self._ep_stats[0] += (self.cur_reward_sum.double() * done_f).sum()
+                self._ep_stats[1] += (self.cur_episode_length.double() * done_f).sum()
+                self._ep_stats[2] += done_f.sum()
+                keep = (dones == 0).float()
+                self.cur_reward_sum *= keep
+                self.cur_episode_length *= keep
+            self.stop_time = time.time()
+            self.collection_time = self.stop_time - self.start_time
+            self.start_time = self.stop_time
+            self._compute_returns(obs_dict)
+        return obs_dict
+
+    def _compute_returns(self, last_obs_dict):
+        """mh_ppo.py:348-395 in one HIP pass over the [T,N,R] slab."""
+        st = self.storage
+        last_values = self.critic.evaluate(last_obs_dict["critic_obs"]).detach().contiguous()
+        T, N, R = self.num_steps_per_env, self.env.num_envs, self.num_rew_fn
+        adv = st.advantages
+        _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,
+                                       float(self.gamma), float(self.lam), st.returns.data_ptr(), adv.data_ptr(), self._gae_stats.data_ptr(),
+                                       _lib.current_stream()), "pbhc_gae")
+        if self.world_size > 1:
+            # same normalisation as one big batch: undo the local one, re-normalise with global moments
+            nb = (T * N + 255) // 256
+            mean_l, std_l = self._gae_stats[2 * nb].float(), self._gae_stats[2 * nb + 1].float()
+            raw = adv * (std_l + 1e-8) + mean_l
+            n = torch.tensor(float(T * N), dtype=torch.float64, device=self.device)
+            mom = torch.stack([raw.double().sum(), (raw.double() ** 2).sum(), n])
+            dist.all_reduce(mom)
+            mean = mom[0] / mom[2]
+            var = (mom[1] - mom[2] * mean * mean) / (mom[2] - 1.0)
+            adv.copy_((raw - mean.float()) / (var.clamp(min=0).sqrt().float() + 1e-8))
+        return st.returns, adv
+
+    # ---- update (mh_ppo.py:397-533) --------------------------------------------------------
+    UPDATE_KEYS = ["actor_obs", "critic_obs", "actions", "values", "advantages", "returns", "actions_log_prob", "action_mean", "action_sigma"]
+
+    def _training_step(self, indices=None):
+        loss = {k: torch.zeros((), device=self.device) for k in ["Value", "Surrogate", "Entropy", "L2C2_Value", "L2C2_Policy"]}
+        keys = list(self.UPDATE_KEYS)
+        if self._need_next:
+            keys += ["next_actor_obs", "next_critic_obs"]
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=keys, indices=indices):
+            self._update_ppo(batch, loss)
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        self.actor_learning_rate = self._lr_a        # tensors; read back lazily by the logger
+        self.critic_learning_rate = self._lr_c
+        return {k: v / n for k, v in loss.items()}
+
+    def _allreduce_grads(self):
+        """ONE RCCL all-reduce of the flat actor+critic gradient bucket (≈5 MB fp32), then average."""
+        flat = self._grad_bucket
+        o = 0
+        for p in self._params:
+            n = p.numel()
+            flat[o:o + n].copy_(p.grad.reshape(-1))
+            o += n
+        dist.all_reduce(flat)
+        flat.div_(self.world_size)
+        o = 0
+        for p in self._params:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+
+    def _update_ppo(self, b, loss):
+        self.actor.update_distribution(b["actor_obs"])
+        logp = self.actor.get_actions_log_prob(b["actions"])
+        value = self.critic.evaluate(b["critic_obs"])
+        mu, sigma, entropy = self.actor.action_mean, self.actor.action_std, self.actor.entropy
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            with torch.no_grad():
+                old_s, old_m = b["action_sigma"], b["action_mean"]
+                kl = torch.sum(torch.log(sigma / old_s + 1.0e-5) + (old_s.square() + (old_m - mu).square()) / (2.0 * sigma.square()) - 0.5, axis=-1)
+                kl_mean = kl.mean()
+                if self.world_size > 1:
+                    dist.all_reduce(kl_mean)
+                    kl_mean = kl_mean / self.world_size
+                up = kl_mean > self.desired_kl * 2.0
+                down = (kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0)
+                for lr in (self._lr_a, self._lr_c):
+                    lr.copy_(torch.where(up, torch.clamp(lr / 1.5, min=1e-5), torch.where(down, torch.clamp(lr * 1.5, max=1e-2), lr)))
+        adv = b["advantages"].squeeze(-1)
+        ratio = torch.exp(logp - b["actions_log_prob"].squeeze(-1))
+        surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            vclip = b["values"] + (value - b["values"]).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - b["returns"]).pow(2), (vclip - b["returns"]).pow(2)).sum(dim=-1).mean()
+        else:
+            value_loss = (b["returns"] - value).pow(2).sum(dim=-1).mean()
+        entropy_loss = entropy.mean()
+        l2c2_v = torch.zeros((), device=self.device)
+        l2c2_p = torch.zeros((), device=self.device)
+        if self._need_next:
+            u = torch.rand(*b["actor_obs"].shape[:-1], 1, device=self.device) * 2 - 1
+            u_mu = self.actor.act_inference(b["actor_obs"] + u * (b["next_actor_obs"] - b["actor_obs"]))
+            u_val = self.critic.evaluate(b["critic_obs"] + u * (b["next_critic_obs"] - b["critic_obs"]))
+            l2c2_v = self.cfg_l2c2.lambda_value * (value - u_val).pow(2).mean()
+            l2c2_p = self.cfg_l2c2.lambda_policy * (b["actions"] - u_mu).pow(2).mean()
+        actor_loss = surrogate - self.entropy_coef * entropy_loss + l2c2_p
+        critic_loss = self.value_loss_coef * value_loss + l2c2_v
+        self.actor_optimizer.zero_grad(set_to_none=False)
+        self.critic_optimizer.zero_grad(set_to_none=False)
+        actor_loss.backward()
+        critic_loss.backward()
+        if self.world_size > 1:
+            self._allreduce_grads()
+        nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm, foreach=True)
+        nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm, foreach=True)
+        self.actor_optimizer.step()
+        self.critic_optimizer.step()
+        with torch.no_grad():
+            loss["Value"] += value_loss.detach(); loss["Surrogate"] += surrogate.detach(); loss["Entropy"] += entropy_loss.detach()
+            loss["L2C2_Value"] += l2c2_v.detach(); loss["L2C2_Policy"] += l2c2_p.detach()
+        return loss
+
+    # ---- evaluation / export surface --------------------------------------------------------
+    @property
+    def inference_model(self):
+        return {"actor": self.actor, "critic": self.critic}
+
+    def get_example_obs(self):
+        obs = self.env.reset_all()
+        return {k: v.clone() for k, v in obs.items()}
+
+    @torch.no_grad()
+    def evaluate_policy_steps(self, Nsteps):
+        self._eval_mode()
+        self.env.set_is_evaluating()
+        obs = self.env.reset_all()
+        for _ in range(Nsteps):
+            obs, _, _, _ = self.env.step({"actions": self.actor.act_inference(obs["actor_obs"])})
+        return obs
+
+    def evaluate_policy(self):
+        return self.evaluate_policy_steps(int(self.env.max_episode_length))
+
+    # ---- logging (mh_ppo.py:547-700, reduced to the Perf/* + Loss/* + Train/* scalars) ------
+    def _post_epoch_logging(self, log, width=80, pad=40):
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.world_size
+        it_time = log["collection_time"] + log["learn_time"]
+        self.tot_time += it_time
+        if log["it"] % self.logging_interval != 0 or self.rank != 0:
+            return
+        stats = self._ep_stats.tolist()           # the only read-back, once per logging interval
+        self._ep_stats.zero_()
+        fps = int(self.num_steps_per_env * self.env.num_envs * self.world_size / max(it_time, 1e-9))
+        it = log["it"]
+        w = self.writer
+        for k, v in log["loss_dict"].items():
+            w.add_scalar("Loss/" + k, float(v), it)
+        w.add_scalar("Loss/actor_learning_rate", float(self._lr_a), it)
+        w.add_scalar("Loss/critic_learning_rate", float(self._lr_c), it)
+        w.add_scalar("Policy/mean_noise_std", float(self.actor.std.mean()), it)
+        w.add_scalar("Perf/total_fps", fps, it)
+        w.add_scalar("Perf/collection_time", log["collection_time"], it)
+        w.add_scalar("Perf/learning_time", log["learn_time"], it)
+        if stats[2] > 0:
+            w.add_scalar("Train/mean_reward", stats[0] / stats[2], it)
+            w.add_scalar("Train/mean_episode_length", stats[1] / stats[2], it)
+        envlog = self.env.read_log() if hasattr(self.env, "read_log") else {}
+        for k, v in envlog.items():
+            w.add_scalar("Env/" + k, float(v), it)
+        print(f"[it {it}] fps {fps}  collect {log['collection_time']:.3f}s  learn {log['learn_time']:.3f}s  "
+              f"value {float(log['loss_dict']['Value']):.4f}  surr {float(log['loss_dict']['Surrogate']):.4f}  "
+              f"lr {float(self._lr_a):.2e}  ep_rew {stats[0] / max(stats[2], 1):.3f}  ep_len {stats[1] / max(stats[2], 1):.1f}", flush=True)

@@ -1,0 +1,166 @@
+"""Actor / critic networks and the rollout buffer of the MHPPO agent (PyTorch-ROCm).
+
+Plain `nn.Linear` stacks so that `state_dict()` keys equal the reference's
+(`std`, `actor_module.module.{0,2,4,6}.{weight,bias}`, `critic_module.module.*`) and checkpoints load
+both ways with `strict=True` (reference: humanoidverse/agents/modules/modules.py:5-66,
+ppo_modules.py:11-99, data_utils.py:22-152).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+
+class BaseModule(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict):
+        super().__init__()
+        self.obs_dim_dict = obs_dim_dict
+        self.module_config_dict = module_config_dict
+        self.input_dim = 0
+        for each in module_config_dict["input_dim"]:
+            if each in obs_dim_dict:
+                self.input_dim += obs_dim_dict[each]
+            elif isinstance(each, (int, float)):
+                self.input_dim += each
+            else:
+                raise ValueError(f"_calculate_input_dim - Unknown input type: {each}")
+        self.output_dim = 0
+        for each in module_config_dict["output_dim"]:
+            if isinstance(each, (int, float)):
+                self.output_dim += each
+            else:
+                raise ValueError(f"_calculate_output_dim - Unknown output type: {each}")
+        lc = module_config_dict["layer_config"]
+        if lc["type"] != "MLP":
+            raise NotImplementedError(f"Unsupported layer type: {lc['type']}")
+        hidden = list(lc["hidden_dims"])
+        act = getattr(nn, lc["activation"])()
+        layers = [nn.Linear(self.input_dim, hidden[0]), act]
+        for l in range(len(hidden)):
+            if l == len(hidden) - 1:
+                layers.append(nn.Linear(hidden[l], self.output_dim))
+            else:
+                layers.append(nn.Linear(hidden[l], hidden[l + 1]))
+                layers.append(act)
+        self.module = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.module(x)
+
+
+class PPOActor(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict, num_actions, init_noise_std):
+        super().__init__()
+        for i, od in enumerate(module_config_dict["output_dim"]):
+            if od == "robot_action_dim":
+                module_config_dict["output_dim"][i] = num_actions
+        self.actor_module = BaseModule(obs_dim_dict, module_config_dict)
+        self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        Normal.set_default_validate_args = False
+
+    @property
+    def actor(self):
+        return self.actor_module
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def update_distribution(self, actor_obs):
+        mean = self.actor(actor_obs)
+        self.distribution = Normal(mean, mean * 0.0 + self.std)
+
+    def act(self, actor_obs, **kwargs):
+        self.update_distribution(actor_obs)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, actor_obs):
+        return self.actor(actor_obs)
+
+
+class PPOCritic(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict):
+        super().__init__()
+        self.critic_module = BaseModule(obs_dim_dict, module_config_dict)
+
+    @property
+    def critic(self):
+        return self.critic_module
+
+    def reset(self, dones=None):
+        pass
+
+    def evaluate(self, critic_obs, **kwargs):
+        return self.critic(critic_obs)
+
+
+class RolloutStorage(nn.Module):
+    """`[T, N, C]` buffers, contiguous in the env axis per step (one coalesced slab per key and step)."""
+
+    def __init__(self, num_envs, num_transitions_per_env, device="cuda"):
+        super().__init__()
+        self.device = device
+        self.num_transitions_per_env = num_transitions_per_env
+        self.num_envs = num_envs
+        self.step = 0
+        self.stored_keys = []
+
+    def register_key(self, key, shape=(), dtype=torch.float):
+        assert not hasattr(self, key), key
+        assert isinstance(shape, (list, tuple)), "shape must be a list or tuple"
+        buf = torch.zeros((self.num_transitions_per_env, self.num_envs) + tuple(shape), dtype=dtype, device=self.device)
+        self.register_buffer(key, buf, persistent=False)
+        self.stored_keys.append(key)
+
+    def increment_step(self):
+        self.step += 1
+
+    def update_key(self, key, data):
+        assert not data.requires_grad
+        assert self.step < self.num_transitions_per_env, "Rollout buffer overflow"
+        getattr(self, key)[self.step].copy_(data)
+
+    def batch_update_data(self, key, data):
+        assert not data.requires_grad
+        getattr(self, key)[:] = data
+
+    def clear(self):
+        self.step = 0
+
+    def query_key(self, key):
+        assert hasattr(self, key), key
+        return getattr(self, key)
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8, keys=None, indices=None):
+        """One permutation per call, the same contiguous slices every epoch (data_utils.py:134-152).
+        `keys` restricts the gather to what the update reads (the reference gathers every key)."""
+        batch_size = self.num_envs * self.num_transitions_per_env
+        mb = batch_size // num_mini_batches
+        if indices is None:
+            indices = torch.randperm(batch_size, device=self.device)
+        keys = self.stored_keys if keys is None else keys
+        shuffled = {k: getattr(self, k).flatten(0, 1)[indices].contiguous() for k in keys}
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                yield {k: v[i * mb:(i + 1) * mb] for k, v in shuffled.items()}

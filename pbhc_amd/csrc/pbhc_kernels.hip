@@ -1,0 +1,1076 @@
+// pbhc_kernels.hip — hand-written gfx950 (CDNA4) kernels + the C ABI of include/pbhc_hip.h.
+//
+// Hot path: one fused launch per control step (k_env_step) + a 1-block finalize.  Mapping:
+// 32 lanes (half a wave64) own one env, lane <-> body / dof / obs element; PBHC_EPB envs per
+// 128-thread workgroup, so 4096 envs = 1024 workgroups = 4 per CU.  Per-env rows are read and
+// written as contiguous rows (reference [N,C] layouts, which is also what the MLP GEMMs consume);
+// the joint chain, the reference frames and the feature row are staged in LDS.
+// This is HBM-bound float work: no MFMA on purpose.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+
+#include "../../include/pbhc_hip.h"
+#include "pbhc_math.h"
+
+using namespace pbhc;
+
+#define PBHC_G 32     // lanes per env
+#define PBHC_EPB 4    // envs per workgroup
+#define PBHC_NP 48    // partial sums per workgroup
+
+static thread_local char g_err[512] = "";
+#define HIP_CHECK(x)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess) {                                                                   \
+      snprintf(g_err, sizeof(g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      return PBHC_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+#define ARG_CHECK(c)                                                                    \
+  do {                                                                                  \
+    if (!(c)) {                                                                         \
+      snprintf(g_err, sizeof(g_err), "%s:%d bad argument: %s", __FILE__, __LINE__, #c); \
+      return PBHC_EINVAL;                                                               \
+    }                                                                                   \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// partial-sum columns written per workgroup by k_env_step, reduced by k_env_finalize
+enum {
+  P_ERR = 0,            // [10] tracking errors (adaptive sigma)
+  P_UPPER_NORM = 10, P_LOWER_NORM, P_VR_NORM, P_JOINT_NORM, P_CLIP_CNT, P_RESET_CNT, P_TERM_GRAVITY, P_TERM_FAR,
+  P_TERM_TIMEOUT, P_TERM_END, P_RESET_EPLEN, P_ETR_SUM, P_ETR_SQ, P_REW_SUM,
+  P_NUM
+};
+static_assert(P_NUM <= PBHC_NP, "partials");
+
+// reduction slots per env (LDS)
+enum {
+  R_UP = 0, R_LO, R_VR, R_FEET, R_ROT, R_VEL, R_ANG, R_MAXNORM, R_UPN, R_LON, R_VRN,
+  R_MAXJP, R_JP2, R_JV2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
+  R_NUM
+};
+
+// per-env LDS layout (floats)
+struct Lds {
+  enum {
+    ACT = 0, ACTD = 32, TAU = 64, Q = 96, QD = 128, RDOF = 160, RDOFV = 192,          // 7 x 32
+    ROOT = 224,                                                                      // 16
+    MISC = 240,                                                                      // 48: scalars
+    CF = 288,                                                                        // 120 contact forces
+    BP = 408, BQ = 528, BV = 688, BW = 808,                                          // body pos3/quat4/vel3/ang3 x40
+    RP = 928, RQ = 1048, RV = 1208, RW = 1328,                                       // reference, same shapes
+    RED = 1448,                                                                      // 32
+    FEAT = 1480
+  };
+};
+// MISC slots
+enum {
+  M_HINV = 0,   // 4 heading-inverse quaternion
+  M_TIME = 4, M_PHASE, M_MLEN, M_START, M_RESET, M_TIMEOUT, M_EPLEN, M_CONTACT0, M_CONTACT1, M_CFILT0, M_CFILT1,
+  M_RCONTACT0, M_RCONTACT1, M_GRAV, M_FAR, M_END, M_TOUT_LEN, M_LASTEP, M_NEWSTART, M_DELAY, M_FAT0, M_FAT1,
+  M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ
+};
+
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 32));
+  return v;
+}
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f4 ld4(const float* p) { return mk4(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ void st4(float* p, f4 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// ---- rigid-body FK of one body from its parent (what Isaac Gym's rigid-body state tensor held in
+// the reference, isaacgym.py:574-605; same chain as forward_kinematics_batch
+// torch_humanoid_batch.py:248-252 with pose_aa = axis*q, twist propagated analytically) ----------
+__device__ __forceinline__ void fk_body(const PbhcSkeleton& sk, int b, const float* q, const float* qd, float* bp, float* bq, float* bv, float* bw) {
+  int p = sk.parent[b];
+  int d = b - 1;
+  f3 pp = ld3(bp + 3 * p), pv = ld3(bv + 3 * p), pw = ld3(bw + 3 * p);
+  f4 pq = ld4(bq + 4 * p);
+  f3 off = mk3(sk.offset[b][0], sk.offset[b][1], sk.offset[b][2]);
+  f3 axis = mk3(sk.dof_axis[d][0], sk.dof_axis[d][1], sk.dof_axis[d][2]);
+  f3 pos = add3(pp, quat_rotate(pq, off));
+  f4 lq = mk4(sk.local_rot_wxyz[b][1], sk.local_rot_wxyz[b][2], sk.local_rot_wxyz[b][3], sk.local_rot_wxyz[b][0]);
+  f4 qj = quat_from_angle_axis(q[d], axis);
+  f4 rq = quat_unit(quat_mul(pq, quat_mul(lq, qj)));
+  f3 w = add3(pw, mul3(quat_rotate(rq, axis), qd[d]));
+  f3 v = add3(pv, cross3(pw, sub3(pos, pp)));
+  st3(bp + 3 * b, pos); st4(bq + 4 * b, rq); st3(bv + 3 * b, v); st3(bw + 3 * b, w);
+}
+
+// level-synchronous chain over the B real bodies; all threads of the workgroup must call it
+__device__ __forceinline__ void fk_chain(const PbhcSkeleton& sk, int lane, bool valid, const float* root, const float* q, const float* qd,
+                                         float* bp, float* bq, float* bv, float* bw) {
+  if (valid && lane == 0) {
+    st3(bp, ld3(root)); st4(bq, ld4(root + 3)); st3(bv, ld3(root + 7)); st3(bw, ld3(root + 10));
+  }
+  __syncthreads();
+  for (int lvl = 1; lvl <= sk.max_depth; ++lvl) {
+    if (valid)
+      for (int b = lane; b < sk.num_bodies; b += PBHC_G)
+        if (sk.depth[b] == lvl) fk_body(sk, b, q, qd, bp, bq, bv, bw);
+    __syncthreads();
+  }
+}
+
+// ---- frame blend (motion_lib_base.py:503-513) -------------------------------------------------
+__device__ __forceinline__ void frame_blend(float t, float len, int nf, float dt, int* f0, int* f1, float* blend) {
+  float phase = clampf(t / len, 0.0f, 1.0f);
+  if (t < 0.0f) t = 0.0f;
+  int i0 = (int)(phase * (float)(nf - 1));
+  int i1 = min(i0 + 1, nf - 1);
+  *f0 = i0; *f1 = i1;
+  *blend = clampf((t - (float)i0 * dt) / dt, 0.0f, 1.0f);
+}
+
+// ---- phase lookup of one env: lerp/slerp of the two packed frame rows into LDS
+// (MotionLibBase.get_motion_state motion_lib_base.py:123-259) ------------------------------------
+__device__ __forceinline__ void motion_lookup(const PbhcMotionTable& tbl, int D, int Bx, int lane, int mid, float t, f3 off, bool bodies,
+                                              float* rdof, float* rdofv, float* rcontact, float* rp, float* rq, float* rv, float* rw) {
+  int f0, f1; float b;
+  frame_blend(t, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &b);
+  const float* r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
+  const float* r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+  float a = 1.0f - b;
+  for (int d = lane; d < D; d += PBHC_G) {
+    rdof[d] = a * r0[d] + b * r1[d];
+    rdofv[d] = a * r0[D + d] + b * r1[D + d];
+  }
+  if (lane < 2) rcontact[lane] = a * r0[2 * D + lane] + b * r1[2 * D + lane];
+  int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+  int nb = bodies ? Bx : 1;
+  for (int i = lane; i < nb; i += PBHC_G) {
+    f3 p0 = ld3(r0 + o_pos + 3 * i), p1 = ld3(r1 + o_pos + 3 * i);
+    st3(rp + 3 * i, mk3(a * p0.x + b * p1.x + off.x, a * p0.y + b * p1.y + off.y, a * p0.z + b * p1.z + off.z));
+    st4(rq + 4 * i, slerp(ld4(r0 + o_rot + 4 * i), ld4(r1 + o_rot + 4 * i), b));
+    f3 v0 = ld3(r0 + o_vel + 3 * i), v1 = ld3(r1 + o_vel + 3 * i);
+    st3(rv + 3 * i, mk3(a * v0.x + b * v1.x, a * v0.y + b * v1.y, a * v0.z + b * v1.z));
+    f3 w0 = ld3(r0 + o_ang + 3 * i), w1 = ld3(r1 + o_ang + 3 * i);
+    st3(rw + 3 * i, mk3(a * w0.x + b * w1.x, a * w0.y + b * w1.y, a * w0.z + b * w1.z));
+  }
+}
+
+// =================================================================================================
+//  k_env_step: LeggedRobotBase.step (legged_robot_base.py:239-338) for LeggedRobotMotionTracking
+// =================================================================================================
+extern __shared__ float smem[];
+
+__global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
+                                                              const double* __restrict__ glob, float* __restrict__ partials,
+                                                              int lds_stride, uint32_t step_ctr) {
+  const PbhcEnvConfig& c = *cfgp;
+  const PbhcSkeleton& sk = c.skel;
+  const int N = c.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
+  const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G;
+  const int env = blockIdx.x * PBHC_EPB + le;
+  const bool valid = env < N;
+  float* S = smem + (size_t)le * lds_stride;
+  float *act = S + Lds::ACT, *actd = S + Lds::ACTD, *tau = S + Lds::TAU, *q = S + Lds::Q, *qd = S + Lds::QD;
+  float *rdof = S + Lds::RDOF, *rdofv = S + Lds::RDOFV, *root = S + Lds::ROOT, *misc = S + Lds::MISC, *cf = S + Lds::CF;
+  float *bp = S + Lds::BP, *bq = S + Lds::BQ, *bv = S + Lds::BV, *bw = S + Lds::BW;
+  float *rp = S + Lds::RP, *rq = S + Lds::RQ, *rv = S + Lds::RV, *rw = S + Lds::RW;
+  float *red = S + Lds::RED, *feat = S + Lds::FEAT;
+  float* blockpart = smem + (size_t)PBHC_EPB * lds_stride;   // [EPB][PBHC_NP]
+  const float dt = c.dt;
+  const size_t eD = (size_t)env * D;
+
+  // ---------------- phase A: _pre_physics_step (motion_tracking.py:749-768), torques from the
+  // pre-step state (legged_robot_base.py:795-838), then the replay frame lands ------------------
+  float clipcnt = 0.0f;
+  if (valid) {
+    const int Q = c.queue_len;
+    const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
+    for (int d = lane; d < D; d += PBHC_G) {
+      float a = clampf(io.actions_in[eD + d], -c.action_clip_value, c.action_clip_value);
+      if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
+      act[d] = a;
+      float delayed = a;
+      if (c.randomize_ctrl_delay) {
+        float* qu = io.action_queue + (size_t)env * Q * D + d;
+        float prev = a;
+        for (int k = 0; k < Q; ++k) {          // queue[k] <- queue[k-1], queue[0] <- a
+          float old = qu[(size_t)k * D];
+          qu[(size_t)k * D] = prev;
+          if (k == didx) delayed = prev;
+          prev = old;
+        }
+      }
+      actd[d] = delayed;
+      float qp = io.dof_state[(eD + d) * 2], qv = io.dof_state[(eD + d) * 2 + 1];
+      float tl = c.torque_limits[d];
+      float tq = io.kp_scale[eD + d] * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) -
+                 io.kd_scale[eD + d] * c.d_gains[d] * qv;
+      if (c.randomize_torque_rfi) {
+        float u = io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(c.seed, env, step_ctr, 1, d);
+        tq = tq + (u * 2.0f - 1.0f) * c.rfi_lim * io.rfi_lim_scale[eD + d] * tl;
+      }
+      if (c.use_rao) tq = tq + io.rao_scale[eD + d] * tl;
+      if (c.clip_torques) tq = clampf(tq, -tl, tl);
+      tau[d] = tq;
+      q[d] = io.frame_dof_pos[eD + d];
+      qd[d] = io.frame_dof_vel[eD + d];
+    }
+    if (lane < 13) root[lane] = io.frame_root[(size_t)env * 13 + lane];
+    for (int i = lane; i < B * 3; i += PBHC_G) cf[i] = io.frame_contact[(size_t)env * B * 3 + i];
+    // old history + static DR features into the feature row
+    const int hoff = c.feat_off[PBHC_F_HISTORY];
+    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = io.hist[(size_t)env * c.hist_dim + i];
+    if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = io.dr_base_com[(size_t)env * 3 + lane];
+    for (int i = lane; i < c.dr_link_mass_dim; i += PBHC_G) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + i] = io.dr_link_mass[(size_t)env * c.dr_link_mass_dim + i];
+    if (lane == 0) {
+      feat[c.feat_off[PBHC_F_DR_FRICTION]] = io.dr_friction[env];
+      feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
+      misc[M_FAT0] = io.feet_air_time[(size_t)env * NF + 0];
+      misc[M_FAT1] = NF > 1 ? io.feet_air_time[(size_t)env * NF + 1] : 0.0f;
+      misc[M_LASTC0] = io.last_contacts[(size_t)env * NF + 0];
+      misc[M_LASTC1] = NF > 1 ? io.last_contacts[(size_t)env * NF + 1] : 0.0f;
+    }
+  }
+  clipcnt = group_sum(clipcnt);
+  __syncthreads();
+
+  // ---------------- phase B: rigid-body state of the new frame (sim-stub FK) -------------------
+  fk_chain(sk, lane, valid, root, q, qd, bp, bq, bv, bw);
+  // extended bodies (motion_tracking.py:619-643): p = R_ext(R_par off) + p_par, q = q_par*q_ext,
+  // w = w_par, v = v_par + w_par x off (offset NOT rotated, sic)
+  if (valid)
+    for (int b = B + lane; b < Bx; b += PBHC_G) {
+      int p = sk.parent[b];
+      f3 off = mk3(sk.offset[b][0], sk.offset[b][1], sk.offset[b][2]);
+      f4 eq = mk4(sk.local_rot_wxyz[b][1], sk.local_rot_wxyz[b][2], sk.local_rot_wxyz[b][3], sk.local_rot_wxyz[b][0]);
+      f4 pq = ld4(bq + 4 * p);
+      f3 pw = ld3(bw + 3 * p);
+      st3(bp + 3 * b, add3(quat_rotate(eq, quat_rotate(pq, off)), ld3(bp + 3 * p)));
+      st4(bq + 4 * b, quat_mul(pq, eq));
+      st3(bw + 3 * b, pw);
+      st3(bv + 3 * b, add3(ld3(bv + 3 * p), cross3(pw, off)));
+    }
+
+  // ---------------- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference
+  // frame motion_tracking.py:554,588) ----------------------------------------------------------
+  if (valid) {
+    f4 rq4 = ld4(root + 3);
+    if (lane == 0) {
+      long long ep = io.episode_length_buf[env] + 1;
+      misc[M_EPLEN] = (float)ep;
+      float start = io.motion_start_times[env];
+      float mlen = io.motion_len[env];
+      misc[M_START] = start; misc[M_MLEN] = mlen;
+      float t = (float)(ep + 1) * dt + start;
+      misc[M_TIME] = t;
+      misc[M_PHASE] = t / mlen;
+      feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
+      f3 e = euler_xyz(rq4);
+      misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
+      feat[c.feat_off[PBHC_F_RELYAW]] = e.z - c.ref_init_yaw;
+      feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];
+      st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
+    } else if (lane == 1) {
+      st3(feat + c.feat_off[PBHC_F_BASE_LIN_VEL], quat_rotate_inverse(rq4, ld3(root + 7)));
+    } else if (lane == 2) {
+      st3(feat + c.feat_off[PBHC_F_BASE_ANG_VEL], quat_rotate_inverse(rq4, ld3(root + 10)));
+    } else if (lane == 3) {
+      f3 g = quat_rotate_inverse(rq4, mk3(0.0f, 0.0f, -1.0f));
+      st3(feat + c.feat_off[PBHC_F_PROJECTED_GRAVITY], g);
+      misc[M_GX] = g.x; misc[M_GY] = g.y; misc[M_GZ] = g.z;
+    } else if (lane >= 4 && lane < 4 + NF) {
+      int f = lane - 4;
+      float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
+      float lastc = io.last_contacts[(size_t)env * NF + f];
+      misc[M_CONTACT0 + f] = cn;
+      misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase D: reference frame (a6) ------------------------------------------------
+  int mid = 0;
+  f3 origin = mk3(0.f, 0.f, 0.f);
+  if (valid) {
+    mid = (int)io.motion_ids[env];
+    origin = ld3(io.env_origins + (size_t)env * 3);
+    motion_lookup(tbl, D, Bx, lane, mid, misc[M_TIME], origin, true, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
+  }
+  __syncthreads();
+
+  // ---------------- phase E: tracking differences + lane-parallel partial sums -------------------
+  // (motion_tracking.py:645-731 and the reductions of the _reward_* terms)
+  float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
+  float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
+  if (valid) {
+    f4 hinv = ld4(misc + M_HINV);
+    f3 rootp = ld3(root);
+    const int o_dif = c.feat_off[PBHC_F_DIF_LOCAL_RIGID_BODY_POS], o_loc = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_POS];
+    const int o_vr = c.feat_off[PBHC_F_VR_3POINT_POS], o_lv = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_VEL], o_gv = c.feat_off[PBHC_F_GLOBAL_REF_RIGID_BODY_VEL];
+    for (int b = lane; b < Bx; b += PBHC_G) {
+      f3 rpos = ld3(rp + 3 * b);
+      f3 dp = sub3(rpos, ld3(bp + 3 * b));
+      float n2 = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
+      float msq = n2 / 3.0f;
+      float nrm = sqrtf(n2);
+      int fl = c.body_flags[b];
+      if (fl & 1) { s_up += msq; s_upn += nrm; }
+      if (fl & 2) { s_lo += msq; s_lon += nrm; }
+      if (fl & 4) { s_vr += msq; s_vrn += nrm; }
+      if (fl & 8) s_feet += msq;
+      s_maxn = fmaxf(s_maxn, nrm);
+      f4 dq = ld4(rq + 4 * b), cq = ld4(bq + 4 * b);
+      float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (:651)
+      s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) / 4.0f;
+      f3 dv = sub3(ld3(rv + 3 * b), ld3(bv + 3 * b));
+      s_vel += (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) / 3.0f;
+      f3 dw3 = sub3(ld3(rw + 3 * b), ld3(bw + 3 * b));
+      s_ang += (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) / 3.0f;
+      st3(feat + o_dif + 3 * b, quat_rotate(hinv, dp));
+      f3 gl = sub3(rpos, rootp);
+      f3 loc = quat_rotate(hinv, gl);
+      st3(feat + o_loc + 3 * b, loc);
+      if (c.track_slot[b] >= 0) st3(feat + o_vr + 3 * c.track_slot[b], loc);
+      f3 rvel = ld3(rv + 3 * b);
+      st3(feat + o_gv + 3 * b, rvel);
+      st3(feat + o_lv + 3 * b, quat_rotate(hinv, rvel));
+    }
+    const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
+    const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
+    for (int d = lane; d < D; d += PBHC_G) {
+      float dj = rdof[d] - q[d], djv = rdofv[d] - qd[d];
+      feat[o_dja + d] = dj; feat[o_djv + d] = djv;
+      s_maxjp = fmaxf(s_maxjp, fabsf(dj));
+      s_jp2 += dj * dj; s_jv2 += djv * djv;
+      s_tau2 += tau[d] * tau[d];
+      float la = io.last_actions[eD + d] - act[d];
+      s_ar += la * la;
+      s_qd2 += qd[d] * qd[d];
+      float acc = (io.last_dof_vel[eD + d] - qd[d]) / dt;
+      s_qacc2 += acc * acc;
+      float lo_l, hi_l;
+      if (c.soft_pos_curriculum) {
+        float m = (c.hard_dof_pos_limits[d][0] + c.hard_dof_pos_limits[d][1]) / 2.0f;
+        float r = c.hard_dof_pos_limits[d][1] - c.hard_dof_pos_limits[d][0];
+        lo_l = m - 0.5f * r * soft_pos; hi_l = m + 0.5f * r * soft_pos;
+      } else { lo_l = c.soft_dof_pos_limits[d][0]; hi_l = c.soft_dof_pos_limits[d][1]; }
+      s_lpos += -fminf(q[d] - lo_l, 0.0f) + fmaxf(q[d] - hi_l, 0.0f);
+      float vlim = c.dof_vel_limits[d] * (c.soft_vel_curriculum ? soft_vel : c.soft_dof_vel_limit);
+      s_lvel += clampf(fabsf(qd[d]) - vlim, 0.0f, 1.0f);
+      if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[d]) - c.torque_limits[d] * soft_tau, 0.0f, 1.0f);
+      else s_ltau += fmaxf(fabsf(tau[d]) - c.torque_limits[d] * c.soft_torque_limit, 0.0f);
+    }
+    for (int i = lane; i < c.num_penalised; i += PBHC_G)
+      if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
+  }
+#define GSUM(v) v = group_sum(v)
+  GSUM(s_up); GSUM(s_lo); GSUM(s_vr); GSUM(s_feet); GSUM(s_rot); GSUM(s_vel); GSUM(s_ang); GSUM(s_upn); GSUM(s_lon); GSUM(s_vrn);
+  GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
+  s_maxn = group_max(s_maxn); s_maxjp = group_max(s_maxjp);
+  if (valid && lane == 0) {
+    red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
+    red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
+    red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
+    red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JV2] = s_jv2; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
+    red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = clipcnt;
+    // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
+    float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
+    if (c.terminate_by_gravity) grav = sqrtf(misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]) > c.termination_gravity ? 1.0f : 0.0f;
+    if (c.terminate_when_motion_far) far = s_maxn > (float)glob[PBHC_G_MOTION_FAR_THR] ? 1.0f : 0.0f;
+    tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
+    if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
+    float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
+    misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
+    misc[M_TIMEOUT] = tout;
+    misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+
+  // ---------------- phase F: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ----
+  float err[PBHC_NUM_SIGMA];
+#pragma unroll
+  for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
+  float rew_total = 0.0f;
+  if (valid) {
+    const float pen_scale = (float)glob[PBHC_G_PENALTY_SCALE];
+    float myrew = 0.0f;
+    if (lane < c.num_terms) {
+      float raw = 0.0f;
+      const int id = c.term_id[lane];
+#define SIG(k) ((float)glob[PBHC_G_SIGMA + (k)])
+      switch (id) {
+        case PBHC_R_TELEOP_CONTACT_MASK: {
+          float e = 0.0f;
+          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
+          raw = 1.0f - e / (float)NF;
+        } break;
+        case PBHC_R_TELEOP_MAX_JOINT_POSITION: raw = expf(-red[R_MAXJP] / SIG(PBHC_S_MAX_JOINT_POS)); break;
+        case PBHC_R_TELEOP_BODY_POSITION_EXTEND:
+          raw = expf(-red[R_LO] / SIG(PBHC_S_LOWER_BODY_POS)) * c.body_pos_lower_weight + expf(-red[R_UP] / SIG(PBHC_S_UPPER_BODY_POS)) * c.body_pos_upper_weight;
+          break;
+        case PBHC_R_TELEOP_VR_3POINT: raw = expf(-red[R_VR] / SIG(PBHC_S_VR_3POINT_POS)); break;
+        case PBHC_R_TELEOP_BODY_POSITION_FEET: raw = expf(-red[R_FEET] / SIG(PBHC_S_FEET_POS)); break;
+        case PBHC_R_TELEOP_BODY_ROTATION_EXTEND: raw = expf(-red[R_ROT] / SIG(PBHC_S_BODY_ROT)); break;
+        case PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND: raw = expf(-red[R_ANG] / SIG(PBHC_S_BODY_ANG_VEL)); break;
+        case PBHC_R_TELEOP_BODY_VELOCITY_EXTEND: raw = expf(-red[R_VEL] / SIG(PBHC_S_BODY_VEL)); break;
+        case PBHC_R_TELEOP_JOINT_POSITION: raw = expf(-(red[R_JP2] / (float)D) / SIG(PBHC_S_JOINT_POS)); break;
+        case PBHC_R_TELEOP_JOINT_VELOCITY: raw = expf(-(red[R_JV2] / (float)D) / SIG(PBHC_S_JOINT_VEL)); break;
+        case PBHC_R_PENALTY_TORQUES: raw = red[R_TAU2]; break;
+        case PBHC_R_PENALTY_DOF_VEL: raw = red[R_QD2]; break;
+        case PBHC_R_PENALTY_DOF_ACC: raw = red[R_QACC2]; break;
+        case PBHC_R_PENALTY_ACTION_RATE: raw = red[R_ARATE]; break;
+        case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
+        case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
+          for (int f = 0; f < NF; ++f) {
+            bool contact = cf[3 * c.feet[f] + 2] > 1.0f;
+            bool cfilt = contact || (misc[M_LASTC0 + f] != 0.0f);
+            float fat = misc[M_FAT0 + f];
+            float first = (fat > 0.0f && cfilt) ? 1.0f : 0.0f;
+            fat = fat + dt;
+            raw += (fat - c.desired_feet_air_time) * first;
+            misc[M_FAT0 + f] = cfilt ? fat * 0.0f : fat;
+          }
+        } break;
+        case PBHC_R_PENALTY_FEET_CONTACT_FORCES:
+          for (int f = 0; f < NF; ++f) raw += fmaxf(norm3(ld3(cf + 3 * c.feet[f])) - c.max_contact_force, 0.0f);
+          break;
+        case PBHC_R_PENALTY_STUMBLE:
+          for (int f = 0; f < NF; ++f) {
+            const float* fc = cf + 3 * c.feet[f];
+            if (sqrtf(fc[0] * fc[0] + fc[1] * fc[1]) > 5.0f * fabsf(fc[2])) raw = 1.0f;
+          }
+          break;
+        case PBHC_R_PENALTY_SLIPPAGE:
+          for (int f = 0; f < NF; ++f) raw += norm3(ld3(bv + 3 * c.feet[f])) * (norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f);
+          break;
+        case PBHC_R_FOOT_SLIP_PENALTY:
+          for (int f = 0; f < NF; ++f) {
+            const float* v = bv + 3 * c.feet[f];
+            raw += (norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f) * sqrtf(v[0] * v[0] + v[1] * v[1]);
+          }
+          break;
+        case PBHC_R_LIMITS_DOF_POS: raw = red[R_LIMPOS]; break;
+        case PBHC_R_LIMITS_DOF_VEL: raw = red[R_LIMVEL]; break;
+        case PBHC_R_LIMITS_TORQUE: raw = red[R_LIMTAU]; break;
+        case PBHC_R_COLLISION: raw = red[R_COLL]; break;
+        case PBHC_R_ALIVE: raw = 1.0f; break;
+        default: raw = 0.0f;
+      }
+#undef SIG
+      myrew = raw * c.term_scale[lane];
+      if (c.term_penalty[lane]) myrew = myrew * pen_scale;
+      float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
+      sum[c.term_sum_col[lane]] += myrew;
+    }
+    if (c.use_vec_reward) {
+      if (lane < c.num_rew_cols) {
+        float v = lane < c.num_terms ? myrew : 0.0f;
+        if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
+        if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
+          float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
+          v += tr;
+          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] += tr;
+        }
+        io.rew_buf[(size_t)env * c.num_rew_cols + lane] = v;
+        rew_total = v;
+      }
+      rew_total = group_sum(rew_total);
+    } else {
+      float v = group_sum(lane < c.num_terms ? myrew : 0.0f);
+      if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
+      if (lane == 0) {
+        if (c.has_termination) {
+          float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
+          v += tr;
+          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] += tr;
+        }
+        io.rew_buf[env] = v;
+      }
+      rew_total = v;
+    }
+    err[PBHC_S_MAX_JOINT_POS] = red[R_MAXJP]; err[PBHC_S_UPPER_BODY_POS] = red[R_UP]; err[PBHC_S_LOWER_BODY_POS] = red[R_LO];
+    err[PBHC_S_VR_3POINT_POS] = red[R_VR]; err[PBHC_S_FEET_POS] = red[R_FEET]; err[PBHC_S_BODY_ROT] = red[R_ROT];
+    err[PBHC_S_BODY_VEL] = red[R_VEL]; err[PBHC_S_BODY_ANG_VEL] = red[R_ANG]; err[PBHC_S_JOINT_POS] = red[R_JP2] / (float)D;
+    err[PBHC_S_JOINT_VEL] = red[R_JV2] / (float)D;
+  }
+  __syncthreads();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
+
+  // optional outputs of the pre-reset state
+  if (valid) {
+    if (io.ref_body_pos_extend)
+      for (int i = lane; i < Bx * 3; i += PBHC_G) io.ref_body_pos_extend[(size_t)env * Bx * 3 + i] = rp[i];
+    if (io.ref_body_rot_extend)
+      for (int i = lane; i < Bx * 4; i += PBHC_G) io.ref_body_rot_extend[(size_t)env * Bx * 4 + i] = rq[i];
+    if (io.rigid_body_state)
+      for (int b = lane; b < B; b += PBHC_G) {
+        float* o = io.rigid_body_state + ((size_t)env * B + b) * 13;
+        st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
+      }
+    if (io.contact_forces)
+      for (int i = lane; i < B * 3; i += PBHC_G) io.contact_forces[(size_t)env * B * 3 + i] = cf[i];
+  }
+
+  // ---------------- phase G: reset_envs_idx for terminated envs (legged_robot_base.py:491-517,
+  // 599-686; motion_tracking.py:265-287,369-378,445-543) ------------------------------------------
+  const bool do_reset = valid && misc[M_RESET] != 0.0f;
+  float etr_val = 0.0f;
+  if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)io.action_delay_idx[env]; }
+  if (do_reset) {
+    const int Q = c.queue_len;
+    for (int d = lane; d < D; d += PBHC_G) {
+      act[d] = 0.0f; actd[d] = 0.0f;
+      if (c.randomize_pd_gain) {
+        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * rng_uniform(c.seed, env, step_ctr, 2, d) + c.kp_range[0];
+        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * rng_uniform(c.seed, env, step_ctr, 3, d) + c.kd_range[0];
+      }
+      if (c.randomize_rfi_lim)
+        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * rng_uniform(c.seed, env, step_ctr, 4, d) + c.rfi_lim_range[0];
+      if (c.use_rao)
+        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * rng_uniform(c.seed, env, step_ctr, 5, d) + (-c.rao_lim);
+      if (c.randomize_ctrl_delay)
+        for (int k = 0; k < Q; ++k) io.action_queue[((size_t)env * Q + k) * D + d] *= 0.0f;
+    }
+    const int hoff = c.feat_off[PBHC_F_HISTORY];
+    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] *= 0.0f;
+    float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
+    for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
+      if (io.episode_rew_out) io.episode_rew_out[(size_t)env * c.num_sum_cols + i] = sum[i] / c.max_episode_length_s;
+      sum[i] = 0.0f;
+    }
+    if (lane == 0) {
+      misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
+      misc[M_CONTACT0] = 0.0f; misc[M_CONTACT1] = 0.0f; misc[M_CFILT0] = 0.0f; misc[M_CFILT1] = 0.0f;
+      float old_start = misc[M_START];
+      float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
+      io.end_time_ratio_buf[env] = etr;
+      float mlen = tbl.motion_len[mid];
+      io.motion_len[env] = mlen;
+      float ns = io.ovr_start_time ? io.ovr_start_time[env] : rng_uniform(c.seed, env, step_ctr, 6, 0) * mlen;   // sample_time motion_lib_base.py:486-495
+      io.motion_start_times[env] = ns;
+      misc[M_NEWSTART] = ns;
+      if (c.randomize_ctrl_delay) {
+        long long nd = io.ovr_delay ? io.ovr_delay[env]
+                                    : (long long)c.ctrl_delay_range[0] + (long long)(rng_uniform(c.seed, env, step_ctr, 7, 0) * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
+        io.action_delay_idx[env] = nd;
+        misc[M_DELAY] = (float)nd;
+      }
+      misc[M_EPLEN] = 0.0f;
+    }
+  }
+  __syncthreads();
+  if (do_reset) {
+    // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
+    // invalidated, motion_tracking.py:378,536-543,477-507)
+    float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
+    motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, red + 30, rp, rq, rv, rw);
+  }
+  __syncthreads();
+  if (do_reset && lane == 0) {
+    st3(root, ld3(rp));
+    st4(root + 3, quat_mul(mk4(0.f, 0.f, 0.f, 1.f), ld4(rq)));       // quat_mul(small_random_quaternions(max_angle=0), root_rot)
+    st3(root + 7, ld3(rv));
+    st3(root + 10, ld3(rw));
+  }
+  if (valid && lane == 0) etr_val = io.end_time_ratio_buf[env];
+
+  // ---------------- phase H: remaining features ---------------------------------------------------
+  if (valid) {
+    const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
+    const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
+    for (int d = lane; d < D; d += PBHC_G) {
+      feat[o_q + d] = q[d] - c.default_dof_pos[d];
+      feat[o_qd + d] = qd[d];
+      feat[o_a + d] = act[d];
+      feat[o_kp + d] = io.kp_scale[eD + d];
+      feat[o_kd + d] = io.kd_scale[eD + d];
+    }
+    if (lane == 0) feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
+  }
+  __syncthreads();
+
+  // ---------------- phase I: observation groups + history write-back ------------------------------
+  // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
+  if (valid) {
+    const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
+    for (int g = 0; g < c.num_groups; ++g) {
+      const PbhcOutMap& m = c.groups[g];
+      float* out = io.obs[g] + (size_t)env * m.dim;
+      for (int j = lane; j < m.dim; j += PBHC_G) {
+        float x = feat[m.src[j]];
+        float ns = m.noise[j];
+        if (ns != 0.0f) x = x + (rng_uniform(c.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns * noise_cur);
+        x = x * m.scale[j];
+        if (m.clip) x = clampf(x, -c.clip_observations, c.clip_observations);
+        out[j] = x;
+      }
+    }
+    // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
+    for (int d = lane; d < D; d += PBHC_G) {
+      io.actions[eD + d] = act[d];
+      io.last_actions[eD + d] = act[d];
+      io.actions_after_delay[eD + d] = actd[d];
+      io.torques[eD + d] = tau[d];
+      io.dof_state[(eD + d) * 2] = q[d];
+      io.dof_state[(eD + d) * 2 + 1] = qd[d];
+      io.last_dof_pos[eD + d] = q[d];
+      io.last_dof_vel[eD + d] = qd[d];
+    }
+    if (lane < 13) io.root_states[(size_t)env * 13 + lane] = root[lane];
+    if (lane < NF) {
+      io.feet_air_time[(size_t)env * NF + lane] = misc[M_FAT0 + lane];
+      io.contacts[(size_t)env * NF + lane] = misc[M_CONTACT0 + lane];
+      io.contacts_filt[(size_t)env * NF + lane] = misc[M_CFILT0 + lane];
+      io.last_contacts[(size_t)env * NF + lane] = misc[M_CONTACT0 + lane];
+      io.last_contacts_filt[(size_t)env * NF + lane] = misc[M_CFILT0 + lane];
+    }
+    if (lane == 0) {
+      io.episode_length_buf[env] = (long long)misc[M_EPLEN];
+      io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];
+      io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;
+      io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;
+    }
+  }
+
+  // ---------------- workgroup partial sums for the host-side scalars of the reference ------------
+  if (lane == 0) {
+    float* bpq = blockpart + le * PBHC_NP;
+    for (int k = 0; k < PBHC_NP; ++k) bpq[k] = 0.0f;
+    if (valid) {
+      for (int k = 0; k < PBHC_NUM_SIGMA; ++k) bpq[P_ERR + k] = err[k];
+      bpq[P_UPPER_NORM] = red[R_UPN]; bpq[P_LOWER_NORM] = red[R_LON]; bpq[P_VR_NORM] = red[R_VRN];
+      bpq[P_JOINT_NORM] = sqrtf(red[R_JP2]);
+      bpq[P_CLIP_CNT] = red[R_CLIPCNT];
+      bpq[P_RESET_CNT] = misc[M_RESET]; bpq[P_TERM_GRAVITY] = misc[M_GRAV]; bpq[P_TERM_FAR] = misc[M_FAR];
+      bpq[P_TERM_TIMEOUT] = misc[M_TIMEOUT]; bpq[P_TERM_END] = misc[M_END];
+      bpq[P_RESET_EPLEN] = misc[M_RESET] != 0.0f ? misc[M_LASTEP] : 0.0f;
+      bpq[P_ETR_SUM] = etr_val; bpq[P_ETR_SQ] = etr_val * etr_val;
+      bpq[P_REW_SUM] = rew_total;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < PBHC_NP) {
+    float v = 0.0f;
+    for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];
+    partials[(size_t)blockIdx.x * PBHC_NP + threadIdx.x] = v;
+  }
+}
+
+// =================================================================================================
+//  k_env_finalize: the scalars the reference updates on the host each step
+// =================================================================================================
+__global__ void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks) {
+  __shared__ double tot[PBHC_NP];
+  const PbhcEnvConfig& c = *cfgp;
+  int k = threadIdx.x;
+  if (k < PBHC_NP) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * PBHC_NP + k];
+    tot[k] = s;
+  }
+  __syncthreads();
+  if (k != 0) return;
+  const double N = (double)c.num_envs;
+  // adaptive sigma (motion_tracking.py:1030-1048, type "origin")
+  if (c.adaptive_sigma)
+    for (int i = 0; i < PBHC_NUM_SIGMA; ++i)
+      if (c.sigma_active[i]) {
+        double mean = (double)(float)(tot[P_ERR + i] / N);
+        double ema = glob[PBHC_G_EMA + i] * (1.0 - (double)c.adaptive_alpha) + mean * (double)c.adaptive_alpha;
+        glob[PBHC_G_EMA + i] = ema;
+        glob[PBHC_G_SIGMA + i] = fmin(ema, glob[PBHC_G_SIGMA + i]);
+      }
+  double* L = glob + PBHC_G_LOG;
+  const double nreset = tot[P_RESET_CNT];
+  L[PBHC_L_UPPER_BODY_DIFF_NORM] = tot[P_UPPER_NORM] / N; L[PBHC_L_LOWER_BODY_DIFF_NORM] = tot[P_LOWER_NORM] / N;
+  L[PBHC_L_VR_3POINT_DIFF_NORM] = tot[P_VR_NORM] / N; L[PBHC_L_JOINT_POS_DIFF_NORM] = tot[P_JOINT_NORM] / N;
+  L[PBHC_L_ACTION_CLIP_FRAC] = tot[P_CLIP_CNT] / (N * (double)c.skel.num_dof);
+  const double rfrac = nreset / N;
+  L[PBHC_L_RESET_FRAC] = rfrac; L[PBHC_L_NUM_RESETS] = nreset;
+  L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
+  L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
+  L[PBHC_L_REW_MEAN] = tot[P_REW_SUM] / N;
+  if (nreset > 0.0) {
+    // _update_average_episode_length (legged_robot_base.py:875-879), fp32 like the reference's 0-dim tensor
+    float cur = (float)(tot[P_RESET_EPLEN] / nreset);
+    double frac = nreset / (double)c.num_compute_average_epl;
+    float avg = (float)glob[PBHC_G_AVG_EP_LEN] * (float)(1.0 - frac) + cur * (float)frac;
+    glob[PBHC_G_AVG_EP_LEN] = (double)avg;
+    if (c.penalty_curriculum) {           // legged_robot_base.py:882-900
+      double p = glob[PBHC_G_PENALTY_SCALE];
+      if (avg < c.penalty_down) p *= (1.0 - (double)c.penalty_degree);
+      else if (avg > c.penalty_up) p *= (1.0 + (double)c.penalty_degree);
+      glob[PBHC_G_PENALTY_SCALE] = fmin(fmax(p, (double)c.penalty_min), (double)c.penalty_max);
+    }
+    double mean = tot[P_ETR_SUM] / N;
+    L[PBHC_L_END_TIME_RATIO] = mean;
+    double var = (tot[P_ETR_SQ] - N * mean * mean) / (N - 1.0);
+    L[PBHC_L_END_TIME_RATIO_STD] = var > 0.0 ? sqrt(var) : 0.0;
+    if (c.terminate_when_motion_far && c.motion_far_curriculum) {   // motion_tracking.py:309-317
+      double t = glob[PBHC_G_MOTION_FAR_THR];
+      if (avg < c.motion_far_down) t *= (1.0 + (double)c.motion_far_degree);
+      else if (avg > c.motion_far_up) t *= (1.0 - (double)c.motion_far_degree);
+      glob[PBHC_G_MOTION_FAR_THR] = fmin(fmax(t, (double)c.motion_far_min), (double)c.motion_far_max);
+    }
+  }
+  glob[PBHC_G_STEP_COUNTER] += 1.0;
+}
+
+// =================================================================================================
+//  standalone kernels: sim FK, motion state, load-time motion build
+// =================================================================================================
+__global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_sim_fk(PbhcSkeleton sk, const float* __restrict__ root_states, const float* __restrict__ dof_pos,
+                                                            const float* __restrict__ dof_vel, int dof_stride, int n, float* __restrict__ out) {
+  __shared__ float sm[PBHC_EPB][16 + 64 + 40 * 13];
+  const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G, env = blockIdx.x * PBHC_EPB + le;
+  const bool valid = env < n;
+  float* root = sm[le];
+  float *q = root + 16, *qd = q + 32, *bp = qd + 32, *bq = bp + 120, *bv = bq + 160, *bw = bv + 120;
+  if (valid) {
+    if (lane < 13) root[lane] = root_states[(size_t)env * 13 + lane];
+    for (int d = lane; d < sk.num_dof; d += PBHC_G) {
+      q[d] = dof_pos[((size_t)env * sk.num_dof + d) * dof_stride];
+      qd[d] = dof_vel[((size_t)env * sk.num_dof + d) * dof_stride];
+    }
+  }
+  __syncthreads();
+  fk_chain(sk, lane, valid, root, q, qd, bp, bq, bv, bw);
+  if (valid)
+    for (int b = lane; b < sk.num_bodies; b += PBHC_G) {
+      float* o = out + ((size_t)env * sk.num_bodies + b) * 13;
+      st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
+    }
+}
+
+__global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_motion_state(PbhcMotionTable tbl, int Bx, int D, const int64_t* __restrict__ ids, const float* __restrict__ times,
+                                                                  const float* __restrict__ offset, int n, float* __restrict__ out) {
+  __shared__ float sm[PBHC_EPB][64 + 8 + 40 * 13];
+  const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G, i = blockIdx.x * PBHC_EPB + le;
+  const bool valid = i < n;
+  float* rdof = sm[le];
+  float *rdofv = rdof + 32, *rc = rdofv + 32, *rp = rc + 8, *rq = rp + 120, *rv = rq + 160, *rw = rv + 120;
+  if (valid) {
+    f3 off = offset ? ld3(offset + (size_t)i * 3) : mk3(0.f, 0.f, 0.f);
+    motion_lookup(tbl, D, Bx, lane, (int)ids[i], times[i], off, true, rdof, rdofv, rc, rp, rq, rv, rw);
+  }
+  __syncthreads();
+  if (!valid) return;
+  float* o = out + (size_t)i * tbl.row;
+  for (int d = lane; d < D; d += PBHC_G) { o[d] = rdof[d]; o[D + d] = rdofv[d]; }
+  if (lane < 2) o[2 * D + lane] = rc[lane];
+  int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+  for (int k = lane; k < 3 * Bx; k += PBHC_G) { o[o_pos + k] = rp[k]; o[o_vel + k] = rv[k]; o[o_ang + k] = rw[k]; }
+  for (int k = lane; k < 4 * Bx; k += PBHC_G) o[o_rot + k] = rq[k];
+}
+
+// load-time FK: one thread per frame walks the chain (Humanoid_Batch.fk_batch +
+// forward_kinematics_batch, torch_humanoid_batch.py:168-269)
+__global__ void k_motion_fk(PbhcSkeleton sk, const float* __restrict__ pose_aa, const float* __restrict__ trans, int F,
+                            float* __restrict__ pos, float* __restrict__ rot) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int Bx = sk.num_bodies_ext;
+  m33 W[PBHC_MAX_BODIES];
+  float P[PBHC_MAX_BODIES][3];
+  for (int i = 0; i < Bx; ++i) {
+    const float* aa = pose_aa + ((size_t)f * Bx + i) * 3;
+    float qw[4];
+    axis_angle_to_quat_wxyz(aa[0], aa[1], aa[2], qw);
+    m33 J = quat_wxyz_to_matrix(qw[0], qw[1], qw[2], qw[3]);
+    int p = sk.parent[i];
+    if (p < 0) {
+      W[i] = J;
+      P[i][0] = trans[f * 3 + 0]; P[i][1] = trans[f * 3 + 1]; P[i][2] = trans[f * 3 + 2];
+    } else {
+      const float* o = sk.offset[i];
+      const m33& Rp = W[p];
+      P[i][0] = Rp.m[0] * o[0] + Rp.m[1] * o[1] + Rp.m[2] * o[2] + P[p][0];
+      P[i][1] = Rp.m[3] * o[0] + Rp.m[4] * o[1] + Rp.m[5] * o[2] + P[p][1];
+      P[i][2] = Rp.m[6] * o[0] + Rp.m[7] * o[1] + Rp.m[8] * o[2] + P[p][2];
+      m33 Lm = quat_wxyz_to_matrix(sk.local_rot_wxyz[i][0], sk.local_rot_wxyz[i][1], sk.local_rot_wxyz[i][2], sk.local_rot_wxyz[i][3]);
+      W[i] = matmul33(Rp, matmul33(Lm, J));
+    }
+    float* po = pos + ((size_t)f * Bx + i) * 3;
+    po[0] = P[i][0]; po[1] = P[i][1]; po[2] = P[i][2];
+    st4(rot + ((size_t)f * Bx + i) * 4, matrix_to_quat_xyzw(W[i]));
+  }
+}
+
+// raw velocities: np.gradient/dt and angle-axis of q_{t+1} * conj(q_t) (torch_humanoid_batch.py:272-290)
+__global__ void k_motion_rawvel(const float* __restrict__ pos, const float* __restrict__ rot, int F, int Bx, float dt,
+                                float* __restrict__ vel, float* __restrict__ ang) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * Bx) return;
+  int f = i / Bx, b = i % Bx;
+  auto P = [&](int ff, int k) { return pos[((size_t)ff * Bx + b) * 3 + k]; };
+  for (int k = 0; k < 3; ++k) {
+    float g;
+    if (F == 1) g = 0.0f;
+    else if (f == 0) g = (P(1, k) - P(0, k)) / 1.0f;
+    else if (f == F - 1) g = (P(F - 1, k) - P(F - 2, k)) / 1.0f;
+    else g = (P(f + 1, k) - P(f - 1, k)) / 2.0f;
+    vel[(size_t)i * 3 + k] = g / dt;
+  }
+  f4 dq = mk4(0.f, 0.f, 0.f, 1.f);
+  if (f < F - 1) dq = quat_unit(quat_mul(ld4(rot + ((size_t)(f + 1) * Bx + b) * 4), quat_conj(ld4(rot + ((size_t)f * Bx + b) * 4))));
+  float s = 2.0f * (dq.w * dq.w) - 1.0f;
+  float angle = acosf(clampf(s, -1.0f, 1.0f));
+  float n = fmaxf(sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-9f);
+  ang[(size_t)i * 3 + 0] = dq.x / n * angle / dt;
+  ang[(size_t)i * 3 + 1] = dq.y / n * angle / dt;
+  ang[(size_t)i * 3 + 2] = dq.z / n * angle / dt;
+}
+
+// scipy.ndimage.gaussian_filter1d(sigma=2, mode="nearest", truncate=4) along time, double accumulation,
+// then pack the frame rows
+__global__ void k_motion_pack(PbhcSkeleton sk, const float* __restrict__ pose_aa, const float* __restrict__ contact, const float* __restrict__ pos,
+                              const float* __restrict__ rot, const float* __restrict__ vel, const float* __restrict__ ang, int F, float dt, int row,
+                              float* __restrict__ out) {
+  const int Bx = sk.num_bodies_ext, D = sk.num_dof, B = sk.num_bodies;
+  int f = blockIdx.x;
+  float* o = out + (size_t)f * row;
+  double w[9];
+  double wsum = 0.0;
+  for (int k = 0; k <= 8; ++k) { w[k] = exp(-0.5 * (double)(k * k) / 4.0); wsum += (k == 0 ? 1.0 : 2.0) * w[k]; }
+  const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+  for (int i = threadIdx.x; i < Bx * 3; i += blockDim.x) {
+    double av = 0.0, aw = 0.0;
+    for (int k = -8; k <= 8; ++k) {
+      int ff = min(max(f + k, 0), F - 1);
+      double wk = w[k < 0 ? -k : k] / wsum;
+      av += wk * (double)vel[(size_t)ff * Bx * 3 + i];
+      aw += wk * (double)ang[(size_t)ff * Bx * 3 + i];
+    }
+    o[o_vel + i] = (float)av; o[o_ang + i] = (float)aw;
+    o[o_pos + i] = pos[(size_t)f * Bx * 3 + i];
+  }
+  for (int i = threadIdx.x; i < Bx * 4; i += blockDim.x) o[o_rot + i] = rot[(size_t)f * Bx * 4 + i];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    auto dofp = [&](int ff) {
+      const float* aa = pose_aa + ((size_t)ff * Bx + (d + 1)) * 3;
+      return aa[0] + aa[1] + aa[2];                                   // pose_aa.sum(-1)[1:B]  (:216)
+    };
+    o[d] = dofp(f);
+    float dv;
+    if (F < 2) dv = 0.0f;
+    else if (f < F - 1) dv = (dofp(f + 1) - dofp(f)) / dt;
+    else { int g = F >= 3 ? F - 3 : 0; dv = (dofp(g + 1) - dofp(g)) / dt; }   // `dof_vel[:, -2:-1]`, sic (:224)
+    o[D + d] = dv;
+  }
+  if (threadIdx.x < 2) o[2 * D + threadIdx.x] = contact ? contact[(size_t)f * 2 + threadIdx.x] : 0.0f;
+  (void)B;
+}
+
+// =================================================================================================
+//  GAE (MHPPO._compute_returns mh_ppo.py:348-395)
+// =================================================================================================
+#define GAE_TPB 256
+__global__ __launch_bounds__(GAE_TPB) void k_gae(const float* __restrict__ rewards, const float* __restrict__ values, const uint8_t* __restrict__ dones,
+                                                 const float* __restrict__ last_values, int T, int N, int R, float gamma, float lam,
+                                                 float* __restrict__ returns) {
+  // thread <-> (env, head): consecutive threads walk consecutive floats of every [t] slab
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * R) return;
+  int n = (int)(i / R);
+  float adv = 0.0f;
+  float next = last_values[i];
+  for (int t = T - 1; t >= 0; --t) {
+    size_t o = (size_t)t * N * R + i;
+    float nt = 1.0f - (dones[(size_t)t * N + n] ? 1.0f : 0.0f);
+    float v = values[o];
+    float delta = rewards[o] + nt * gamma * next - v;
+    adv = delta + nt * gamma * lam * adv;
+    returns[o] = adv + v;
+    next = v;
+  }
+}
+// advantages = sum over heads of (returns - values); block partial sums of x and x^2 (double)
+__global__ __launch_bounds__(GAE_TPB) void k_adv_sum(const float* __restrict__ returns, const float* __restrict__ values, size_t TN, int R,
+                                                     float* __restrict__ adv, double* __restrict__ part) {
+  __shared__ double s1[GAE_TPB], s2[GAE_TPB];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double a = 0.0;
+  if (i < TN) {
+    float s = 0.0f;
+    for (int r = 0; r < R; ++r) s += returns[i * R + r] - values[i * R + r];
+    adv[i] = s;
+    a = (double)s;
+  }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = a * a;
+  __syncthreads();
+  for (int st = GAE_TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
+}
+__global__ void k_adv_stats(double* __restrict__ part, int nblocks, double TN) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblocks; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+  double mean = a / TN;
+  double var = (b - TN * mean * mean) / (TN - 1.0);       // torch.std: unbiased
+  part[2 * nblocks] = mean;
+  part[2 * nblocks + 1] = sqrt(var > 0.0 ? var : 0.0);
+}
+__global__ void k_adv_norm(float* __restrict__ adv, size_t TN, const double* __restrict__ stats) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= TN) return;
+  float mean = (float)stats[0], sd = (float)stats[1];
+  adv[i] = (adv[i] - mean) / (sd + 1e-8f);
+}
+
+// =================================================================================================
+//  C ABI
+// =================================================================================================
+struct PbhcEnv {
+  PbhcEnvConfig cfg;
+  PbhcEnvConfig* d_cfg;
+  PbhcMotionTable tbl;
+  double* d_glob;
+  float* d_partials;
+  int nblocks;
+  int lds_stride;
+  size_t lds_bytes;
+  uint32_t step_ctr;
+};
+
+extern "C" {
+
+int pbhc_abi_version(void) { return PBHC_ABI_VERSION; }
+const char* pbhc_last_error(void) { return g_err; }
+int pbhc_sizeof_env_config(void) { return (int)sizeof(PbhcEnvConfig); }
+int pbhc_sizeof_step_io(void) { return (int)sizeof(PbhcStepIO); }
+
+static int check_skel(const PbhcSkeleton* sk) {
+  ARG_CHECK(sk != nullptr);
+  ARG_CHECK(sk->num_bodies >= 1 && sk->num_bodies <= sk->num_bodies_ext && sk->num_bodies_ext <= PBHC_MAX_BODIES);
+  ARG_CHECK(sk->num_dof == sk->num_bodies - 1 && sk->num_dof <= PBHC_MAX_DOF);
+  ARG_CHECK(sk->parent[0] == -1);
+  for (int i = 1; i < sk->num_bodies_ext; ++i) ARG_CHECK(sk->parent[i] >= 0 && sk->parent[i] < i && sk->parent[i] < sk->num_bodies);
+  for (int i = 1; i < sk->num_bodies; ++i) ARG_CHECK(sk->depth[i] == sk->depth[sk->parent[i]] + 1 && sk->depth[i] <= sk->max_depth);
+  return PBHC_OK;
+}
+
+int pbhc_motion_build(const PbhcSkeleton* skel, const float* pose_aa, const float* trans, const float* contact, int F, float dt,
+                      float* out_rows, float* scratch, void* stream) {
+  int rc = check_skel(skel);
+  if (rc) return rc;
+  ARG_CHECK(pose_aa && trans && out_rows && scratch && F >= 1 && dt > 0.0f);
+  hipStream_t st = (hipStream_t)stream;
+  const int Bx = skel->num_bodies_ext, D = skel->num_dof;
+  const int row = 2 * D + 2 + 13 * Bx;
+  float* pos = scratch;
+  float* rot = pos + (size_t)F * Bx * 3;
+  float* vel = rot + (size_t)F * Bx * 4;
+  float* ang = vel + (size_t)F * Bx * 3;
+  hipLaunchKernelGGL(k_motion_fk, dim3((F + 63) / 64), dim3(64), 0, st, *skel, pose_aa, trans, F, pos, rot);
+  hipLaunchKernelGGL(k_motion_rawvel, dim3((F * Bx + 127) / 128), dim3(128), 0, st, pos, rot, F, Bx, dt, vel, ang);
+  hipLaunchKernelGGL(k_motion_pack, dim3(F), dim3(128), 0, st, *skel, pose_aa, contact, pos, rot, vel, ang, F, dt, row, out_rows);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_motion_state(const PbhcMotionTable* tbl, int Bx, int D, const int64_t* ids, const float* times, const float* offset, int n,
+                      float* out, void* stream) {
+  ARG_CHECK(tbl && tbl->frames && ids && times && out && n >= 0);
+  ARG_CHECK(Bx >= 1 && Bx <= PBHC_MAX_BODIES && D >= 1 && D <= PBHC_MAX_DOF && tbl->row == 2 * D + 2 + 13 * Bx);
+  if (n == 0) return PBHC_OK;
+  hipLaunchKernelGGL(k_motion_state, dim3((n + PBHC_EPB - 1) / PBHC_EPB), dim3(PBHC_G * PBHC_EPB), 0, (hipStream_t)stream, *tbl, Bx, D, ids, times, offset, n, out);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_sim_fk(const PbhcSkeleton* skel, const float* root_states, const float* dof_pos, const float* dof_vel, int dof_stride, int n,
+                float* out, void* stream) {
+  int rc = check_skel(skel);
+  if (rc) return rc;
+  ARG_CHECK(root_states && dof_pos && dof_vel && out && n >= 0 && dof_stride >= 1);
+  if (n == 0) return PBHC_OK;
+  hipLaunchKernelGGL(k_sim_fk, dim3((n + PBHC_EPB - 1) / PBHC_EPB), dim3(PBHC_G * PBHC_EPB), 0, (hipStream_t)stream, *skel, root_states, dof_pos, dof_vel, dof_stride, n, out);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double* globals, PbhcEnv** out) {
+  ARG_CHECK(cfg && tbl && globals && out);
+  ARG_CHECK(cfg->abi_version == PBHC_ABI_VERSION);
+  int rc = check_skel(&cfg->skel);
+  if (rc) return rc;
+  const int D = cfg->skel.num_dof, Bx = cfg->skel.num_bodies_ext;
+  ARG_CHECK(cfg->num_envs >= 1);
+  ARG_CHECK(cfg->num_feet >= 1 && cfg->num_feet <= PBHC_MAX_FEET);
+  ARG_CHECK(cfg->num_terms >= 0 && cfg->num_terms <= PBHC_MAX_TERMS && cfg->num_terms <= PBHC_G && cfg->num_rew_cols <= PBHC_G);
+  ARG_CHECK(cfg->num_groups >= 1 && cfg->num_groups <= PBHC_MAX_GROUPS);
+  ARG_CHECK(cfg->queue_len >= 1 && cfg->queue_len <= PBHC_MAX_QUEUE);
+  ARG_CHECK(tbl->row == 2 * D + 2 + 13 * Bx && tbl->frames && tbl->num_motions >= 1);
+  ARG_CHECK(cfg->feat_dim > 0 && cfg->feat_dim < 8192);
+  for (int g = 0; g < cfg->num_groups; ++g) ARG_CHECK(cfg->groups[g].dim > 0 && cfg->groups[g].src && cfg->groups[g].scale && cfg->groups[g].noise);
+  for (int i = 0; i < PBHC_F_NUM; ++i) ARG_CHECK(cfg->feat_off[i] >= 0 && cfg->feat_off[i] < cfg->feat_dim);
+  PbhcEnv* e = new (std::nothrow) PbhcEnv();
+  if (!e) return PBHC_ENOMEM;
+  e->cfg = *cfg;
+  e->tbl = *tbl;
+  e->d_glob = globals;
+  e->nblocks = (cfg->num_envs + PBHC_EPB - 1) / PBHC_EPB;
+  e->lds_stride = Lds::FEAT + ((cfg->feat_dim + 3) & ~3);
+  e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+  e->step_ctr = 0;
+  if (e->lds_bytes > 160 * 1024) { delete e; snprintf(g_err, sizeof(g_err), "feature row too large for LDS"); return PBHC_EINVAL; }
+  if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
+  if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
+  HIP_CHECK(hipMemcpy(e->d_cfg, cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
+  if (e->lds_bytes > 64 * 1024)
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_env_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+  *out = e;
+  return PBHC_OK;
+}
+
+void pbhc_env_destroy(PbhcEnv* e) {
+  if (!e) return;
+  hipFree(e->d_cfg);
+  hipFree(e->d_partials);
+  delete e;
+}
+
+int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
+  ARG_CHECK(e && io);
+  ARG_CHECK(io->actions_in && io->frame_root && io->frame_dof_pos && io->frame_dof_vel && io->frame_contact);
+  ARG_CHECK(io->root_states && io->dof_state && io->actions && io->last_actions && io->actions_after_delay && io->action_queue);
+  ARG_CHECK(io->last_dof_pos && io->last_dof_vel && io->torques && io->feet_air_time && io->contacts && io->contacts_filt);
+  ARG_CHECK(io->last_contacts && io->last_contacts_filt && io->kp_scale && io->kd_scale && io->rfi_lim_scale && io->rao_scale);
+  ARG_CHECK(io->motion_start_times && io->motion_len && io->end_time_ratio_buf && io->episode_sums && io->hist);
+  ARG_CHECK(io->episode_length_buf && io->last_episode_length_buf && io->reset_buf && io->action_delay_idx && io->motion_ids && io->time_out_buf);
+  ARG_CHECK(io->env_origins && io->dr_base_com && io->dr_link_mass && io->dr_friction && io->rew_buf);
+  for (int g = 0; g < e->cfg.num_groups; ++g) ARG_CHECK(io->obs[g] != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_env_step, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials,
+                     e->lds_stride, e->step_ctr);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks);
+  e->step_ctr++;
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int T, int N, int R, float gamma,
+             float lam, float* returns, float* advantages, double* stats, void* stream) {
+  ARG_CHECK(rewards && values && dones && last_values && returns && advantages && stats && T >= 1 && N >= 1 && R >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  size_t NR = (size_t)N * R, TN = (size_t)T * N;
+  int nb = (int)((TN + GAE_TPB - 1) / GAE_TPB);
+  hipLaunchKernelGGL(k_gae, dim3((unsigned)((NR + GAE_TPB - 1) / GAE_TPB)), dim3(GAE_TPB), 0, st, rewards, values, dones, last_values, T, N, R, gamma, lam, returns);
+  hipLaunchKernelGGL(k_adv_sum, dim3(nb), dim3(GAE_TPB), 0, st, returns, values, TN, R, advantages, stats);
+  hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(64), 0, st, stats, nb, (double)TN);
+  hipLaunchKernelGGL(k_adv_norm, dim3(nb), dim3(GAE_TPB), 0, st, advantages, TN, stats + 2 * nb);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+}  // extern "C"

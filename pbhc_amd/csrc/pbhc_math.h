@@ -1,0 +1,181 @@
+// pbhc_math.h — device-side quaternion / rotation algebra (xyzw), the "device functions of every
+// kernel" (SURVEY §8 a1).  Each function follows one function of the reference's
+// humanoidverse/isaac_utils/isaac_utils/rotations.py (line numbers cited) op for op, so that the
+// three algebraically different rotate formulas keep their own rounding.  Compiled with
+// -ffp-contract=off: the reference's eager torch ops are not fused either.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pbhc {
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 mul3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float norm3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+// rotations.py:82-97 / :244-253 (my_quat_rotate):  v(2w^2-1) + 2w(q x v) + 2 q (q.v)
+__device__ __forceinline__ f3 quat_rotate(f4 q, f3 v) {
+  float s = 2.0f * q.w * q.w - 1.0f;
+  f3 qv = mk3(q.x, q.y, q.z);
+  f3 c = cross3(qv, v);
+  float d = dot3(qv, v);
+  return mk3(v.x * s + c.x * q.w * 2.0f + q.x * d * 2.0f,
+             v.y * s + c.y * q.w * 2.0f + q.y * d * 2.0f,
+             v.z * s + c.z * q.w * 2.0f + q.z * d * 2.0f);
+}
+// rotations.py:101-116:  a - b + c
+__device__ __forceinline__ f3 quat_rotate_inverse(f4 q, f3 v) {
+  float s = 2.0f * q.w * q.w - 1.0f;
+  f3 qv = mk3(q.x, q.y, q.z);
+  f3 c = cross3(qv, v);
+  float d = dot3(qv, v);
+  return mk3(v.x * s - c.x * q.w * 2.0f + q.x * d * 2.0f,
+             v.y * s - c.y * q.w * 2.0f + q.y * d * 2.0f,
+             v.z * s - c.z * q.w * 2.0f + q.z * d * 2.0f);
+}
+// rotations.py:414-441: Hamilton product, 9-multiplication form
+__device__ __forceinline__ f4 quat_mul(f4 a, f4 b) {
+  float ww = (a.z + a.x) * (b.x + b.y);
+  float yy = (a.w - a.y) * (b.w + b.z);
+  float zz = (a.w + a.y) * (b.w - b.z);
+  float xx = ww + yy + zz;
+  float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+  f4 r;
+  r.w = qq - ww + (a.z - a.y) * (b.y - b.z);
+  r.x = qq - xx + (a.x + a.w) * (b.x + b.w);
+  r.y = qq - yy + (a.w - a.x) * (b.y + b.z);
+  r.z = qq - zz + (a.z + a.y) * (b.w - b.x);
+  return r;
+}
+__device__ __forceinline__ f4 quat_conj(f4 q) { return mk4(-q.x, -q.y, -q.z, q.w); }
+// maths.py:6-8 normalize (clamp 1e-9)
+__device__ __forceinline__ f4 quat_unit(f4 q) {
+  float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  n = fmaxf(n, 1e-9f);
+  return mk4(q.x / n, q.y / n, q.z / n, q.w / n);
+}
+__device__ __forceinline__ f3 normalize3(f3 v) {
+  float n = fmaxf(norm3(v), 1e-9f);
+  return mk3(v.x / n, v.y / n, v.z / n);
+}
+// rotations.py:210-232 slerp with the <0.001 sin and >=1 cos fall-backs
+__device__ __forceinline__ f4 slerp(f4 q0, f4 q1, float t) {
+  float c = q0.x * q1.x + q0.y * q1.y + q0.z * q1.z + q0.w * q1.w;
+  if (c < 0.0f) { q1.x = -q1.x; q1.y = -q1.y; q1.z = -q1.z; q1.w = -q1.w; }
+  c = fabsf(c);
+  float half = acosf(c);
+  float s = sqrtf(1.0f - c * c);
+  float ra = sinf((1.0f - t) * half) / s;
+  float rb = sinf(t * half) / s;
+  f4 r = mk4(ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w);
+  if (fabsf(s) < 0.001f) r = mk4(0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w);
+  if (fabsf(c) >= 1.0f) r = q0;
+  return r;
+}
+// rotations.py:257-268 heading = atan2 of the rotated x axis
+__device__ __forceinline__ float calc_heading(f4 q) {
+  f3 r = quat_rotate(q, mk3(1.0f, 0.0f, 0.0f));
+  return atan2f(r.y, r.x);
+}
+// rotations.py:138-145 with axis = z (as calc_heading_quat(_inv) :281-306 call it)
+__device__ __forceinline__ f4 quat_from_angle_z(float angle) {
+  float th = angle / 2.0f;
+  // normalize(axis) = (0,0,1)/max(1,1e-9)
+  f4 q = mk4(0.0f * sinf(th), 0.0f * sinf(th), 1.0f * sinf(th), cosf(th));
+  return quat_unit(q);
+}
+__device__ __forceinline__ f4 quat_from_angle_axis(float angle, f3 axis) {
+  float th = angle / 2.0f;
+  f3 a = normalize3(axis);
+  float s = sinf(th);
+  return quat_unit(mk4(a.x * s, a.y * s, a.z * s, cosf(th)));
+}
+// rotations.py:368-387 (+ maths.copysign :16-19)
+__device__ __forceinline__ f3 euler_xyz(f4 q) {
+  float sinr = 2.0f * (q.w * q.x + q.y * q.z);
+  float cosr = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+  float roll = atan2f(sinr, cosr);
+  float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+  float sgn = (sinp > 0.0f) ? 1.0f : ((sinp < 0.0f) ? -1.0f : 0.0f);
+  float pitch = (fabsf(sinp) >= 1.0f) ? (1.5707963267948966f * sgn) : asinf(sinp);
+  float siny = 2.0f * (q.w * q.z + q.x * q.y);
+  float cosy = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+  return mk3(roll, pitch, atan2f(siny, cosy));
+}
+
+// ---- wxyz helpers of the motion-library FK (rotations.py:519-636) --------------------------
+struct m33 { float m[9]; };
+__device__ __forceinline__ m33 quat_wxyz_to_matrix(float r, float i, float j, float k) {
+  float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+  m33 o;
+  o.m[0] = 1.0f - two_s * (j * j + k * k); o.m[1] = two_s * (i * j - k * r); o.m[2] = two_s * (i * k + j * r);
+  o.m[3] = two_s * (i * j + k * r); o.m[4] = 1.0f - two_s * (i * i + k * k); o.m[5] = two_s * (j * k - i * r);
+  o.m[6] = two_s * (i * k - j * r); o.m[7] = two_s * (j * k + i * r); o.m[8] = 1.0f - two_s * (i * i + j * j);
+  return o;
+}
+__device__ __forceinline__ m33 matmul33(const m33& a, const m33& b) {
+  m33 c;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int col = 0; col < 3; ++col)
+      c.m[r * 3 + col] = a.m[r * 3 + 0] * b.m[0 * 3 + col] + a.m[r * 3 + 1] * b.m[1 * 3 + col] + a.m[r * 3 + 2] * b.m[2 * 3 + col];
+  return c;
+}
+// rotations.py:554-578 axis-angle -> wxyz quaternion (Taylor below 1e-6)
+__device__ __forceinline__ void axis_angle_to_quat_wxyz(float ax, float ay, float az, float* q) {
+  float angle = sqrtf(ax * ax + ay * ay + az * az);
+  float half = angle * 0.5f;
+  float s = (fabsf(angle) < 1e-6f) ? (0.5f - (angle * angle) / 48.0f) : (sinf(half) / angle);
+  q[0] = cosf(half); q[1] = ax * s; q[2] = ay * s; q[3] = az * s;
+}
+// rotations.py:589-636 best-conditioned candidate, output xyzw
+__device__ __forceinline__ f4 matrix_to_quat_xyzw(const m33& M) {
+  const float* m = M.m;
+  float x0 = 1.0f + m[0] + m[4] + m[8], x1 = 1.0f + m[0] - m[4] - m[8], x2 = 1.0f - m[0] + m[4] - m[8], x3 = 1.0f - m[0] - m[4] + m[8];
+  float qa[4] = {x0 > 0.0f ? sqrtf(x0) : 0.0f, x1 > 0.0f ? sqrtf(x1) : 0.0f, x2 > 0.0f ? sqrtf(x2) : 0.0f, x3 > 0.0f ? sqrtf(x3) : 0.0f};
+  int best = 0;
+  for (int i = 1; i < 4; ++i) if (qa[i] > qa[best]) best = i;   // argmax, first on ties
+  float den = 2.0f * fmaxf(qa[best], 0.1f);
+  float c[4];
+  if (best == 0) { c[0] = qa[0] * qa[0]; c[1] = m[7] - m[5]; c[2] = m[2] - m[6]; c[3] = m[3] - m[1]; }
+  else if (best == 1) { c[0] = m[7] - m[5]; c[1] = qa[1] * qa[1]; c[2] = m[3] + m[1]; c[3] = m[2] + m[6]; }
+  else if (best == 2) { c[0] = m[2] - m[6]; c[1] = m[3] + m[1]; c[2] = qa[2] * qa[2]; c[3] = m[5] + m[7]; }
+  else { c[0] = m[3] - m[1]; c[1] = m[6] + m[2]; c[2] = m[7] + m[5]; c[3] = qa[3] * qa[3]; }
+  return mk4(c[1] / den, c[2] / den, c[3] / den, c[0] / den);
+}
+
+// ---- Philox4x32-10 counter RNG (own; the reference draws from torch's global generator, so
+// noise-on runs are compared statistically, never bitwise) ---------------------------------------
+__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in [0,1): 24 mantissa bits
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t env, uint32_t step, uint32_t stream, uint32_t idx) {
+  uint32_t o[4];
+  philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), env, step, stream, idx >> 2, o);
+  return u01(o[idx & 3]);
+}
+
+}  // namespace pbhc

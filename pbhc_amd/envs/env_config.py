@@ -1,0 +1,349 @@
+"""Config tree (the reference's YAML schema) -> PbhcEnvConfig + device-side output maps.
+
+Host-side, load-time.  Mirrors what the reference derives at construction:
+  * obs dims / sorted-key layout      helpers.determine_obs_dim (utils/helpers.py:47-80),
+                                      _post_config_observation_callback (legged_robot_base.py:787-793)
+  * history buffers                   HistoryHandler.__init__ (envs/env_utils/history_handler.py:12-31)
+  * reward list, scales * dt          _prepare_reward_function (legged_robot_base.py:167-233)
+  * body index sets                   _setup_robot_body_indices (base_task.py:169-205),
+                                      _init_tracking_config / _init_motion_extend (motion_tracking.py:203-242)
+  * gains / limits                    _init_buffers (legged_robot_base.py:74-108), isaacgym._process_dof_props
+A reward or observation name the kernels do not implement raises NotImplementedError — the
+reference would call `_reward_<name>` / `_get_obs_<name>`; we refuse instead of silently skipping.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+K = _lib.K
+
+SIGMA_KEYS = ["teleop_max_joint_pos", "teleop_upper_body_pos", "teleop_lower_body_pos", "teleop_vr_3point_pos", "teleop_feet_pos",
+              "teleop_body_rot", "teleop_body_vel", "teleop_body_ang_vel", "teleop_joint_pos", "teleop_joint_vel"]
+TERM_SIGMAS = {
+    "teleop_max_joint_position": [0], "teleop_body_position_extend": [1, 2], "teleop_vr_3point": [3], "teleop_body_position_feet": [4],
+    "teleop_body_rotation_extend": [5], "teleop_body_velocity_extend": [6], "teleop_body_ang_velocity_extend": [7],
+    "teleop_joint_position": [8], "teleop_joint_velocity": [9],
+}
+OBS_FEATURES = {
+    "base_lin_vel": "BASE_LIN_VEL", "base_ang_vel": "BASE_ANG_VEL", "projected_gravity": "PROJECTED_GRAVITY", "dof_pos": "DOF_POS",
+    "dof_vel": "DOF_VEL", "actions": "ACTIONS", "ref_motion_phase": "REF_MOTION_PHASE",
+    "dif_local_rigid_body_pos": "DIF_LOCAL_RIGID_BODY_POS", "local_ref_rigid_body_pos": "LOCAL_REF_RIGID_BODY_POS",
+    "vr_3point_pos": "VR_3POINT_POS", "dr_base_com": "DR_BASE_COM", "dr_link_mass": "DR_LINK_MASS", "dr_kp": "DR_KP", "dr_kd": "DR_KD",
+    "dr_friction": "DR_FRICTION", "dr_ctrl_delay": "DR_CTRL_DELAY", "relyaw": "RELYAW", "base_pos_z": "BASE_POS_Z",
+    "dif_joint_angles": "DIF_JOINT_ANGLES", "dif_joint_velocities": "DIF_JOINT_VELOCITIES",
+    "local_ref_rigid_body_vel": "LOCAL_REF_RIGID_BODY_VEL", "global_ref_rigid_body_vel": "GLOBAL_REF_RIGID_BODY_VEL",
+}
+
+
+def flatten_obs_dims(obs_cfg):
+    d = obs_cfg.obs_dims
+    if isinstance(d, list):
+        return {k: int(v) for item in d for k, v in item.items()}
+    return {k: int(v) for k, v in d.items()}
+
+
+def determine_obs_dim(cfg):
+    """helpers.determine_obs_dim: fills cfg.robot.algo_obs_dim_dict and returns (group dims, key dims, aux dims)."""
+    ob = cfg.obs
+    assert set(ob.noise_scales.keys()) == set(ob.obs_scales.keys())
+    dims = flatten_obs_dims(ob)
+    ob.obs_dims = dims
+    aux = {}
+    for aux_key, aux_cfg in ob.obs_auxiliary.items():
+        aux[aux_key] = sum(dims[k] * n for k, n in aux_cfg.items())
+    groups = {}
+    for g, keys in ob.obs_dict.items():
+        tot = 0
+        for key in keys:
+            k = key[:-4] if key.endswith("_raw") else key
+            tot += dims[k] if k in dims else aux[k]
+        groups[g] = tot
+    cfg.robot.algo_obs_dim_dict = groups
+    return groups, dims, aux
+
+
+class EnvLayout:
+    """Everything the host needs to know about the layouts the kernels use."""
+
+
+def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
+    ec = cfg.env.config
+    rc = cfg.robot
+    rw = cfg.rewards
+    ob = cfg.obs
+    dr = cfg.domain_rand
+    D, B, Bx = skel.num_dof, skel.num_bodies, skel.num_bodies_ext
+    if list(rc.dof_names) and len(rc.dof_names) != D:
+        raise _lib.PbhcError("config dof_names do not match the skeleton")
+    c = _lib.PbhcEnvConfig()
+    L = EnvLayout()
+    c.abi_version = K["PBHC_ABI_VERSION"]
+    c.num_envs = num_envs
+    c.skel = skel.to_c()
+    sim = cfg.simulator.config.sim
+    dt = sim.control_decimation * (1.0 / sim.fps)
+    c.dt = dt
+    L.dt = dt
+    L.max_episode_length = float(np.ceil(ec.max_episode_length_s / dt))
+    c.max_episode_length = L.max_episode_length
+    c.max_episode_length_s = float(ec.max_episode_length_s)
+    # ---- control
+    ctrl = rc.control
+    if ctrl.control_type != "P":
+        raise NotImplementedError(f"control_type {ctrl.control_type!r} (only 'P' is on the hot path)")
+    for i, name in enumerate(rc.dof_names):
+        c.default_dof_pos[i] = float(rc.init_state.default_joint_angles[name])
+        found = False
+        for k in ctrl.stiffness.keys():
+            if k in name:
+                c.p_gains[i] = float(ctrl.stiffness[k])
+                c.d_gains[i] = float(ctrl.damping[k])
+                found = True
+                c.action_scale[i] = float(ctrl.action_scale if isinstance(ctrl.action_scale, (int, float)) else ctrl.action_scale[k])
+        if not found:
+            raise ValueError(f"PD gain of joint {name} were not defined. Should be defined in the yaml file.")
+        c.torque_limits[i] = float(rc.dof_effort_limit_list[i])
+        c.dof_vel_limits[i] = float(rc.dof_vel_limit_list[i])
+        lo, hi = np.float32(rc.dof_pos_lower_limit_list[i]), np.float32(rc.dof_pos_upper_limit_list[i])
+        c.hard_dof_pos_limits[i][0], c.hard_dof_pos_limits[i][1] = float(lo), float(hi)
+        m = np.float32((lo + hi) / np.float32(2))
+        r = np.float32(hi - lo)
+        s = rw.reward_limit.soft_dof_pos_limit
+        c.soft_dof_pos_limits[i][0] = float(np.float32(m - np.float32(np.float32(0.5) * r) * np.float32(s)))
+        c.soft_dof_pos_limits[i][1] = float(np.float32(m + np.float32(np.float32(0.5) * r) * np.float32(s)))
+    c.action_clip_value = float(ctrl.action_clip_value)
+    c.clip_torques = int(bool(ctrl.clip_torques))
+    c.randomize_torque_rfi = int(bool(dr.randomize_torque_rfi))
+    c.rfi_lim = float(dr.get("rfi_lim", 0.0))
+    c.use_rao = int(bool(dr.use_rao))
+    c.rao_lim = float(dr.get("rao_lim", 0.0))
+    c.randomize_ctrl_delay = int(bool(dr.randomize_ctrl_delay))
+    c.queue_len = int(dr.ctrl_delay_step_range[1]) + 1 if dr.randomize_ctrl_delay else 1
+    c.ctrl_delay_range[0], c.ctrl_delay_range[1] = int(dr.ctrl_delay_step_range[0]), int(dr.ctrl_delay_step_range[1])
+    c.randomize_pd_gain = int(bool(dr.randomize_pd_gain))
+    c.kp_range[0], c.kp_range[1] = float(dr.kp_range[0]), float(dr.kp_range[1])
+    c.kd_range[0], c.kd_range[1] = float(dr.kd_range[0]), float(dr.kd_range[1])
+    c.randomize_rfi_lim = int(bool(dr.randomize_rfi_lim))
+    c.rfi_lim_range[0], c.rfi_lim_range[1] = float(dr.rfi_lim_range[0]), float(dr.rfi_lim_range[1])
+    for unsupported in ("parallel_serial_pd", "parallel_serial_tau"):
+        if unsupported in dr and dr[unsupported].get("enable", False):
+            raise NotImplementedError(f"domain_rand.{unsupported}")
+    if dr.get("randomize_default_dof_pos", False):
+        raise NotImplementedError("domain_rand.randomize_default_dof_pos")
+    # ---- body index sets
+    names = skel.body_names
+    ext = skel.body_names_ext
+    feet = [names.index(s) for s in names if rc.foot_name in s]
+    if len(feet) != 2:
+        raise _lib.PbhcError(f"expected 2 feet, found {len(feet)}")
+    c.num_feet = len(feet)
+    for i, f in enumerate(feet):
+        c.feet[i] = f
+    pen = []
+    for n in rc.penalize_contacts_on:
+        pen.extend([names.index(s) for s in names if n in s])
+    c.num_penalised = len(pen)
+    for i, p in enumerate(pen):
+        c.penalised[i] = p
+    m = rc.motion
+    upper = [ext.index(l) for l in m.get("upper_body_link", [])]
+    lower = [ext.index(l) for l in m.get("lower_body_link", [])]
+    track = [ext.index(l) for l in m.get("motion_tracking_link", [])]
+    c.num_upper, c.num_lower, c.num_track = len(upper), len(lower), len(track)
+    for i, b in enumerate(upper):
+        c.upper[i] = b
+    for i, b in enumerate(lower):
+        c.lower[i] = b
+    for i, b in enumerate(track):
+        c.track[i] = b
+    for b in range(Bx):
+        c.body_flags[b] = (1 if b in upper else 0) | (2 if b in lower else 0) | (4 if b in track else 0) | (8 if b in feet else 0)
+        c.track_slot[b] = track.index(b) if b in track else -1
+    L.feet, L.penalised, L.upper, L.lower, L.track = feet, pen, upper, lower, track
+    # ---- termination
+    T = ec.termination
+    for flag in ("terminate_by_contact", "terminate_by_low_height", "terminate_when_close_to_dof_pos_limit",
+                 "terminate_when_close_to_dof_vel_limit", "terminate_when_close_to_torque_limit", "terminate_when_dof_far"):
+        if T.get(flag, False):
+            raise NotImplementedError(f"termination.{flag}")
+    c.terminate_by_gravity = int(bool(T.terminate_by_gravity))
+    c.termination_gravity = float(ec.termination_scales.termination_gravity)
+    c.terminate_when_motion_far = int(bool(T.terminate_when_motion_far))
+    c.terminate_when_motion_end = int(bool(T.terminate_when_motion_end))
+    tc = ec.termination_curriculum
+    c.motion_far_curriculum = int(bool(tc.terminate_when_motion_far_curriculum))
+    c.motion_far_degree = float(tc.terminate_when_motion_far_curriculum_degree)
+    c.motion_far_down = float(tc.terminate_when_motion_far_curriculum_level_down_threshold)
+    c.motion_far_up = float(tc.terminate_when_motion_far_curriculum_level_up_threshold)
+    c.motion_far_min = float(tc.terminate_when_motion_far_threshold_min)
+    c.motion_far_max = float(tc.terminate_when_motion_far_threshold_max)
+    # ---- rewards
+    scales = {}
+    for k, v in rw.reward_scales.items():
+        if v != 0:
+            scales[k] = v * dt
+    L.reward_scales = scales
+    L.reward_names = [k for k in scales if k != "termination"]
+    L.sum_names = list(scales.keys())
+    c.num_terms = len(L.reward_names)
+    if c.num_terms > min(K["PBHC_MAX_TERMS"], 31):
+        raise _lib.PbhcError("too many reward terms")
+    c.use_vec_reward = int(bool(ec.use_vec_reward))
+    c.num_rew_cols = c.num_terms + 1 if ec.use_vec_reward else 1
+    L.num_rew_fn = c.num_rew_cols
+    pen_names = set(rw.reward_penalty_reward_names)
+    for i, name in enumerate(L.reward_names):
+        key = "PBHC_R_" + name.upper()
+        if key not in K:
+            raise NotImplementedError(f"reward term {name!r} has no HIP implementation")
+        c.term_id[i] = K[key]
+        c.term_scale[i] = float(scales[name])
+        c.term_penalty[i] = int(name in pen_names and bool(rw.reward_penalty_curriculum))
+        c.term_sum_col[i] = L.sum_names.index(name)
+        for s in TERM_SIGMAS.get(name, []):
+            c.sigma_active[s] = 1
+    c.has_termination = int("termination" in scales)
+    if c.has_termination:
+        c.termination_scale = float(scales["termination"])
+        c.termination_sum_col = L.sum_names.index("termination")
+    c.num_sum_cols = len(L.sum_names)
+    c.only_positive_rewards = int(bool(rw.only_positive_rewards))
+    c.body_pos_lower_weight = float(rw.get("teleop_body_pos_lowerbody_weight", 1.0))
+    c.body_pos_upper_weight = float(rw.get("teleop_body_pos_upperbody_weight", 1.0))
+    c.desired_feet_air_time = float(rw.get("desired_feet_air_time", 0.0))
+    c.max_contact_force = float(rw.get("locomotion_max_contact_force", 0.0))
+    ats = rw.get("adaptive_tracking_sigma", {})
+    c.adaptive_sigma = int(bool(ats.get("enable", False)))
+    if c.adaptive_sigma and ats.get("type", "origin") != "origin":
+        raise NotImplementedError("adaptive_tracking_sigma.type other than 'origin'")
+    c.adaptive_alpha = float(ats.get("alpha", 0.0))
+    c.penalty_curriculum = int(bool(rw.reward_penalty_curriculum))
+    c.penalty_degree = float(rw.reward_penalty_degree)
+    c.penalty_down = float(rw.reward_penalty_level_down_threshold)
+    c.penalty_up = float(rw.reward_penalty_level_up_threshold)
+    c.penalty_min = float(rw.reward_min_penalty_scale)
+    c.penalty_max = float(rw.reward_max_penalty_scale)
+    c.num_compute_average_epl = int(rw.num_compute_average_epl)
+    lc = rw.reward_limit.reward_limits_curriculum
+    c.soft_pos_curriculum = int(bool(lc.soft_dof_pos_curriculum))
+    c.soft_vel_curriculum = int(bool(lc.soft_dof_vel_curriculum))
+    c.soft_tau_curriculum = int(bool(lc.soft_torque_curriculum))
+    for pre in ("soft_dof_pos", "soft_dof_vel", "soft_torque"):
+        if lc[pre + "_curriculum"] and lc[pre + "_min_limit"] != lc[pre + "_max_limit"]:
+            raise NotImplementedError(f"non-degenerate {pre} limit curriculum")        # shipped yamls have min == max
+    c.soft_dof_vel_limit = float(rw.reward_limit.soft_dof_vel_limit)
+    c.soft_torque_limit = float(rw.reward_limit.soft_torque_limit)
+    # ---- features
+    groups, dims, aux = determine_obs_dim(cfg)
+    L.obs_dims, L.group_dims = dims, groups
+    hist_len = {}
+    for aux_cfg in ob.obs_auxiliary.values():
+        for k, n in aux_cfg.items():
+            hist_len[k] = max(hist_len.get(k, 0), int(n))
+    hist_keys = sorted(hist_len.keys())
+    hist_off, o = {}, 0
+    for k in hist_keys:
+        hist_off[k] = o
+        o += hist_len[k] * dims[k]
+    c.hist_dim = max(o, 1)
+    L.hist_keys, L.hist_len, L.hist_off, L.hist_dim = hist_keys, hist_len, hist_off, c.hist_dim
+    fdim = {
+        "BASE_LIN_VEL": 3, "BASE_ANG_VEL": 3, "PROJECTED_GRAVITY": 3, "DOF_POS": D, "DOF_VEL": D, "ACTIONS": D, "REF_MOTION_PHASE": 1,
+        "DIF_LOCAL_RIGID_BODY_POS": 3 * Bx, "LOCAL_REF_RIGID_BODY_POS": 3 * Bx, "VR_3POINT_POS": 3 * max(len(track), 1),
+        "DR_BASE_COM": 3, "DR_LINK_MASS": max(sim_link_mass_dim, 1), "DR_KP": D, "DR_KD": D, "DR_FRICTION": 1, "DR_CTRL_DELAY": 1,
+        "RELYAW": 1, "BASE_POS_Z": 1, "DIF_JOINT_ANGLES": D, "DIF_JOINT_VELOCITIES": D, "LOCAL_REF_RIGID_BODY_VEL": 3 * Bx,
+        "GLOBAL_REF_RIGID_BODY_VEL": 3 * Bx, "HISTORY": c.hist_dim, "ZERO": 1,
+    }
+    off = 0
+    feat_off = {}
+    for name, n in fdim.items():
+        feat_off[name] = off
+        c.feat_off[K["PBHC_F_" + name]] = off
+        off += n
+    c.feat_dim = off
+    c.dr_link_mass_dim = sim_link_mass_dim
+    L.feat_off, L.feat_dim_each = feat_off, fdim
+
+    def key_sources(key):
+        """feature-row indices of observation key `key` (flat, in the reference's element order)."""
+        if key in ob.obs_auxiliary:                      # _get_obs_history_* (motion_tracking.py:993-1015)
+            idx = []
+            a = ob.obs_auxiliary[key]
+            for hk in sorted(a.keys()):
+                n = int(a[hk])
+                base = feat_off["HISTORY"] + hist_off[hk]
+                idx.extend(range(base, base + n * dims[hk]))
+            return idx
+        if key not in OBS_FEATURES:
+            raise NotImplementedError(f"observation {key!r} has no HIP implementation")
+        f = OBS_FEATURES[key]
+        if dims[key] > fdim[f]:
+            raise _lib.PbhcError(f"obs_dims[{key}]={dims[key]} exceeds the feature size {fdim[f]}")
+        return list(range(feat_off[f], feat_off[f] + dims[key]))
+
+    maps = []           # (name, src, scale, noise, clip)
+    for g, keys in ob.obs_dict.items():
+        src, sc, ns = [], [], []
+        for key in sorted(keys):
+            raw = key.endswith("_raw")
+            k = key[:-4] if raw else key
+            idx = key_sources(k)
+            src.extend(idx)
+            sc.extend([float(ob.obs_scales[k])] * len(idx))
+            ns.extend([0.0 if raw else float(ob.noise_scales[k])] * len(idx))
+        assert len(src) == groups[g], (g, len(src), groups[g])
+        maps.append((g, src, sc, ns, 1))
+    # history write-back: new[k][0] = parse(current k), new[k][t] = old[k][t-1]  (history_handler.py:40-44)
+    src, sc, ns = [], [], []
+    for hk in hist_keys:
+        cur = key_sources(hk)
+        src.extend(cur); sc.extend([float(ob.obs_scales[hk])] * len(cur)); ns.extend([float(ob.noise_scales[hk])] * len(cur))
+        base = feat_off["HISTORY"] + hist_off[hk]
+        n_old = (hist_len[hk] - 1) * dims[hk]
+        src.extend(range(base, base + n_old)); sc.extend([1.0] * n_old); ns.extend([0.0] * n_old)
+    if not src:
+        src, sc, ns = [feat_off["ZERO"]], [1.0], [0.0]
+    maps.append(("__history__", src, sc, ns, 0))
+    if len(maps) > K["PBHC_MAX_GROUPS"]:
+        raise _lib.PbhcError("too many observation groups")
+    c.num_groups = len(maps)
+    L.group_names = [m[0] for m in maps]
+    L.map_tensors = []
+    for i, (g, src, sc, ns, clip) in enumerate(maps):
+        ts = torch.tensor(src, dtype=torch.int32, device=device)
+        tsc = torch.tensor(sc, dtype=torch.float32, device=device)
+        tn = torch.tensor(ns, dtype=torch.float32, device=device)
+        L.map_tensors.append((ts, tsc, tn))
+        c.groups[i].dim = len(src)
+        c.groups[i].clip = clip
+        c.groups[i].src = ts.data_ptr()
+        c.groups[i].scale = tsc.data_ptr()
+        c.groups[i].noise = tn.data_ptr()
+    c.clip_observations = float(ec.normalization.clip_observations)
+    c.has_contact_mask = int(bool(motion_lib.has_contact_mask))
+    if "teleop_contact_mask" in L.reward_names and not motion_lib.has_contact_mask:
+        raise AttributeError("teleop_contact_mask reward needs a motion file with contact_mask")   # reference raises too (motion_tracking.py:1156)
+    c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    # ---- initial globals
+    g = np.zeros(K["PBHC_NUM_GLOBALS"], dtype=np.float64)
+    for i, k in enumerate(SIGMA_KEYS):
+        v = float(rw.reward_tracking_sigma.get(k, 1.0)) if "reward_tracking_sigma" in rw else 1.0
+        g[K["PBHC_G_SIGMA"] + i] = v
+        g[K["PBHC_G_EMA"] + i] = v
+    g[K["PBHC_G_PENALTY_SCALE"]] = float(rw.reward_initial_penalty_scale) if rw.reward_penalty_curriculum else 1.0
+    g[K["PBHC_G_AVG_EP_LEN"]] = 0.0
+    g[K["PBHC_G_MOTION_FAR_THR"]] = float(tc.terminate_when_motion_far_initial_threshold if (T.terminate_when_motion_far and tc.terminate_when_motion_far_curriculum)
+                                           else ec.termination_scales.termination_motion_far_threshold)
+    g[K["PBHC_G_SOFT_POS_VAL"]] = float(lc.soft_dof_pos_initial_limit)
+    g[K["PBHC_G_SOFT_VEL_VAL"]] = float(lc.soft_dof_vel_initial_limit)
+    g[K["PBHC_G_SOFT_TAU_VAL"]] = float(lc.soft_torque_initial_limit)
+    g[K["PBHC_G_NOISE_CURRICULUM"]] = float(ob.noise_initial_value) if ob.get("add_noise_currculum", False) else 1.0
+    if ob.get("add_noise_currculum", False):
+        raise NotImplementedError("obs.add_noise_currculum")
+    if "noise_process" in ob and ob.noise_process.get("enable", False):
+        raise NotImplementedError("obs.noise_process")
+    L.globals0 = g
+    return c, L

@@ -1,0 +1,339 @@
+"""LeggedRobotMotionTracking — drop-in for the reference's KungfuBot (v1) env, running the whole
+`step()` as one fused HIP launch.
+
+Same constructor, methods, attributes and return values as the reference class
+(reference: humanoidverse/envs/motion_tracking/motion_tracking.py:97-135 on top of
+legged_robot_base.py:29-37,239-265 and base_task.py:19-93), selected the same way:
+`env._target_: pbhc_amd.envs.motion_tracking.LeggedRobotMotionTracking`.
+`step(actor_state)` returns `(obs_dict, rew_buf, reset_buf, extras)` with env-owned tensors that
+are overwritten by the next step, as in the reference.  There is no eager / CPU path: every step
+goes through `pbhc_env_step`; construction fails if libpbhc_hip.so is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..motion_lib import MotionLib
+from . import env_config
+
+K = _lib.K
+
+
+def get_class(path):
+    mod, name = path.rsplit(".", 1)
+    return getattr(importlib.import_module(mod), name)
+
+
+class LeggedRobotMotionTracking:
+    def __init__(self, config, device):
+        """config = cfg.env.config (with .robot/.obs/.rewards/.domain_rand/.terrain/.simulator aliased
+        to the top-level nodes, as Hydra composes it)."""
+        self.init_done = False
+        self.config = config
+        self._lib = _lib.lib()
+        self.is_evaluating = False
+        # ---- BaseTask.__init__ (base_task.py:20-64)
+        self.simulator = get_class(config.simulator._target_)(config=config, device=device)
+        self.headless = config.headless
+        self.simulator.set_headless(self.headless)
+        self.simulator.setup()
+        self.device = torch.device(self.simulator.sim_device)
+        self.sim_dt = self.simulator.sim_dt
+        self.up_axis_idx = 2
+        self.dt = config.simulator.config.sim.control_decimation * self.sim_dt
+        self.max_episode_length_s = config.max_episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.num_envs = N = config.num_envs
+        self.dim_actions = config.robot.actions_dim
+        self.simulator.setup_terrain(config.terrain.mesh_type)
+        self.num_dof, self.num_bodies, self.dof_names, self.body_names = self.simulator.load_assets()
+        assert self.num_dof == self.dim_actions, "Number of DOFs must be equal to number of actions"
+        self.num_dofs = self.num_dof
+        dev = self.device
+        rc = config.robot
+        base = list(rc.init_state.pos) + list(rc.init_state.rot) + list(rc.init_state.lin_vel) + list(rc.init_state.ang_vel)
+        self.base_init_state = torch.tensor(base, dtype=torch.float, device=dev)
+        self._get_env_origins()
+        self.simulator.create_envs(N, self.env_origins, self.base_init_state)
+        self.dof_pos_limits, self.dof_vel_limits, self.torque_limits = self.simulator.get_dof_limits_properties()
+        self.simulator.prepare_sim()
+        self.viewer = None
+        # ---- motion library (motion_tracking.py:171-199)
+        self.skeleton = self.simulator.skeleton
+        rc.motion.step_dt = self.dt
+        self._motion_lib = MotionLib.from_config(rc.motion, self.skeleton, N, dev)
+        self._motion_lib.load_motions(random_sample=not self.is_evaluating)
+        for e in rc.motion.get("extend_config", []):
+            self.simulator._body_list.append(e["joint_name"])           # motion_tracking.py:226
+        self.num_extend_bodies = len(rc.motion.get("extend_config", []))
+        # ---- static config -> device
+        top = _TopView(config)
+        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        self._c, self.layout = env_config.build(top, self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1], seed=seed)
+        L = self.layout
+        self.reward_names = L.reward_names
+        self.reward_scales = L.reward_scales
+        self.feet_indices = torch.tensor(L.feet, dtype=torch.long, device=dev)
+        self.penalised_contact_indices = torch.tensor(L.penalised, dtype=torch.long, device=dev)
+        self.motion_tracking_id, self.lower_body_id, self.upper_body_id = L.track, L.lower, L.upper
+        self.globals = torch.tensor(L.globals0, dtype=torch.float64, device=dev)
+        # reference yaw of env 0 at t = dt (motion_tracking.py:186-187); host-side, once
+        ref0 = self._motion_lib.get_motion_state(torch.zeros(1, dtype=torch.long, device=dev), torch.full((1,), self.dt, device=dev), offset=self.env_origins[:1])
+        q = ref0["root_rot"][0].tolist()
+        self.ref_init_yaw = float(np.arctan2(2.0 * (q[3] * q[2] + q[0] * q[1]), q[3] * q[3] + q[0] * q[0] - q[1] * q[1] - q[2] * q[2]))
+        self._c.ref_init_yaw = self.ref_init_yaw
+        self._env = C.c_void_p()
+        _lib.check(self._lib.pbhc_env_create(C.byref(self._c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(self._env)), "pbhc_env_create")
+        self._init_buffers()
+        self._build_io()
+        self.log_dict = {}
+        self.extras = {}
+        self.common_step_counter = 0
+        self._resample_motion_times(torch.arange(N, device=dev))
+        self.init_done = True
+
+    # ------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_env", None):
+                self._lib.pbhc_env_destroy(self._env)
+                self._env = None
+        except Exception:
+            pass
+
+    def _get_env_origins(self):
+        # base_task.py:102-138, plane terrain branch
+        N, dev = self.num_envs, self.device
+        self.custom_origins = False
+        self.env_origins = torch.zeros(N, 3, device=dev)
+        num_cols = np.floor(np.sqrt(N))
+        num_rows = np.ceil(N / num_cols)
+        xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+        spacing = self.config.env_spacing
+        self.env_origins[:, 0] = (spacing * xx.flatten()[:N]).to(dev)
+        self.env_origins[:, 1] = (spacing * yy.flatten()[:N]).to(dev)
+
+    def _init_buffers(self):
+        N, D, dev, L = self.num_envs, self.num_dof, self.device, self.layout
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.actions, self.last_actions, self.actions_after_delay = f(N, D), f(N, D), f(N, D)
+        self.action_queue = f(N, self._c.queue_len, D)
+        dr = self.config.domain_rand
+        if dr.randomize_ctrl_delay:
+            self.action_delay_idx = torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev)
+        else:
+            self.action_delay_idx = torch.zeros(N, dtype=torch.long, device=dev)
+        self.last_dof_pos, self.last_dof_vel, self.torques = f(N, D), f(N, D), f(N, D)
+        self.feet_air_time, self.contacts, self.contacts_filt = f(N, 2), f(N, 2), f(N, 2)
+        self.last_contacts, self.last_contacts_filt = f(N, 2), f(N, 2)
+        self._kp_scale, self._kd_scale = torch.ones(N, D, device=dev), torch.ones(N, D, device=dev)
+        self._rfi_lim_scale, self._rao_scale = torch.ones(N, D, device=dev), torch.ones(N, D, device=dev)
+        self.motion_start_times, self.motion_len, self.end_time_ratio_buf = f(N), f(N), f(N)
+        self._episode_sums = f(N, len(L.sum_names))
+        self.episode_sums = {name: self._episode_sums[:, i] for i, name in enumerate(L.sum_names)}
+        self._episode_rew_out = f(N, len(L.sum_names))
+        self._hist = f(N, L.hist_dim)
+        self._episode_length_buf = torch.zeros(N, dtype=torch.long, device=dev)
+        self.last_episode_length_buf = torch.zeros(N, dtype=torch.long, device=dev)
+        self.reset_buf = torch.ones(N, dtype=torch.long, device=dev)
+        self.time_out_buf = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.motion_ids = torch.arange(N, device=dev)
+        self.rew_buf = f(N, L.num_rew_fn) if self.config.use_vec_reward else f(N)
+        self.obs_buf_dict = {g: f(N, L.group_dims[g]) for g in L.group_names[:-1]}
+        Bx = self.skeleton.num_bodies_ext
+        self.ref_body_pos_extend, self.ref_body_rot_extend = f(N, Bx, 3), f(N, Bx, 4)
+        self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(D)], device=dev).repeat(N, 1)
+        self.p_gains = torch.tensor([self._c.p_gains[i] for i in range(D)], device=dev)
+        self.d_gains = torch.tensor([self._c.d_gains[i] for i in range(D)], device=dev)
+
+    @property
+    def history(self):
+        """per-key views [N, len, dim] of the packed history state (HistoryHandler.history)."""
+        L = self.layout
+        return {k: self._hist[:, L.hist_off[k]:L.hist_off[k] + L.hist_len[k] * L.obs_dims[k]].view(self.num_envs, L.hist_len[k], L.obs_dims[k]) for k in L.hist_keys}
+
+    @property
+    def episode_length_buf(self):
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, v):           # MHPPO.learn assigns it (mh_ppo.py:208)
+        self._episode_length_buf.copy_(v.to(self._episode_length_buf.dtype))
+
+    @property
+    def num_rew_fn(self):
+        return self.layout.num_rew_fn
+
+    def _build_io(self):
+        s = self.simulator
+        io = _lib.PbhcStepIO()
+        p = lambda t: t.data_ptr()
+        io.root_states, io.dof_state = p(s.robot_root_states), p(s.dof_state)
+        io.rigid_body_state, io.contact_forces = p(s._rigid_body_state), p(s.contact_forces)
+        io.actions, io.last_actions, io.actions_after_delay, io.action_queue = p(self.actions), p(self.last_actions), p(self.actions_after_delay), p(self.action_queue)
+        io.last_dof_pos, io.last_dof_vel, io.torques = p(self.last_dof_pos), p(self.last_dof_vel), p(self.torques)
+        io.feet_air_time, io.contacts, io.contacts_filt = p(self.feet_air_time), p(self.contacts), p(self.contacts_filt)
+        io.last_contacts, io.last_contacts_filt = p(self.last_contacts), p(self.last_contacts_filt)
+        io.kp_scale, io.kd_scale, io.rfi_lim_scale, io.rao_scale = p(self._kp_scale), p(self._kd_scale), p(self._rfi_lim_scale), p(self._rao_scale)
+        io.motion_start_times, io.motion_len, io.end_time_ratio_buf = p(self.motion_start_times), p(self.motion_len), p(self.end_time_ratio_buf)
+        io.episode_sums, io.hist = p(self._episode_sums), p(self._hist)
+        io.episode_length_buf, io.last_episode_length_buf = p(self._episode_length_buf), p(self.last_episode_length_buf)
+        io.reset_buf, io.action_delay_idx = p(self.reset_buf), p(self.action_delay_idx)
+        self._slot_clip = self._motion_lib.slot_clip.contiguous()
+        io.motion_ids = p(self._slot_clip)
+        io.time_out_buf = p(self.time_out_buf)
+        io.env_origins = p(self.env_origins)
+        self._friction_flat = s.friction_coeffs.reshape(self.num_envs, -1).contiguous()
+        io.dr_base_com, io.dr_link_mass, io.dr_friction = p(s._base_com_bias), p(s._link_mass_scale.contiguous()), p(self._friction_flat)
+        L = self.layout
+        for i, g in enumerate(L.group_names[:-1]):
+            io.obs[i] = p(self.obs_buf_dict[g])
+        io.obs[len(L.group_names) - 1] = p(self._hist)
+        io.rew_buf = p(self.rew_buf)
+        io.ref_body_pos_extend, io.ref_body_rot_extend = p(self.ref_body_pos_extend), p(self.ref_body_rot_extend)
+        io.episode_rew_out = p(self._episode_rew_out)
+        self._io = io
+        self._overrides = {}
+
+    # ---- test / replay hooks: inject the random draws instead of the in-kernel Philox ---------
+    def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None):
+        """Keeps the tensors alive and points the kernel at them (None -> in-kernel RNG)."""
+        self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay)
+        for k, v in self._overrides.items():
+            setattr(self._io, k, None if v is None else v.data_ptr())
+
+    # ------------------------------------------------------------------------------------
+    def set_is_evaluating(self):
+        self.is_evaluating = True
+
+    def _resample_motion_times(self, env_ids):
+        # motion_tracking.py:369-378
+        if len(env_ids) == 0:
+            return
+        self.motion_len[env_ids] = self._motion_lib.get_motion_length(self.motion_ids[env_ids])
+        if self.is_evaluating and not self.config.enforce_randomize_motion_start_eval:
+            self.motion_start_times[env_ids] = 0.0
+        else:
+            self.motion_start_times[env_ids] = self._motion_lib.sample_time(self.motion_ids[env_ids])
+
+    def reset_all(self):
+        """base_task.py:83-93: reset every env, then one step with zero actions.  Start-up path,
+        done with torch ops on the device (the per-step reset of terminated envs is in the kernel)."""
+        N, dev = self.num_envs, self.device
+        ids = torch.arange(N, device=dev)
+        g = self.globals
+        # _reset_buffers_callback (legged_robot_base.py:670-686)
+        for t in (self.actions, self.last_actions, self.actions_after_delay, self.last_dof_pos, self.last_dof_vel, self.feet_air_time,
+                  self.contacts, self.contacts_filt, self.last_contacts, self.last_contacts_filt, self._hist):
+            t.zero_()
+        cur = torch.mean(self.last_episode_length_buf, dtype=torch.float)
+        frac = N / self._c.num_compute_average_epl
+        avg = g[K["PBHC_G_AVG_EP_LEN"]].float() * (1 - frac) + cur * frac
+        g[K["PBHC_G_AVG_EP_LEN"]] = avg.double()
+        self._episode_length_buf.zero_()
+        self.reset_buf.fill_(1)
+        # _episodic_domain_randomization (legged_robot_base.py:599-635)
+        dr = self.config.domain_rand
+        D = self.num_dof
+        u = lambda lo, hi: (hi - lo) * torch.rand(N, D, device=dev) + lo
+        if dr.randomize_pd_gain:
+            self._kp_scale.copy_(u(dr.kp_range[0], dr.kp_range[1]))
+            self._kd_scale.copy_(u(dr.kd_range[0], dr.kd_range[1]))
+        if dr.randomize_rfi_lim:
+            self._rfi_lim_scale.copy_(u(dr.rfi_lim_range[0], dr.rfi_lim_range[1]))
+        if dr.use_rao:
+            self._rao_scale.copy_(u(-dr.rao_lim, dr.rao_lim))
+        if dr.randomize_ctrl_delay:
+            self.action_queue.zero_()
+            self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev))
+        # curricula keyed on average_episode_length (legged_robot_base.py:882-900, motion_tracking.py:309-317)
+        c = self._c
+        avg_f = float(avg)
+        if c.penalty_curriculum:
+            p = float(g[K["PBHC_G_PENALTY_SCALE"]])
+            p *= (1 - c.penalty_degree) if avg_f < c.penalty_down else ((1 + c.penalty_degree) if avg_f > c.penalty_up else 1.0)
+            g[K["PBHC_G_PENALTY_SCALE"]] = float(np.clip(p, c.penalty_min, c.penalty_max))
+        end_time = self.last_episode_length_buf * self.dt + self.motion_start_times
+        self.end_time_ratio_buf.copy_(end_time / self.motion_len.clamp(min=1e-9))
+        self._resample_motion_times(ids)
+        if c.terminate_when_motion_far and c.motion_far_curriculum:
+            t = float(g[K["PBHC_G_MOTION_FAR_THR"]])
+            t *= (1 + c.motion_far_degree) if avg_f < c.motion_far_down else ((1 - c.motion_far_degree) if avg_f > c.motion_far_up else 1.0)
+            g[K["PBHC_G_MOTION_FAR_THR"]] = float(np.clip(t, c.motion_far_min, c.motion_far_max))
+        # _reset_dofs / _reset_root_states from the reference frame at (0+1)*dt + start
+        ref = self._motion_lib.get_motion_state(self.motion_ids, (self._episode_length_buf + 1) * self.dt + self.motion_start_times, offset=self.env_origins)
+        s = self.simulator
+        s.dof_pos.copy_(ref["dof_pos"]); s.dof_vel.copy_(ref["dof_vel"])
+        s.robot_root_states[:, 0:3] = ref["root_pos"]; s.robot_root_states[:, 3:7] = ref["root_rot"]
+        s.robot_root_states[:, 7:10] = ref["root_vel"]; s.robot_root_states[:, 10:13] = ref["root_ang_vel"]
+        self.extras["episode"] = {"rew_" + k: (v / self.max_episode_length_s).clone() for k, v in self.episode_sums.items()}
+        self._episode_sums.zero_()
+        self.extras["time_outs"] = self.time_out_buf
+        obs_dict, _, _, _ = self.step({"actions": torch.zeros(N, self.dim_actions, device=dev)})
+        return obs_dict
+
+    def step(self, actor_state):
+        """legged_robot_base.py:239-265 — one fused launch."""
+        actions = actor_state["actions"]
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(self.device, torch.float32).contiguous()
+        if tuple(actions.shape) != (self.num_envs, self.num_dof):
+            raise _lib.PbhcError(f"actions must be [{self.num_envs},{self.num_dof}], got {tuple(actions.shape)}")
+        self._actions_in = actions
+        s = self.simulator
+        k = s.next_frame_index()
+        r = s.replay
+        io = self._io
+        io.actions_in = actions.data_ptr()
+        io.frame_root = r["root"][k].data_ptr()
+        io.frame_dof_pos = r["dof_pos"][k].data_ptr()
+        io.frame_dof_vel = r["dof_vel"][k].data_ptr()
+        io.frame_contact = r["contact"][k].data_ptr()
+        _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
+        self.common_step_counter += 1
+        self.extras["time_outs"] = self.time_out_buf
+        self.extras["ref_body_pos_extend"] = self.ref_body_pos_extend
+        self.extras["ref_body_rot_extend"] = self.ref_body_rot_extend
+        self.extras["to_log"] = self.log_dict
+        self.extras["episode_rew"] = self._episode_rew_out
+        return self.obs_buf_dict, self.rew_buf, self.reset_buf, self.extras
+
+    # ---- logging: device-side means, read back on demand (no per-step sync) ----------------
+    def read_log(self):
+        g = self.globals.cpu().numpy()
+        L0 = K["PBHC_G_LOG"]
+        out = {
+            "upper_body_diff_norm": g[L0 + K["PBHC_L_UPPER_BODY_DIFF_NORM"]], "lower_body_diff_norm": g[L0 + K["PBHC_L_LOWER_BODY_DIFF_NORM"]],
+            "vr_3point_diff_norm": g[L0 + K["PBHC_L_VR_3POINT_DIFF_NORM"]], "joint_pos_diff_norm": g[L0 + K["PBHC_L_JOINT_POS_DIFF_NORM"]],
+            "action_clip_frac": g[L0 + K["PBHC_L_ACTION_CLIP_FRAC"]], "terminate_by_gravity": g[L0 + K["PBHC_L_TERM_GRAVITY"]],
+            "terminate_by_motion_far": g[L0 + K["PBHC_L_TERM_MOTION_FAR"]], "terminate_by_time_out": g[L0 + K["PBHC_L_TERM_TIME_OUT"]],
+            "terminate_by_motion_end": g[L0 + K["PBHC_L_TERM_MOTION_END"]], "end_time_ratio": g[L0 + K["PBHC_L_END_TIME_RATIO"]],
+            "end_time_ratio_std": g[L0 + K["PBHC_L_END_TIME_RATIO_STD"]], "penalty_scale": g[K["PBHC_G_PENALTY_SCALE"]],
+            "average_episode_length": g[K["PBHC_G_AVG_EP_LEN"]], "terminate_when_motion_far_threshold": g[K["PBHC_G_MOTION_FAR_THR"]],
+            "reward_mean": g[L0 + K["PBHC_L_REW_MEAN"]],
+        }
+        for i, k in enumerate(env_config.SIGMA_KEYS):
+            out["adp_sigma_" + k] = g[K["PBHC_G_SIGMA"] + i]
+            out["error_ema_" + k] = g[K["PBHC_G_EMA"] + i]
+        self.log_dict.update({k: torch.tensor(float(v)) for k, v in out.items()})
+        return out
+
+
+class _TopView:
+    """env.config holds aliases of the top-level nodes; present them under the top-level names the
+    config builder uses (cfg.env.config, cfg.robot, cfg.obs, ...)."""
+
+    def __init__(self, env_cfg):
+        self.env = _NS(config=env_cfg)
+        self.robot, self.obs, self.rewards = env_cfg.robot, env_cfg.obs, env_cfg.rewards
+        self.domain_rand, self.terrain, self.simulator = env_cfg.domain_rand, env_cfg.terrain, env_cfg.simulator
+
+
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)

@@ -1,0 +1,158 @@
+"""Reference-motion library on the GPU: load-time FK tables + per-step phase lookup.
+
+Drop-in for the parts of MotionLibBase / MotionLibRobot / MotionLibRobotWJX the env uses
+(reference: humanoidverse/utils/motion_lib/motion_lib_base.py:123-259,261-391,486-513;
+motion_lib_robot_WJX.py:146-293).  Differences by design:
+* FK + filtered velocities run once per UNIQUE clip in HIP (`pbhc_motion_build`), not once per
+  env slot in Python; slots map to clips through `slot_clip`.
+* all per-frame quantities live in ONE packed row per frame
+  `[dof_pos D | dof_vel D | contact 2 | pos Bx*3 | rot Bx*4 | vel Bx*3 | ang Bx*3]`
+  so a lookup reads two contiguous rows.
+Motion files: the reference's joblib .pkl (read by the static, non-executing parser
+`pbhc_amd.utils.safe_pkl`) or an .npz with the same arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils import safe_pkl
+
+
+def load_motion_file(path):
+    """-> list of (name, clip dict) with root_trans_offset [F,3], pose_aa [F,Bx,3], fps, optional contact_mask [F,2]."""
+    if os.path.isdir(path):
+        out = []
+        for f in sorted(os.listdir(path)):
+            if f.endswith((".pkl", ".npz")):
+                out.extend(load_motion_file(os.path.join(path, f)))
+        return out
+    if path.endswith(".npz"):
+        z = np.load(path, allow_pickle=False)
+        names = sorted({k.split("::")[0] for k in z.files})
+        clips = []
+        for n in names:
+            c = {k.split("::")[1]: z[k] for k in z.files if k.startswith(n + "::")}
+            c["fps"] = int(c["fps"])
+            clips.append((n, c))
+        return clips
+    data = safe_pkl.load(path)
+    return [(k, v) for k, v in data.items()]
+
+
+def save_motion_npz(path, clips):
+    arrs = {}
+    for name, c in clips:
+        for k in ("root_trans_offset", "pose_aa", "contact_mask"):
+            if k in c:
+                arrs[f"{name}::{k}"] = np.asarray(c[k])
+        arrs[f"{name}::fps"] = np.int64(c["fps"])
+    np.savez_compressed(path, **arrs)
+
+
+class MotionLib:
+    def __init__(self, skeleton, clips, num_envs, device):
+        """clips: list of clip dicts (see load_motion_file)."""
+        self.skeleton = skeleton
+        self.device = torch.device(device)
+        self.num_envs = num_envs
+        self._csk = skeleton.to_c()
+        Bx, D = skeleton.num_bodies_ext, skeleton.num_dof
+        self.row = 2 * D + 2 + 13 * Bx
+        self.has_contact_mask = all("contact_mask" in c for c in clips)
+        self._contact_size = 2
+        rows, starts, nframes, dts, lens = [], [], [], [], []
+        s = 0
+        st = _lib.current_stream()
+        for c in clips:
+            fps = int(c["fps"])
+            pose = torch.as_tensor(np.asarray(c["pose_aa"], dtype=np.float32)[:, :Bx]).contiguous().to(self.device)
+            trans = torch.as_tensor(np.asarray(c["root_trans_offset"], dtype=np.float32)).contiguous().to(self.device)
+            if pose.shape[1] != Bx:
+                raise _lib.PbhcError(f"pose_aa has {pose.shape[1]} bodies, skeleton needs {Bx}")
+            F = pose.shape[0]
+            contact = None
+            if self.has_contact_mask:
+                contact = torch.as_tensor(np.asarray(c["contact_mask"], dtype=np.float32)).contiguous().to(self.device)
+                if tuple(contact.shape) != (F, 2):
+                    raise _lib.PbhcError(f"contact mask shape {tuple(contact.shape)} is not supported")
+            out = torch.empty(F, self.row, device=self.device)
+            scratch = torch.empty(F * Bx * 14, device=self.device)
+            _lib.check(_lib.lib().pbhc_motion_build(C.byref(self._csk), _lib.ptr(pose), _lib.ptr(trans), _lib.ptr(contact), F,
+                                                    1.0 / fps, _lib.ptr(out), _lib.ptr(scratch), st), "pbhc_motion_build")
+            torch.cuda.current_stream().synchronize()      # scratch/pose are freed after this iteration
+            rows.append(out)
+            starts.append(s); nframes.append(F); dts.append(1.0 / fps); lens.append(1.0 / fps * (F - 1))
+            s += F
+        self.frames = torch.cat(rows, dim=0).contiguous()
+        self.length_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
+        self.num_frames = torch.tensor(nframes, dtype=torch.int32, device=self.device)
+        self._motion_dt = torch.tensor(dts, dtype=torch.float32, device=self.device)
+        self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=self.device)
+        self._num_unique_motions = len(clips)
+        self._sampling_prob = torch.ones(len(clips), device=self.device) / len(clips)
+        self.slot_clip = torch.zeros(num_envs, dtype=torch.long, device=self.device)
+        self.table = _lib.PbhcMotionTable()
+        self.table.frames = self.frames.data_ptr()
+        self.table.row = self.row
+        self.table.num_motions = len(clips)
+        self.table.length_starts = self.length_starts.data_ptr()
+        self.table.num_frames = self.num_frames.data_ptr()
+        self.table.motion_dt = self._motion_dt.data_ptr()
+        self.table.motion_len = self._motion_lengths.data_ptr()
+
+    @classmethod
+    def from_config(cls, mcfg, skeleton, num_envs, device):
+        """mcfg = config.robot.motion (motion_file = .pkl / .npz / directory)."""
+        path = str(mcfg.motion_file)
+        if not os.path.isabs(path) and not os.path.exists(path):
+            path = os.path.join(_lib.ROOT, path)
+        clips = [c for _, c in load_motion_file(path)]
+        if mcfg.get("motion_lib_type", "origin") == "WJX" and len(clips) != 1:
+            raise _lib.PbhcError("Not Allowed to load more than one motion!")     # motion_lib_robot_WJX.py:202
+        return cls(skeleton, clips, num_envs, device)
+
+    # ---- slot -> clip assignment (load_motions, motion_lib_base.py:293-305) -----------------
+    def load_motions(self, random_sample=True, start_idx=0):
+        if random_sample:
+            self.slot_clip = torch.multinomial(self._sampling_prob, num_samples=self.num_envs, replacement=True)
+        else:
+            self.slot_clip = torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions)
+        return self.slot_clip
+
+    def get_motion_length(self, slot_ids=None):
+        if slot_ids is None:
+            return self._motion_lengths[self.slot_clip]
+        return self._motion_lengths[self.slot_clip[slot_ids]]
+
+    def sample_time(self, slot_ids):
+        # motion_lib_base.py:486-495
+        phase = torch.rand(slot_ids.shape, device=self.device)
+        return phase * self.get_motion_length(slot_ids)
+
+    def get_motion_state(self, slot_ids, motion_times, offset=None):
+        """motion_lib_base.py:123-259; returns the reference's dict keys (views of one packed buffer)."""
+        n = slot_ids.shape[0]
+        D, Bx, B = self.skeleton.num_dof, self.skeleton.num_bodies_ext, self.skeleton.num_bodies
+        ids = self.slot_clip[slot_ids].contiguous()
+        times = motion_times.to(torch.float32).contiguous()
+        off = None if offset is None else offset.to(torch.float32).contiguous()
+        out = torch.empty(n, self.row, device=self.device)
+        _lib.check(_lib.lib().pbhc_motion_state(C.byref(self.table), Bx, D, _lib.ptr(ids), _lib.ptr(times), _lib.ptr(off), n,
+                                                _lib.ptr(out), _lib.current_stream()), "pbhc_motion_state")
+        o_pos = 2 * D + 2
+        o_rot, o_vel, o_ang = o_pos + 3 * Bx, o_pos + 7 * Bx, o_pos + 10 * Bx
+        pos = out[:, o_pos:o_rot].view(n, Bx, 3)
+        rot = out[:, o_rot:o_vel].view(n, Bx, 4)
+        vel = out[:, o_vel:o_ang].view(n, Bx, 3)
+        ang = out[:, o_ang:].view(n, Bx, 3)
+        res = dict(root_pos=pos[:, 0], root_rot=rot[:, 0], dof_pos=out[:, :D], root_vel=vel[:, 0], root_ang_vel=ang[:, 0],
+                   dof_vel=out[:, D:2 * D], rg_pos=pos[:, :B], rb_rot=rot[:, :B], body_vel=vel[:, :B], body_ang_vel=ang[:, :B],
+                   rg_pos_t=pos, rg_rot_t=rot, body_vel_t=vel, body_ang_vel_t=ang)
+        if self.has_contact_mask:
+            res["contact_mask"] = out[:, 2 * D:2 * D + 2]
+        return res

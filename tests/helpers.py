@@ -43,3 +43,84 @@ def state_dict_from_golden(g, prefix="state0__", step=None):
             v = g[k]
             out[k[len(prefix):]] = v if step is None else v[step]
     return out
+
+
+# ---- HIP-side helpers (GPU tests, smoke, bench) ---------------------------------------------------
+STUB = "pbhc_amd.simulator.replay_stub.ReplaySimStub"
+
+
+def build_hip_env(cfgname, num_envs, device="cuda:0", noise_off=True, overrides=None):
+    from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking
+
+    ov = {"num_envs": num_envs, "simulator._target_": STUB}
+    ov.update(overrides or {})
+    cfg = load_config(os.path.join(GOLDEN, "configs", cfgname), ov, now="test")
+    if noise_off:
+        for k in list(cfg.obs.noise_scales.keys()):
+            cfg.obs.noise_scales[k] = 0.0
+    env = LeggedRobotMotionTracking(cfg.env.config, device)
+    return cfg, env
+
+
+def load_state_into_hip_env(env, st, g=None):
+    """st: state dict with the names of oracle/ref_harness/gen_env_golden.snapshot."""
+    from pbhc_amd.envs.env_config import SIGMA_KEYS
+    from pbhc_amd import _lib
+
+    K = _lib.K
+    dev = env.device
+    t = lambda k, dt=torch.float32: torch.as_tensor(np.asarray(st[k])).to(dev, dt)
+    s = env.simulator
+    s.robot_root_states.copy_(t("root_states"))
+    s.dof_pos.copy_(t("dof_pos")); s.dof_vel.copy_(t("dof_vel"))
+    s.contact_forces.copy_(t("contact_forces"))
+    for name in ["actions", "last_actions", "actions_after_delay", "action_queue", "last_dof_pos", "last_dof_vel", "torques", "feet_air_time",
+                 "contacts", "contacts_filt", "last_contacts", "last_contacts_filt", "motion_start_times", "motion_len", "end_time_ratio_buf"]:
+        getattr(env, name).copy_(t(name))
+    env._kp_scale.copy_(t("kp_scale")); env._kd_scale.copy_(t("kd_scale"))
+    env._rfi_lim_scale.copy_(t("rfi_lim_scale")); env._rao_scale.copy_(t("rao_scale"))
+    env.action_delay_idx.copy_(t("action_delay_idx", torch.long))
+    env._episode_length_buf.copy_(t("episode_length_buf", torch.long))
+    env.last_episode_length_buf.copy_(t("last_episode_length_buf", torch.long))
+    for name, col in env.episode_sums.items():
+        col.copy_(t("sum__" + name))
+    for name, view in env.history.items():
+        view.copy_(t("hist__" + name))
+    gl = env.globals
+    for i, k in enumerate(SIGMA_KEYS):
+        if "sigma__" + k in st:
+            gl[K["PBHC_G_SIGMA"] + i] = float(st["sigma__" + k])
+            gl[K["PBHC_G_EMA"] + i] = float(st.get("ema__" + k, st["sigma__" + k]))
+    gl[K["PBHC_G_PENALTY_SCALE"]] = float(st["reward_penalty_scale"])
+    gl[K["PBHC_G_AVG_EP_LEN"]] = float(st["average_episode_length"])
+    gl[K["PBHC_G_MOTION_FAR_THR"]] = float(st["motion_far_threshold"])
+    if g is not None:
+        env.env_origins.copy_(torch.from_numpy(g["env_origins"]).to(dev))
+        s._base_com_bias.copy_(torch.from_numpy(g["base_com_bias"]).to(dev))
+        s._link_mass_scale.copy_(torch.from_numpy(g["link_mass_scale"]).to(dev))
+        s.friction_coeffs.copy_(torch.from_numpy(g["friction_coeffs"]).to(dev))
+
+
+def synth_replay(ml, skel, N, T, start_times, ep_len, dt, origins, seed, feet, has_contact=True):
+    """Synthetic replay window on the CPU (oracle motion lib): state_k = ref((ep+k+1)dt+start) + noise."""
+    from oracle import rotations as R
+
+    g = torch.Generator().manual_seed(seed)
+    D, B = skel["dof_axis"].shape[0], skel["num_bodies"]
+    root = torch.zeros(T, N, 13); qp = torch.zeros(T, N, D); qv = torch.zeros(T, N, D); cf = torch.zeros(T, N, B, 3)
+    ids = torch.zeros(N, dtype=torch.long)
+    for k in range(T):
+        t = (ep_len + k + 1).float() * dt + start_times
+        ref = ml.get_motion_state(ids, t, offset=origins)
+        root[k, :, 0:3] = ref["root_pos"] + 0.02 * torch.randn(N, 3, generator=g)
+        small = R.normalize(torch.cat([0.02 * torch.randn(N, 3, generator=g), torch.ones(N, 1)], -1))
+        root[k, :, 3:7] = R.normalize(R.quat_mul(small, ref["root_rot"]))
+        root[k, :, 7:10] = ref["root_vel"] + 0.1 * torch.randn(N, 3, generator=g)
+        root[k, :, 10:13] = ref["root_ang_vel"] + 0.1 * torch.randn(N, 3, generator=g)
+        qp[k] = ref["dof_pos"] + 0.02 * torch.randn(N, D, generator=g)
+        qv[k] = ref["dof_vel"] + 0.1 * torch.randn(N, D, generator=g)
+        on = (ref["contact_mask"] > 0.5).float() if "contact_mask" in ref else (ref["rg_pos_t"][:, feet, 2] < 0.06).float()
+        on = torch.where(torch.rand(N, 2, generator=g) < 0.1, 1 - on, on)
+        cf[k, :, feet, 2] = on * (300.0 + 50.0 * torch.randn(N, 2, generator=g))
+        cf[k, :, feet, 0:2] = on.unsqueeze(-1) * 20.0 * torch.randn(N, 2, 2, generator=g)
+    return root, qp, qv, cf

@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path (through the C ABI of libpbhc_hip.so) against the oracle and the
+reference-generated golden traces.  Tolerances are fp32: rtol = atol = 2e-5 on observations /
+states, 1e-4 on exp()-amplified reward terms and velocity tables (different libm, tree reductions)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (GOLDEN, build_hip_env, clip_from_env_golden, fixture_config, load_env_golden, load_state_into_hip_env,
+                           skel_from_golden, state_dict_from_golden, synth_replay)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# Two quantities of the reference are discontinuous / ill-conditioned in fp32 and get a two-tier bound
+# (`hard` = worst case, `frac` = share of elements allowed above `tol`):
+#  * slerp (rotations.py:210-232) switches to 0.5*(q0+q1) when sin(half angle) < 1e-3: one ulp in the dot
+#    product flips the branch for near-static clips, a jump of up to |t-0.5|*|q1-q0| ~ 1e-3;
+#  * table angular velocities come from acos(2w^2-1) of a near-identity quaternion
+#    (torch_humanoid_batch.py:282-290): one ulp of w moves them by ~2e-4/|omega| rad/s.
+SLERP = dict(hard=1.2e-3, frac=0.05)
+ANGVEL = dict(hard=1e-2, frac=0.02, tol_override=2e-3)
+
+
+def close(a, b, tol, what, rtol=None, hard=None, frac=0.0, tol_override=None):
+    tol = tol if tol_override is None else tol_override
+    a = torch.as_tensor(a).detach().float().cpu()
+    b = torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    lim = tol + (tol if rtol is None else rtol) * b.abs()
+    bad = err > lim
+    if hard is not None:
+        assert float(err.max()) <= hard, (what, "hard bound", float(err.max()))
+        assert float(bad.float().mean()) <= frac, (what, float(err.max()), float(bad.float().mean()))
+        return
+    assert not bool(bad.any()), (what, float(err.max()), int(bad.sum()), bad.nonzero()[:5].tolist())
+
+
+def _hip_motion_lib(clip, N=8):
+    from pbhc_amd.motion_lib import MotionLib
+    from pbhc_amd.skeleton import Skeleton
+
+    sk = Skeleton.from_json(os.path.join(GOLDEN, "skeleton_g1_23dof_lock_wrist_fitmotionONLY.json"))
+    return sk, MotionLib(sk, [clip], N, DEV)
+
+
+def test_skeleton_json_matches_reference_tables():
+    from pbhc_amd.skeleton import Skeleton
+
+    sk = Skeleton.from_json(os.path.join(GOLDEN, "skeleton_g1_23dof_lock_wrist_fitmotionONLY.json"))
+    g = skel_from_golden()
+    assert sk.body_names_ext == g["body_names_ext"]
+    assert np.array_equal(sk.parents, g["parents"]) and np.allclose(sk.offsets, g["offsets"]) and np.allclose(sk.local_rot_wxyz, g["local_rot_wxyz"])
+    assert np.allclose(sk.dof_axis, g["dof_axis"])
+
+
+def test_motion_build_matches_reference_fk():
+    """pbhc_motion_build vs the reference's Humanoid_Batch.fk_batch outputs (golden)."""
+    g = dict(np.load(os.path.join(GOLDEN, "skeleton_fk_g1_23dof.npz")))
+    clip = dict(pose_aa=g["pose_aa"], root_trans_offset=g["root_trans_offset"], fps=int(g["fps"]))
+    sk, ml = _hip_motion_lib(clip)
+    D, Bx = sk.num_dof, sk.num_bodies_ext
+    rows = ml.frames.cpu()
+    F = rows.shape[0]
+    o = 2 * D + 2
+    close(rows[:, :D], g["dof_pos"], 2e-6, "dof_pos")
+    close(rows[:, D:2 * D], g["dof_vel"], 2e-5, "dof_vel")
+    close(rows[:, o:o + 3 * Bx].view(F, Bx, 3), g["gts_t"], 3e-6, "gts_t")
+    rot = rows[:, o + 3 * Bx:o + 7 * Bx].view(F, Bx, 4)
+    close(rot, g["grs_t"], 3e-6, "grs_t")
+    close(rows[:, o + 7 * Bx:o + 10 * Bx].view(F, Bx, 3), g["gvs_t"], 5e-5, "gvs_t")
+    # angular velocity = axis * acos(2w^2-1) / dt of a near-identity quaternion (reference
+    # torch_humanoid_batch.py:282-290) is ill-conditioned: one ulp of w moves it by ~4*ulp/(dt^2*|w|) ≈ 2e-4/|omega| rad/s,
+    # and HIP sinf/cosf differ from glibc by an ulp.  Bound: abs 1e-2 and 2e-3 relative Frobenius error over the table.
+    gav = rows[:, o + 10 * Bx:].view(F, Bx, 3)
+    close(gav, g["gavs_t"], 1e-2, "gavs_t")
+    ref = torch.from_numpy(g["gavs_t"])
+    assert float((gav - ref).norm() / ref.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["wjx_horse", "origin_walk"])
+def test_motion_state_matches_reference(tag):
+    g = dict(np.load(os.path.join(GOLDEN, f"motion_state_{tag}.npz")))
+    clip = dict(pose_aa=g["pose_aa"], root_trans_offset=g["root_trans_offset"], fps=int(g["fps"]))
+    if "clip_contact_mask" in g:
+        clip["contact_mask"] = g["clip_contact_mask"]
+    N = g["times"].shape[0]
+    sk, ml = _hip_motion_lib(clip, N)
+    res = ml.get_motion_state(torch.arange(N, device=DEV), torch.from_numpy(g["times"]).to(DEV), torch.from_numpy(g["offset"]).to(DEV))
+    for k in ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos_t", "rg_rot_t", "body_vel_t", "body_ang_vel_t",
+              "rg_pos", "rb_rot", "body_vel", "body_ang_vel"] + (["contact_mask"] if "contact_mask" in g else []):
+        extra = ANGVEL if "ang_vel" in k else (SLERP if "rot" in k else {})
+        close(res[k], g[k], 5e-5, f"{tag}:{k}", **extra)
+
+
+def test_sim_fk_matches_oracle():
+    from oracle.fk import sim_fk
+    from pbhc_amd import _lib
+    from pbhc_amd.skeleton import Skeleton
+
+    sk = Skeleton.from_json(os.path.join(GOLDEN, "skeleton_g1_23dof_lock_wrist_fitmotionONLY.json"))
+    osk = skel_from_golden()
+    N, D, B = 1000, sk.num_dof, sk.num_bodies
+    gen = torch.Generator().manual_seed(0)
+    root = torch.randn(N, 13, generator=gen)
+    root[:, 3:7] /= root[:, 3:7].norm(dim=-1, keepdim=True)
+    q, qd = torch.randn(N, D, generator=gen), torch.randn(N, D, generator=gen)
+    out = torch.zeros(N, B, 13, device=DEV)
+    csk = sk.to_c()
+    rg, qg, qdg = root.to(DEV), q.to(DEV).contiguous(), qd.to(DEV).contiguous()
+    _lib.check(_lib.lib().pbhc_sim_fk(C.byref(csk), rg.data_ptr(), qg.data_ptr(), qdg.data_ptr(), 1, N, out.data_ptr(), _lib.current_stream()))
+    p, r, v, w = sim_fk(osk, root, q, qd)
+    close(out[..., 0:3], p, 1e-5, "pos"); close(out[..., 3:7], r, 1e-5, "rot"); close(out[..., 7:10], v, 2e-5, "vel"); close(out[..., 10:13], w, 2e-5, "ang")
+
+
+CASES = [("horse", "v1_g1_23dof_horse_stance.yaml"), ("walk", "v1_g1_23dof_walk.yaml")]
+
+
+@pytest.mark.parametrize("tag,cfgname", CASES)
+def test_env_step_matches_reference_trace(tag, cfgname):
+    """The fused HIP step replays the reference's own trace (same inputs, injected draws)."""
+    g = load_env_golden(tag)
+    T, N, D = g["actions_in"].shape
+    cfg, env = build_hip_env(cfgname, N)
+    assert env.reward_names == list(g["reward_names"])
+    load_state_into_hip_env(env, state_dict_from_golden(g), g)
+    dev = env.device
+    tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    env.simulator.set_replay(tg(g["replay_root"]), tg(g["replay_dof_pos"]), tg(g["replay_dof_vel"]), tg(g["replay_contact"]))
+    K = __import__("pbhc_amd._lib", fromlist=["K"]).K
+    for k in range(T):
+        st = lambda name, dt=torch.float32: tg(g["step__state__" + name][k]).to(dt)
+        env.set_injected_draws(u_rfi=tg(g["step__u_rfi"][k]), start_time=st("motion_start_times"), kp=st("kp_scale"), kd=st("kd_scale"),
+                               rfi_lim=st("rfi_lim_scale"), rao=st("rao_scale"), delay=st("action_delay_idx", torch.long))
+        obs, rew, reset, extras = env.step({"actions": tg(g["actions_in"][k])})
+        torch.cuda.synchronize()
+        w = f"{tag} step {k}: "
+        assert torch.equal(reset.cpu(), torch.from_numpy(g["step__reset_buf_out"][k])), w + "reset_buf"
+        assert torch.equal(extras["time_outs"].cpu(), torch.from_numpy(g["step__time_outs"][k])), w + "time_outs"
+        close(extras["ref_body_pos_extend"], g["step__ref_body_pos_extend"][k], 2e-5, w + "ref_body_pos_extend")
+        close(extras["ref_body_rot_extend"], g["step__ref_body_rot_extend"][k], 2e-5, w + "ref_body_rot_extend", **SLERP)
+        close(env.simulator._rigid_body_pos, g["step__x___rigid_body_pos_extend"][k][:, :env.num_bodies], 2e-5, w + "body pos")
+        close(rew, g["step__rew_buf"][k], 3e-5, w + "rew_buf", rtol=1e-4)
+        for ok in ["actor_obs", "critic_obs"]:
+            close(obs[ok], g["step__obs__" + ok][k], 3e-5, w + ok)
+        for name in ["torques", "feet_air_time", "last_contacts", "actions", "last_actions", "action_queue", "motion_len", "end_time_ratio_buf",
+                     "contacts_filt", "last_dof_vel", "motion_start_times"]:
+            close(getattr(env, name), g["step__state__" + name][k], 3e-5, w + "state " + name)
+        close(env.simulator.dof_pos, g["step__state__dof_pos"][k], 3e-5, w + "dof_pos")
+        close(env.simulator.robot_root_states[:, :10], g["step__state__root_states"][k][:, :10], 3e-5, w + "root_states", **SLERP)
+        close(env.simulator.robot_root_states[:, 10:], g["step__state__root_states"][k][:, 10:], 3e-5, w + "root ang vel", **ANGVEL)
+        assert torch.equal(env.episode_length_buf.cpu(), torch.from_numpy(g["step__state__episode_length_buf"][k]))
+        for name, col in env.episode_sums.items():
+            close(col, g["step__state__sum__" + name][k], 3e-5, w + "sum " + name, rtol=1e-4)
+        for name, view in env.history.items():
+            close(view, g["step__state__hist__" + name][k], 3e-5, w + "hist " + name)
+        gl = env.globals.cpu().numpy()
+        from pbhc_amd.envs.env_config import SIGMA_KEYS
+        for i, name in enumerate(SIGMA_KEYS):
+            ref = float(g["step__state__sigma__" + name][k])
+            assert abs(gl[K["PBHC_G_SIGMA"] + i] - ref) <= 2e-6 * abs(ref), w + "sigma " + name
+        assert abs(gl[K["PBHC_G_PENALTY_SCALE"]] - float(g["step__state__reward_penalty_scale"][k])) < 1e-9
+        assert abs(gl[K["PBHC_G_AVG_EP_LEN"]] - float(g["step__state__average_episode_length"][k])) < 1e-5
+        assert abs(gl[K["PBHC_G_MOTION_FAR_THR"]] - float(g["step__state__motion_far_threshold"][k])) < 1e-9
+        log = env.read_log()
+        for lk in ["terminate_by_gravity", "terminate_by_motion_far", "terminate_by_time_out", "upper_body_diff_norm", "joint_pos_diff_norm", "action_clip_frac"]:
+            close(torch.tensor(log[lk]), g["step__log__" + lk][k], 1e-4, w + "log " + lk)
+
+
+def test_env_step_matches_oracle_4096():
+    """Full-size (4096 envs) HIP step vs the oracle on identical synthetic replay tensors."""
+    from oracle.env_v1 import MotionTrackingOracle
+    from oracle.fk import sim_fk
+    from oracle.motion_lib import MotionLib as OML
+
+    N, T = 4096, 4
+    cfgname = "v1_g1_23dof_horse_stance.yaml"
+    cfg, env = build_hip_env(cfgname, N)
+    g = load_env_golden("horse")
+    skel = skel_from_golden()
+    oml = OML(skel, [clip_from_env_golden(g)])
+    ocfg = fixture_config(cfgname, N)
+    dr = dict(base_com_bias=env.simulator._base_com_bias.cpu(), link_mass_scale=env.simulator._link_mass_scale.cpu(), friction_coeffs=env.simulator.friction_coeffs.cpu())
+    orc = MotionTrackingOracle(ocfg, skel, oml, N, dr)
+    orc.env_origins = env.env_origins.cpu()
+    orc.ref_init_yaw = env.ref_init_yaw
+    gen = torch.Generator().manual_seed(5)
+    start = torch.rand(N, generator=gen) * float(oml.motion_len[0])
+    ep = torch.randint(0, 50, (N,), generator=gen)
+    start[:64] = float(oml.motion_len[0]) - 0.03          # some motion-end time-outs
+    st = {k: v.clone() for k, v in orc.s.items()}
+    st["motion_start_times"] = start; st["episode_length_buf"] = ep; st["last_episode_length_buf"] = ep.clone()
+    st["motion_len"] = torch.full((N,), float(oml.motion_len[0]))
+    st["kp_scale"] = 0.9 + 0.2 * torch.rand(N, 23, generator=gen); st["kd_scale"] = 0.9 + 0.2 * torch.rand(N, 23, generator=gen)
+    st["rfi_lim_scale"] = 0.5 + torch.rand(N, 23, generator=gen); st["rao_scale"] = 0.1 * (torch.rand(N, 23, generator=gen) - 0.5)
+    st["action_delay_idx"] = torch.randint(0, 3, (N,), generator=gen)
+    root, qp, qv, cf = synth_replay(oml, skel, N, T + 1, start, ep, orc.dt, orc.env_origins, 6, orc.feet)
+    st["root_states"], st["dof_pos"], st["dof_vel"], st["contact_forces"] = root[0], qp[0], qv[0], cf[0]
+    flat = {k: v.numpy() for k, v in st.items()}
+    for k in orc.sums:
+        flat["sum__" + k] = np.zeros(N, np.float32)
+    for k in orc.hist:
+        flat["hist__" + k] = (0.1 * torch.randn(orc.hist[k].shape, generator=gen)).numpy()
+    for k in orc.sigma:
+        flat["sigma__" + k] = orc.sigma[k]
+    flat.update(reward_penalty_scale=0.1, average_episode_length=0.0, motion_far_threshold=1.5)
+    orc.load_state(flat)
+    load_state_into_hip_env(env, flat)
+    tg = lambda a: a.contiguous().to(DEV)
+    env.simulator.set_replay(tg(root[1:]), tg(qp[1:]), tg(qv[1:]), tg(cf[1:]))
+    for k in range(T):
+        act = 0.5 * torch.randn(N, 23, generator=gen)
+        u = torch.rand(N, 23, generator=gen)
+        samp = dict(motion_start_times=torch.rand(N, generator=gen) * float(oml.motion_len[0]), kp_scale=0.9 + 0.2 * torch.rand(N, 23, generator=gen),
+                    kd_scale=0.9 + 0.2 * torch.rand(N, 23, generator=gen), rfi_lim_scale=0.5 + torch.rand(N, 23, generator=gen),
+                    rao_scale=0.1 * (torch.rand(N, 23, generator=gen) - 0.5), action_delay_idx=torch.randint(0, 3, (N,), generator=gen))
+        frame = dict(root=root[k + 1], dof_pos=qp[k + 1], dof_vel=qv[k + 1], contact=cf[k + 1])
+        body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
+        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp)
+        env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
+                               rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]))
+        obs, rew, reset, extras = env.step({"actions": tg(act)})
+        torch.cuda.synchronize()
+        w = f"step {k}: "
+        assert torch.equal(reset.cpu(), o_reset), w + f"reset mismatch {int((reset.cpu() != o_reset).sum())}"
+        assert int(o_reset.sum()) > 0 or k > 0
+        close(rew, o_rew, 3e-5, w + "rew", rtol=2e-4)
+        for ok in o_obs:      # env origins reach 320 m: fp32 spacing there is 3e-5, and the position differences cancel at that magnitude
+            close(obs[ok], o_obs[ok], 1e-4, w + ok)
+        close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
+        for name, view in env.history.items():
+            close(view, orc.hist[name], 3e-5, w + "hist " + name)
+
+
+def test_gae_matches_reference_storage():
+    from pbhc_amd import _lib
+
+    g = {k: v for k, v in np.load(os.path.join(GOLDEN, "ppo_v1.npz")).items()}
+    T, N, R = g["st__rewards"].shape
+    tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rewards, values, dones = tg(g["st__rewards"]), tg(g["st__values"]), tg(g["st__dones"][..., 0])
+    # last_values of the golden = critic(last_obs) with the initial weights: recompute on CPU via the oracle nets
+    from oracle import ppo
+    cp = {k[len("critic__"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("critic__")}
+    last_values = ppo.mlp_forward(cp, "critic_module", torch.from_numpy(g["last_critic_obs"]))
+    returns = torch.zeros(T, N, R, device=DEV); adv = torch.zeros(T, N, device=DEV)
+    stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=DEV)
+    _lib.check(_lib.lib().pbhc_gae(rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), tg(last_values.numpy()).data_ptr(), T, N, R, 0.99, 0.95,
+                                   returns.data_ptr(), adv.data_ptr(), stats.data_ptr(), _lib.current_stream()))
+    torch.cuda.synchronize()
+    close(returns, g["st__returns"], 2e-5, "returns")
+    close(adv.unsqueeze(-1), g["st__advantages"], 5e-5, "advantages")
