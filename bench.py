@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the obs + reward + PPO-update hot path on MI355X.
+
+A "step" is one PPO iteration: 24 control steps of `num_envs` envs (replay sim-stub -> fused HIP
+FK/obs/reward/termination/reset step -> actor+critic forward -> rollout-buffer write), GAE +
+advantage normalisation, then 5 epochs x 4 minibatches of the clipped-surrogate update (+ one RCCL
+gradient all-reduce per optimiser step when N > 1).  env-steps/s = envs * 24 * K / wall, the
+reference's own `Perf/total_fps` formula (mh_ppo.py:649-652).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+WORKLOAD_CFG = "v1_g1_23dof_walk.yaml"     # BASELINE.json configs[1]: 4096 envs, G1 23-DoF, g1_walk_45cms, 1xMI355X
+
+
+def algorithmic_bytes_per_env_step(env):
+    """fp32 words k_env_step must move per env per control step, split as
+    (streamed words, words of the two gathered reference-motion rows, which stay cache-resident for a single clip)."""
+    L, c = env.layout, env._c
+    D, B, Bx, F = env.num_dof, env.num_bodies, env.skeleton.num_bodies_ext, 2
+    Q = c.queue_len
+    reads = dict(
+        actions_in=D, action_queue=Q * D, dof_state_prev=2 * D, dr_scales=4 * D, frame=13 + 2 * D + 3 * B, hist=L.hist_dim,
+        dr_obs=3 + c.dr_link_mass_dim + 1, foot_state=2 * F + F, scalars=2 + 1 + 1 + 2 + 3 + 2, last_actions=D, last_dof_vel=D,
+        episode_sums=c.num_sum_cols,
+    )
+    writes = dict(
+        action_queue=Q * D, obs=sum(L.group_dims.values()), hist=L.hist_dim, rew=c.num_rew_cols, episode_sums=c.num_sum_cols,
+        ref_body_extend=7 * Bx, rigid_body_state=13 * B, contact_forces=3 * B, act_state=4 * D, dof_state=2 * D, last_dof=2 * D, root=13,
+        foot_state=5 * F, scalars=2 + 2 + 2 + 1,
+    )
+    motion = 2 * env._motion_lib.row
+    return sum(reads.values()) + sum(writes.values()), motion, reads, writes
+
+
+def make_replay_on_device(env, num_frames, seed):
+    """Synthetic replay window, resident in HBM: state_k = ref((ep+k+1) dt + start) + noise
+    (SURVEY §8d 'Stub inputs'); generated with the HIP motion lookup, outside the timed region."""
+    N, D, B, dev = env.num_envs, env.num_dof, env.num_bodies, env.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    root = torch.empty(num_frames, N, 13, device=dev)
+    qp = torch.empty(num_frames, N, D, device=dev)
+    qv = torch.empty(num_frames, N, D, device=dev)
+    cf = torch.zeros(num_frames, N, B, 3, device=dev)
+    feet = env.feet_indices
+    ids = env.motion_ids
+    for k in range(num_frames):
+        t = (env.episode_length_buf + k + 1).float() * env.dt + env.motion_start_times
+        t = torch.remainder(t, env.motion_len)
+        ref = env._motion_lib.get_motion_state(ids, t, offset=env.env_origins)
+        root[k, :, 0:3] = ref["root_pos"] + 0.02 * rn(N, 3)
+        dq = torch.cat([0.02 * rn(N, 3), torch.ones(N, 1, device=dev)], -1)
+        dq = dq / dq.norm(dim=-1, keepdim=True)
+        q = ref["root_rot"]
+        # small rotation * reference rotation (Hamilton product, xyzw)
+        x1, y1, z1, w1 = dq.unbind(-1); x2, y2, z2, w2 = q.unbind(-1)
+        root[k, :, 3:7] = torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                                       w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], -1)
+        root[k, :, 7:10] = ref["root_vel"] + 0.1 * rn(N, 3)
+        root[k, :, 10:13] = ref["root_ang_vel"] + 0.1 * rn(N, 3)
+        qp[k] = ref["dof_pos"] + 0.02 * rn(N, D)
+        qv[k] = ref["dof_vel"] + 0.1 * rn(N, D)
+        on = (ref["rg_pos_t"][:, feet, 2] < 0.06).float() if "contact_mask" not in ref else (ref["contact_mask"] > 0.5).float()
+        cf[k, :, feet, 2] = on * (300.0 + 50.0 * rn(N, 2))
+    return root, qp, qv, cf
+
+
+def build(num_envs, device, seed):
+    from pbhc_amd.agents.mh_ppo import MHPPO
+    from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking
+    from pbhc_amd.utils.config import load_config
+
+    cfg = load_config(os.path.join(ROOT, "tests", "golden", "configs", WORKLOAD_CFG),
+                      {"num_envs": num_envs, "simulator._target_": "pbhc_amd.simulator.replay_stub.ReplaySimStub"}, now="bench")
+    torch.manual_seed(seed)
+    env = LeggedRobotMotionTracking(cfg.env.config, device)
+    return cfg, env, MHPPO
+
+
+def cpu_baseline(num_envs_sample=2048):
+    """The oracle ('port') timed on the host cores: one full PPO iteration at `num_envs_sample` envs."""
+    from oracle.cpu_loop import run_iteration
+    from tests.helpers import clip_from_env_golden, fixture_config, load_env_golden, skel_from_golden
+
+    # host cores actually used: the affinity mask, capped at the 16-core CPU share of a one-GPU box
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    cfg = fixture_config(WORKLOAD_CFG, num_envs_sample)
+    r = run_iteration(cfg, skel_from_golden(), clip_from_env_golden(load_env_golden("walk")), num_envs_sample)
+    return {"value": r["env_steps"] / r["seconds"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 PPO iteration (24 steps + GAE + 5x4 minibatch updates) of {num_envs_sample} envs on the CPU oracle, "
+                      f"{r['seconds']:.1f} s (rollout {r['rollout_s']:.1f} s, update {r['update_s']:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    N, K, W = a.envs, a.steps, a.warmup
+    cfg, env, MHPPO = build(N, device, seed=1234 + rank)
+    algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=device)
+    algo.setup()
+    T = algo.num_steps_per_env
+    obs = env.reset_all()
+    frames = (K + W) * T + 2
+    env.simulator.set_replay(*make_replay_on_device(env, frames, seed=99 + rank))
+    algo._train_mode()
+    from pbhc_amd import _lib
+    lib = _lib.lib()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(W):
+        obs = algo._rollout_step(obs)
+        algo._training_step()
+    _lib.check(lib.pbhc_env_profile(env._env, 1))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ev[3 * i].record()
+        obs = algo._rollout_step(obs)
+        ev[3 * i + 1].record()
+        algo._training_step()
+        ev[3 * i + 2].record()
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    rollout_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K
+    update_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / K
+    # --- roofline of the fused obs/reward step kernel: HIP events recorded by the library around k_env_step
+    buf = (C.c_float * 512)()
+    cnt = C.c_int(0)
+    _lib.check(lib.pbhc_env_profile_read(env._env, buf, min(512, K * T), C.byref(cnt)))
+    kern_ms = sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
+    words, motion_words, _, _ = algorithmic_bytes_per_env_step(env)
+    alg_bytes = 4.0 * (words + motion_words) * N
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    flops_per_sample = 2.0 * sum(p.numel() for n, p in list(algo.actor.named_parameters()) + list(algo.critic.named_parameters()) if n.endswith("weight"))
+    upd_flops = 3.0 * flops_per_sample * T * N * algo.num_learning_epochs
+    if rank == 0:
+        out = {
+            "metric": "env-steps/s (obs+reward+PPO update), 4096 G1 envs @1/2/4/8 MI355X",
+            "value": N * world * T * K / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N} envs/GPU, G1 23-DoF, single reference motion g1_walk_45cms (122 frames), v1 env (LeggedRobotMotionTracking) + MHPPO, "
+                                   f"24 steps/iter, 5 epochs x 4 minibatches; replay sim-stub tensors resident in HBM",
+                       "envs_per_gpu": N, "global_envs": N * world, "num_steps_per_env": T, "parallelism": f"dp{world}"},
+            "rollout_ms": rollout_ms, "update_ms": update_ms,
+            "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": kern_ms, "launches_timed": cnt.value,
+                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
+                         "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
+            "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase (GEMMs via rocBLAS + gather + Adam), fp32"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

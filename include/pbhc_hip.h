@@ -288,6 +288,13 @@ void pbhc_env_destroy(PbhcEnv* env);
 /* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */
 int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
 
+/* Measurement aid: when enabled, k_env_step of each following pbhc_env_step is bracketed by a pair of HIP
+ * events on the launch stream (ring of PBHC_PROFILE_RING pairs).  pbhc_env_profile_read synchronises on the
+ * recorded events and returns the most recent durations in milliseconds (oldest first). */
+#define PBHC_PROFILE_RING 512
+int pbhc_env_profile(PbhcEnv* env, int enable);
+int pbhc_env_profile_read(PbhcEnv* env, float* ms_out, int max_count, int* count);
+
 /* GAE + returns + normalised advantages.  Replaces MHPPO._compute_returns (mh_ppo.py:348-395).
  * rewards/values/returns [T,N,R], dones [T,N] bool, last_values [N,R], advantages [T,N].
  * stats: device double[4] scratch. */

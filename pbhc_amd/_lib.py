@@ -84,7 +84,8 @@ PbhcMotionTable = _S["PbhcMotionTable"]
 PbhcStepIO = _S["PbhcStepIO"]
 
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
-           "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae"]
+           "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
+           "pbhc_env_profile", "pbhc_env_profile_read"]
 
 
 class PbhcError(RuntimeError):
@@ -111,6 +112,8 @@ def _load():
     lib.pbhc_env_destroy.argtypes = [vp]
     lib.pbhc_env_destroy.restype = None
     lib.pbhc_env_step.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
+    lib.pbhc_env_profile.argtypes = [vp, i]
+    lib.pbhc_env_profile_read.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(C.c_int)]
     lib.pbhc_gae.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp]
     return lib
 

@@ -940,6 +940,9 @@ struct PbhcEnv {
   int lds_stride;
   size_t lds_bytes;
   uint32_t step_ctr;
+  int profile;
+  int prof_count;
+  hipEvent_t ev0[PBHC_PROFILE_RING], ev1[PBHC_PROFILE_RING];
 };
 
 extern "C" {
@@ -1023,9 +1026,11 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->lds_stride = Lds::FEAT + ((cfg->feat_dim + 3) & ~3);
   e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
   e->step_ctr = 0;
+  e->profile = 0;
+  e->prof_count = 0;
   if (e->lds_bytes > 160 * 1024) { delete e; snprintf(g_err, sizeof(g_err), "feature row too large for LDS"); return PBHC_EINVAL; }
   if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
-  if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
+  if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
   HIP_CHECK(hipMemcpy(e->d_cfg, cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
   if (e->lds_bytes > 64 * 1024)
     HIP_CHECK(hipFuncSetAttribute((const void*)k_env_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
@@ -1035,9 +1040,38 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
 
 void pbhc_env_destroy(PbhcEnv* e) {
   if (!e) return;
-  hipFree(e->d_cfg);
-  hipFree(e->d_partials);
+  if (e->profile)
+    for (int i = 0; i < PBHC_PROFILE_RING; ++i) { (void)hipEventDestroy(e->ev0[i]); (void)hipEventDestroy(e->ev1[i]); }
+  (void)hipFree(e->d_cfg);
+  (void)hipFree(e->d_partials);
   delete e;
+}
+
+int pbhc_env_profile(PbhcEnv* e, int enable) {
+  ARG_CHECK(e);
+  if (enable && !e->profile) {
+    for (int i = 0; i < PBHC_PROFILE_RING; ++i) { HIP_CHECK(hipEventCreate(&e->ev0[i])); HIP_CHECK(hipEventCreate(&e->ev1[i])); }
+    e->profile = 1;
+  }
+  if (!enable && e->profile) {
+    for (int i = 0; i < PBHC_PROFILE_RING; ++i) { (void)hipEventDestroy(e->ev0[i]); (void)hipEventDestroy(e->ev1[i]); }
+    e->profile = 0;
+  }
+  e->prof_count = 0;
+  return PBHC_OK;
+}
+
+int pbhc_env_profile_read(PbhcEnv* e, float* ms_out, int max_count, int* count) {
+  ARG_CHECK(e && ms_out && count && e->profile);
+  int n = e->prof_count < PBHC_PROFILE_RING ? e->prof_count : PBHC_PROFILE_RING;
+  if (n > max_count) n = max_count;
+  for (int i = 0; i < n; ++i) {
+    int slot = (e->prof_count - n + i) % PBHC_PROFILE_RING;
+    HIP_CHECK(hipEventSynchronize(e->ev1[slot]));
+    HIP_CHECK(hipEventElapsedTime(&ms_out[i], e->ev0[slot], e->ev1[slot]));
+  }
+  *count = n;
+  return PBHC_OK;
 }
 
 int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
@@ -1051,8 +1085,11 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(io->env_origins && io->dr_base_com && io->dr_link_mass && io->dr_friction && io->rew_buf);
   for (int g = 0; g < e->cfg.num_groups; ++g) ARG_CHECK(io->obs[g] != nullptr);
   hipStream_t st = (hipStream_t)stream;
+  const int slot = e->prof_count % PBHC_PROFILE_RING;
+  if (e->profile) HIP_CHECK(hipEventRecord(e->ev0[slot], st));
   hipLaunchKernelGGL(k_env_step, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials,
                      e->lds_stride, e->step_ctr);
+  if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
   hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks);
   e->step_ctr++;
   HIP_CHECK(hipGetLastError());

@@ -135,7 +135,10 @@ class ReplaySimStub:
     def next_frame_index(self):
         """Index of the frame the next control step lands on; advances the cursor (pointer bump)."""
         if self.replay is None:
-            raise _lib.PbhcError("ReplaySimStub: set_replay() was not called")
+            # nothing to replay yet (e.g. the reset_all() inside MHPPO.__init__): hold the current state
+            self.replay = dict(root=self.robot_root_states.clone()[None], dof_pos=self.dof_pos.clone()[None].contiguous(),
+                               dof_vel=self.dof_vel.clone()[None].contiguous(), contact=self.contact_forces.clone()[None])
+            self.replay_len = 1
         k = self._frame % self.replay_len
         self._frame += 1
         return k

@@ -254,3 +254,63 @@ def test_gae_matches_reference_storage():
     torch.cuda.synchronize()
     close(returns, g["st__returns"], 2e-5, "returns")
     close(adv.unsqueeze(-1), g["st__advantages"], 5e-5, "advantages")
+
+
+def test_mhppo_update_matches_reference():
+    """One _training_step (5 epochs x 4 minibatches) of pbhc_amd MHPPO on the reference's rollout buffer, initial weights and
+    permutation reproduces the reference's updated weights, losses and learning rate (tests/golden/ppo_v1.npz)."""
+    from pbhc_amd.agents.mh_ppo import MHPPO
+
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_v1.npz")).items()}
+    N = g["st__actions"].shape[1]
+    cfg, env = build_hip_env("v1_g1_23dof_horse_stance.yaml", N)
+    hd = [int(x) for x in g["hidden_dims"]]
+    cfg.algo.config.module_dict.actor.layer_config.hidden_dims = hd
+    cfg.algo.config.module_dict.critic.layer_config.hidden_dims = hd
+    algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+    algo.setup()
+    algo.actor.load_state_dict({k[len("actor__"):]: v for k, v in g.items() if k.startswith("actor__")}, strict=True)
+    algo.critic.load_state_dict({k[len("critic__"):]: v for k, v in g.items() if k.startswith("critic__")}, strict=True)
+    for k in algo.storage.stored_keys:
+        getattr(algo.storage, k).copy_(g["st__" + k].to(DEV))
+    algo._train_mode()
+    loss = algo._training_step(indices=g["perm"].to(DEV))
+    torch.cuda.synchronize()
+    for k in ["Value", "Surrogate", "Entropy"]:
+        assert abs(float(loss[k]) - float(g["loss__" + k])) < 2e-4 * max(1.0, abs(float(g["loss__" + k]))), k
+    assert abs(float(algo._lr_a) - float(g["lr_actor"])) < 1e-9 and abs(float(algo._lr_c) - float(g["lr_critic"])) < 1e-9
+    for k, v in algo.actor.state_dict().items():
+        close(v, g["actor1__" + k], 5e-5, "actor " + k, rtol=2e-4)
+    for k, v in algo.critic.state_dict().items():
+        close(v, g["critic1__" + k], 5e-5, "critic " + k, rtol=2e-4)
+
+
+def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
+    from pbhc_amd.agents.mh_ppo import MHPPO
+
+    cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 16)
+    algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+    algo.setup()
+    p = str(tmp_path / "model_0.pt")
+    algo.save(p, infos={"x": 1})
+    d = torch.load(p, map_location="cpu", weights_only=False)
+    assert set(d.keys()) == {"actor_model_state_dict", "critic_model_state_dict", "actor_optimizer_state_dict", "critic_optimizer_state_dict", "iter", "infos"}
+    assert list(d["actor_model_state_dict"].keys()) == ["std"] + [f"actor_module.module.{i}.{w}" for i in (0, 2, 4, 6) for w in ("weight", "bias")]
+    assert list(d["critic_model_state_dict"].keys()) == [f"critic_module.module.{i}.{w}" for i in (0, 2, 4, 6) for w in ("weight", "bias")]
+    assert d["critic_model_state_dict"]["critic_module.module.6.weight"].shape[0] == env.num_rew_fn
+    assert isinstance(d["actor_optimizer_state_dict"]["param_groups"][0]["lr"], float)
+    assert algo.load(p) == {"x": 1}
+
+
+def test_learn_runs_two_iterations():
+    from pbhc_amd.agents.mh_ppo import MHPPO
+
+    cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 256, noise_off=False)
+    algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+    algo.setup()
+    algo.learn(num_iterations=2)
+    torch.cuda.synchronize()
+    for p in algo.actor.parameters():
+        assert torch.isfinite(p).all()
+    log = env.read_log()
+    assert np.isfinite(log["reward_mean"])
