@@ -27,11 +27,12 @@ extern "C" {
 #define PBHC_ENOMEM (-12)
 #define PBHC_EHIP (-5)      /* a HIP runtime call failed; see pbhc_last_error() */
 
-#define PBHC_MAX_BODIES 40   /* bodies incl. extended (hands, head) */
+#define PBHC_MAX_BODIES 36   /* bodies incl. extended (hands, head) */
+#define PBHC_MAX_DEPTH 12    /* longest root->body chain */
 #define PBHC_MAX_DOF 32
 #define PBHC_MAX_FEET 2
 #define PBHC_MAX_TERMS 32    /* reward terms (vector-reward heads - 1) */
-#define PBHC_MAX_IDX 40
+#define PBHC_MAX_IDX 36
 #define PBHC_MAX_GROUPS 6    /* observation groups + the history write-back map */
 #define PBHC_MAX_QUEUE 8     /* control-delay queue depth */
 #define PBHC_NUM_SIGMA 10
@@ -50,6 +51,9 @@ typedef struct PbhcSkeleton {
   float offset[PBHC_MAX_BODIES][3];
   float local_rot_wxyz[PBHC_MAX_BODIES][4];
   float dof_axis[PBHC_MAX_DOF][3];
+  /* chain[b][0..chain_len[b]-1]: the non-root bodies on the path root -> b (for an extended body: root -> its parent) */
+  int32_t chain_len[PBHC_MAX_BODIES];
+  int32_t chain[PBHC_MAX_BODIES][PBHC_MAX_DEPTH];
 } PbhcSkeleton;
 
 /* ---- reward term ids (reference: `_reward_<name>` in legged_robot_base.py:944-1087 and
@@ -193,7 +197,7 @@ typedef struct PbhcEnvConfig {
   float max_episode_length_s;
   /* observations */
   float clip_observations;
-  int32_t feat_off[PBHC_F_NUM];
+  int32_t feat_off[PBHC_F_NUM];              /* features no observation reads share one scratch region at the end of the row */
   int32_t feat_dim;
   int32_t hist_dim;                          /* floats of history state per env */
   int32_t num_groups;

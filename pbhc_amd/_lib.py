@@ -14,7 +14,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "pbhc_hip.h")
-LIB_PATH = os.path.join(_HERE, "libpbhc_hip.so")
+LIB_PATH = os.environ.get("PBHC_LIB", os.path.join(_HERE, "libpbhc_hip.so"))   # PBHC_LIB: diagnostic builds only
 
 _CTYPES = {
     "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,

@@ -22,6 +22,15 @@ using namespace pbhc;
 #define PBHC_NP 48    // partial sums per workgroup
 
 static thread_local char g_err[512] = "";
+
+// Diagnostic build only (-DPBHC_STAMPS, libpbhc_hip_stamps.so): shader-clock stamps of workgroup 0 at the phase
+// boundaries of k_env_step, written to a buffer nothing else reads.  The product build contains none of this.
+#ifdef PBHC_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define HIP_CHECK(x)                                                                          \
   do {                                                                                        \
     hipError_t e_ = (x);                                                                      \
@@ -52,20 +61,23 @@ static_assert(P_NUM <= PBHC_NP, "partials");
 enum {
   R_UP = 0, R_LO, R_VR, R_FEET, R_ROT, R_VEL, R_ANG, R_MAXNORM, R_UPN, R_LON, R_VRN,
   R_MAXJP, R_JP2, R_JV2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
-  R_NUM
+  R_EXP0,                      // [10] exp(-err_k / sigma_k)
+  R_FOOT0 = R_EXP0 + 10,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2)
+  R_NUM = R_FOOT0 + 10
 };
+static_assert(R_NUM <= 48, "RED region");
 
-// per-env LDS layout (floats)
+// per-env LDS layout (floats); body arrays sized for PBHC_MAX_BODIES = 36
 struct Lds {
   enum {
     ACT = 0, ACTD = 32, TAU = 64, Q = 96, QD = 128, RDOF = 160, RDOFV = 192,          // 7 x 32
     ROOT = 224,                                                                      // 16
     MISC = 240,                                                                      // 48: scalars
-    CF = 288,                                                                        // 120 contact forces
-    BP = 408, BQ = 528, BV = 688, BW = 808,                                          // body pos3/quat4/vel3/ang3 x40
-    RP = 928, RQ = 1048, RV = 1208, RW = 1328,                                       // reference, same shapes
-    RED = 1448,                                                                      // 32
-    FEAT = 1480
+    CF = 288,                                                                        // 108 contact forces
+    BP = 396, BQ = 504, BV = 648, BW = 756,                                          // body pos3/quat4/vel3/ang3 x36
+    RP = 864, RQ = 972, RV = 1116, RW = 1224,                                        // reference, same shapes
+    RED = 1332,                                                                      // 48
+    FEAT = 1380
   };
 };
 // MISC slots
@@ -92,38 +104,85 @@ __device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[
 __device__ __forceinline__ void st4(float* p, f4 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// ---- rigid-body FK of one body from its parent (what Isaac Gym's rigid-body state tensor held in
-// the reference, isaacgym.py:574-605; same chain as forward_kinematics_batch
-// torch_humanoid_batch.py:248-252 with pose_aa = axis*q, twist propagated analytically) ----------
-__device__ __forceinline__ void fk_body(const PbhcSkeleton& sk, int b, const float* q, const float* qd, float* bp, float* bq, float* bv, float* bw) {
-  int p = sk.parent[b];
-  int d = b - 1;
-  f3 pp = ld3(bp + 3 * p), pv = ld3(bv + 3 * p), pw = ld3(bw + 3 * p);
-  f4 pq = ld4(bq + 4 * p);
-  f3 off = mk3(sk.offset[b][0], sk.offset[b][1], sk.offset[b][2]);
-  f3 axis = mk3(sk.dof_axis[d][0], sk.dof_axis[d][1], sk.dof_axis[d][2]);
-  f3 pos = add3(pp, quat_rotate(pq, off));
-  f4 lq = mk4(sk.local_rot_wxyz[b][1], sk.local_rot_wxyz[b][2], sk.local_rot_wxyz[b][3], sk.local_rot_wxyz[b][0]);
-  f4 qj = quat_from_angle_axis(q[d], axis);
-  f4 rq = quat_unit(quat_mul(pq, quat_mul(lq, qj)));
-  f3 w = add3(pw, mul3(quat_rotate(rq, axis), qd[d]));
-  f3 v = add3(pv, cross3(pw, sub3(pos, pp)));
-  st3(bp + 3 * b, pos); st4(bq + 4 * b, rq); st3(bv + 3 * b, v); st3(bw + 3 * b, w);
+// global -> LDS copy by one env group, 8 independent loads in flight per lane before the first store
+__device__ __forceinline__ void copy_g2l(float* dst, const float* __restrict__ src, int n, int lane) {
+  for (int i0 = lane; i0 < n; i0 += 8 * PBHC_G) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * PBHC_G; v[u] = i < n ? src[i] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * PBHC_G; if (i < n) dst[i] = v[u]; }
+  }
 }
 
-// level-synchronous chain over the B real bodies; all threads of the workgroup must call it
-__device__ __forceinline__ void fk_chain(const PbhcSkeleton& sk, int lane, bool valid, const float* root, const float* q, const float* qd,
-                                         float* bp, float* bq, float* bv, float* bw) {
-  if (valid && lane == 0) {
-    st3(bp, ld3(root)); st4(bq, ld4(root + 3)); st3(bv, ld3(root + 7)); st3(bw, ld3(root + 10));
+// ---- skeleton constants staged once per workgroup in LDS (shared by its envs) -------------------
+// per body b: off[3] lq_xyzw[4] axis[3] chain_len chain[PBHC_MAX_DEPTH]
+#define SKC_W (11 + PBHC_MAX_DEPTH)
+#define SKC_WORDS (PBHC_MAX_BODIES * SKC_W)
+__device__ __forceinline__ float skel_word(const PbhcSkeleton& sk, int i) {
+  int b = i / SKC_W, w = i - b * SKC_W;
+  if (w < 3) return sk.offset[b][w];
+  if (w < 7) return sk.local_rot_wxyz[b][(w - 3 + 1) & 3];                 // wxyz -> xyzw
+  if (w < 10) return (b >= 1 && b < sk.num_bodies) ? sk.dof_axis[b - 1][w - 7] : 0.0f;
+  if (w == 10) return __int_as_float(sk.chain_len[b]);
+  return __int_as_float(sk.chain[b][w - 11]);
+}
+__device__ __forceinline__ void stage_skeleton(const PbhcSkeleton& sk, float* skc) {
+  const int n = sk.num_bodies_ext * SKC_W;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x; v[u] = i < n ? skel_word(sk, i) : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x; if (i < n) skc[i] = v[u]; }
   }
+}
+
+// ---- rigid-body pose + twist of every body (what Isaac Gym's rigid-body state tensor held in the
+// reference, isaacgym.py:574-605).  Same chain as forward_kinematics_batch
+// (torch_humanoid_batch.py:248-252) with pose_aa = axis*q; twist propagated analytically:
+// w_i = w_par + R_i axis_i qd_i, v_i = v_par + w_par x (p_i - p_par).
+// Step 1: lane b composes relq[b] = q_local[b] * q_joint(q[b-1]) (one sincos per lane).
+// Step 2: lane b walks ITS OWN root->b chain from LDS — no barriers inside the chain.
+// Extended bodies (motion_tracking.py:619-643) walk to their parent, then apply
+// p = R_ext(R_par off) + p_par, q = q_par*q_ext, w = w_par, v = v_par + w_par x off (offset NOT rotated, sic).
+// All threads of the workgroup must call it (two barriers).
+__device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lane, bool valid, const float* root, const float* q, const float* qd,
+                                        float* relq, float* bp, float* bq, float* bv, float* bw) {
+  if (valid)
+    for (int b = 1 + lane; b < B; b += PBHC_G) {
+      const float* k = skc + b * SKC_W;
+      f3 axis = ld3(k + 7);
+      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_axis(q[b - 1], axis)));
+    }
   __syncthreads();
-  for (int lvl = 1; lvl <= sk.max_depth; ++lvl) {
-    if (valid)
-      for (int b = lane; b < sk.num_bodies; b += PBHC_G)
-        if (sk.depth[b] == lvl) fk_body(sk, b, q, qd, bp, bq, bv, bw);
-    __syncthreads();
-  }
+  if (valid)
+    for (int b = lane; b < Bx; b += PBHC_G) {
+      const float* kb = skc + b * SKC_W;
+      const int n = __float_as_int(kb[10]);
+      f3 p = ld3(root), v = ld3(root + 7), w = ld3(root + 10);
+      f4 r = ld4(root + 3);
+      for (int i = 0; i < n; ++i) {
+        const int a = __float_as_int(kb[11 + i]);
+        const float* ka = skc + a * SKC_W;
+        f3 axis = ld3(ka + 7);
+        f3 pn = add3(p, quat_rotate(r, ld3(ka)));
+        f4 rn = quat_unit(quat_mul(r, ld4(relq + 4 * a)));
+        f3 wn = add3(w, mul3(quat_rotate(rn, axis), qd[a - 1]));
+        v = add3(v, cross3(w, sub3(pn, p)));
+        p = pn; r = rn; w = wn;
+      }
+      if (b >= B) {
+        f3 off = ld3(kb);
+        f4 eq = ld4(kb + 3);
+        f3 pe = add3(quat_rotate(eq, quat_rotate(r, off)), p);
+        v = add3(v, cross3(w, off));
+        r = quat_mul(r, eq);
+        p = pe;
+      }
+      st3(bp + 3 * b, p); st4(bq + 4 * b, r); st3(bv + 3 * b, v); st3(bw + 3 * b, w);
+    }
+  __syncthreads();
 }
 
 // ---- frame blend (motion_lib_base.py:503-513) -------------------------------------------------
@@ -183,53 +242,101 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float *bp = S + Lds::BP, *bq = S + Lds::BQ, *bv = S + Lds::BV, *bw = S + Lds::BW;
   float *rp = S + Lds::RP, *rq = S + Lds::RQ, *rv = S + Lds::RV, *rw = S + Lds::RW;
   float *red = S + Lds::RED, *feat = S + Lds::FEAT;
-  float* blockpart = smem + (size_t)PBHC_EPB * lds_stride;   // [EPB][PBHC_NP]
+  float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
+  float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
   const float dt = c.dt;
   const size_t eD = (size_t)env * D;
+  stage_skeleton(sk, skc);
 
+  // ---------------- prologue: every load that does not depend on this step's compute is issued here, into
+  // registers, so that the kernel pays ONE global round trip up front (plus the dependent reference rows,
+  // whose latency hides behind the FK chain).  All lanes of an env compute the frame address redundantly.
+  long long ep1 = 0;
+  float start = 0.0f, mlen_env = 0.0f, tref = 0.0f, blend = 0.0f;
+  int mid = 0;
+  f3 origin = mk3(0.f, 0.f, 0.f);
+  f3 rp0 = mk3(0, 0, 0), rp1 = rp0, rv0 = rp0, rv1 = rp0, rw0 = rp0, rw1 = rp0;
+  f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
+  float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
+  float pf_last_act = 0, pf_last_qd = 0, pf_sum = 0, pf_tscale = 0;
+  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0;
+  const float* r0 = nullptr;
+  const float* r1 = nullptr;
+  if (valid) {
+    ep1 = io.episode_length_buf[env] + 1;
+    start = io.motion_start_times[env];
+    mlen_env = io.motion_len[env];
+    mid = (int)io.motion_ids[env];
+    origin = ld3(io.env_origins + (size_t)env * 3);
+    if (lane < D) { pf_last_act = io.last_actions[eD + lane]; pf_last_qd = io.last_dof_vel[eD + lane]; }
+    if (lane < c.num_terms) {
+      pf_tid = c.term_id[lane]; pf_tscale = c.term_scale[lane]; pf_tpen = c.term_penalty[lane]; pf_tcol = c.term_sum_col[lane];
+      pf_sum = io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol];
+    }
+    tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
+    int f0, f1;
+    frame_blend(tref, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &blend);
+    r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
+    r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+    if (lane < Bx) {
+      rp0 = ld3(r0 + o_pos + 3 * lane); rp1 = ld3(r1 + o_pos + 3 * lane);
+      rq0 = ld4(r0 + o_rot + 4 * lane); rq1 = ld4(r1 + o_rot + 4 * lane);
+      rv0 = ld3(r0 + o_vel + 3 * lane); rv1 = ld3(r1 + o_vel + 3 * lane);
+      rw0 = ld3(r0 + o_ang + 3 * lane); rw1 = ld3(r1 + o_ang + 3 * lane);
+    }
+    if (lane < D) { rd0 = r0[lane]; rd1 = r1[lane]; rdv0 = r0[D + lane]; rdv1 = r1[D + lane]; }
+    if (lane < 2) { rc0 = r0[2 * D + lane]; rc1 = r1[2 * D + lane]; }
+  }
+
+  STAMP(0);
   // ---------------- phase A: _pre_physics_step (motion_tracking.py:749-768), torques from the
   // pre-step state (legged_robot_base.py:795-838), then the replay frame lands ------------------
   float clipcnt = 0.0f;
   if (valid) {
     const int Q = c.queue_len;
-    const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
-    for (int d = lane; d < D; d += PBHC_G) {
-      float a = clampf(io.actions_in[eD + d], -c.action_clip_value, c.action_clip_value);
+    const int d = lane;                       // D <= 32: one dof per lane
+    // history (largest read) first, all loads of this phase are independent: issue them before any store
+    const int hoff = c.feat_off[PBHC_F_HISTORY];
+    copy_g2l(feat + hoff, io.hist + (size_t)env * c.hist_dim, c.hist_dim, lane);
+    if (d < D) {
+      const float a_in = io.actions_in[eD + d];
+      float qold[PBHC_MAX_QUEUE];
+      float* qu = io.action_queue + (size_t)env * Q * D + d;
+#pragma unroll
+      for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = (c.randomize_ctrl_delay && k < Q) ? qu[(size_t)k * D] : 0.0f;
+      const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
+      const float qp = io.dof_state[(eD + d) * 2], qv = io.dof_state[(eD + d) * 2 + 1];
+      const float kp = io.kp_scale[eD + d], kd = io.kd_scale[eD + d], rfs = io.rfi_lim_scale[eD + d], ras = io.rao_scale[eD + d];
+      const float fq = io.frame_dof_pos[eD + d], fqd = io.frame_dof_vel[eD + d];
+      const float u = c.randomize_torque_rfi ? (io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(c.seed, env, step_ctr, 1, d)) : 0.5f;
+      const float tl = c.torque_limits[d];
+      const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
       if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
       act[d] = a;
       float delayed = a;
-      if (c.randomize_ctrl_delay) {
-        float* qu = io.action_queue + (size_t)env * Q * D + d;
-        float prev = a;
-        for (int k = 0; k < Q; ++k) {          // queue[k] <- queue[k-1], queue[0] <- a
-          float old = qu[(size_t)k * D];
-          qu[(size_t)k * D] = prev;
-          if (k == didx) delayed = prev;
-          prev = old;
-        }
+      if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
+#pragma unroll
+        for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
+          if (k < Q) {
+            float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
+            qu[(size_t)k * D] = nv;
+            if (k == didx) delayed = nv;
+          }
       }
       actd[d] = delayed;
-      float qp = io.dof_state[(eD + d) * 2], qv = io.dof_state[(eD + d) * 2 + 1];
-      float tl = c.torque_limits[d];
-      float tq = io.kp_scale[eD + d] * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) -
-                 io.kd_scale[eD + d] * c.d_gains[d] * qv;
-      if (c.randomize_torque_rfi) {
-        float u = io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(c.seed, env, step_ctr, 1, d);
-        tq = tq + (u * 2.0f - 1.0f) * c.rfi_lim * io.rfi_lim_scale[eD + d] * tl;
-      }
-      if (c.use_rao) tq = tq + io.rao_scale[eD + d] * tl;
+      float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
+      if (c.randomize_torque_rfi) tq = tq + (u * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
+      if (c.use_rao) tq = tq + ras * tl;
       if (c.clip_torques) tq = clampf(tq, -tl, tl);
       tau[d] = tq;
-      q[d] = io.frame_dof_pos[eD + d];
-      qd[d] = io.frame_dof_vel[eD + d];
+      q[d] = fq;
+      qd[d] = fqd;
     }
     if (lane < 13) root[lane] = io.frame_root[(size_t)env * 13 + lane];
-    for (int i = lane; i < B * 3; i += PBHC_G) cf[i] = io.frame_contact[(size_t)env * B * 3 + i];
-    // old history + static DR features into the feature row
-    const int hoff = c.feat_off[PBHC_F_HISTORY];
-    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = io.hist[(size_t)env * c.hist_dim + i];
+    copy_g2l(cf, io.frame_contact + (size_t)env * B * 3, B * 3, lane);
     if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = io.dr_base_com[(size_t)env * 3 + lane];
-    for (int i = lane; i < c.dr_link_mass_dim; i += PBHC_G) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + i] = io.dr_link_mass[(size_t)env * c.dr_link_mass_dim + i];
+    copy_g2l(feat + c.feat_off[PBHC_F_DR_LINK_MASS], io.dr_link_mass + (size_t)env * c.dr_link_mass_dim, c.dr_link_mass_dim, lane);
     if (lane == 0) {
       feat[c.feat_off[PBHC_F_DR_FRICTION]] = io.dr_friction[env];
       feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
@@ -242,34 +349,20 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   clipcnt = group_sum(clipcnt);
   __syncthreads();
 
+  STAMP(1);
   // ---------------- phase B: rigid-body state of the new frame (sim-stub FK) -------------------
-  fk_chain(sk, lane, valid, root, q, qd, bp, bq, bv, bw);
-  // extended bodies (motion_tracking.py:619-643): p = R_ext(R_par off) + p_par, q = q_par*q_ext,
-  // w = w_par, v = v_par + w_par x off (offset NOT rotated, sic)
-  if (valid)
-    for (int b = B + lane; b < Bx; b += PBHC_G) {
-      int p = sk.parent[b];
-      f3 off = mk3(sk.offset[b][0], sk.offset[b][1], sk.offset[b][2]);
-      f4 eq = mk4(sk.local_rot_wxyz[b][1], sk.local_rot_wxyz[b][2], sk.local_rot_wxyz[b][3], sk.local_rot_wxyz[b][0]);
-      f4 pq = ld4(bq + 4 * p);
-      f3 pw = ld3(bw + 3 * p);
-      st3(bp + 3 * b, add3(quat_rotate(eq, quat_rotate(pq, off)), ld3(bp + 3 * p)));
-      st4(bq + 4 * b, quat_mul(pq, eq));
-      st3(bw + 3 * b, pw);
-      st3(bv + 3 * b, add3(ld3(bv + 3 * p), cross3(pw, off)));
-    }
+  fk_walk(skc, B, Bx, lane, valid, root, q, qd, rq /* scratch: relq, overwritten by the reference lookup later */, bp, bq, bv, bw);
 
+  STAMP(2);
   // ---------------- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference
   // frame motion_tracking.py:554,588) ----------------------------------------------------------
   if (valid) {
     f4 rq4 = ld4(root + 3);
     if (lane == 0) {
-      long long ep = io.episode_length_buf[env] + 1;
-      misc[M_EPLEN] = (float)ep;
-      float start = io.motion_start_times[env];
-      float mlen = io.motion_len[env];
+      misc[M_EPLEN] = (float)ep1;
+      const float mlen = mlen_env;
       misc[M_START] = start; misc[M_MLEN] = mlen;
-      float t = (float)(ep + 1) * dt + start;
+      const float t = tref;
       misc[M_TIME] = t;
       misc[M_PHASE] = t / mlen;
       feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
@@ -296,16 +389,33 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   }
   __syncthreads();
 
+  STAMP(3);
   // ---------------- phase D: reference frame (a6) ------------------------------------------------
-  int mid = 0;
-  f3 origin = mk3(0.f, 0.f, 0.f);
+  // lerp / slerp of the two prefetched frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
   if (valid) {
-    mid = (int)io.motion_ids[env];
-    origin = ld3(io.env_origins + (size_t)env * 3);
-    motion_lookup(tbl, D, Bx, lane, mid, misc[M_TIME], origin, true, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
+    const float a = 1.0f - blend, bb = blend;
+    if (lane < D) { rdof[lane] = a * rd0 + bb * rd1; rdofv[lane] = a * rdv0 + bb * rdv1; }
+    if (lane < 2) misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
+    if (lane < Bx) {
+      st3(rp + 3 * lane, mk3(a * rp0.x + bb * rp1.x + origin.x, a * rp0.y + bb * rp1.y + origin.y, a * rp0.z + bb * rp1.z + origin.z));
+      st4(rq + 4 * lane, slerp(rq0, rq1, bb));
+      st3(rv + 3 * lane, mk3(a * rv0.x + bb * rv1.x, a * rv0.y + bb * rv1.y, a * rv0.z + bb * rv1.z));
+      st3(rw + 3 * lane, mk3(a * rw0.x + bb * rw1.x, a * rw0.y + bb * rw1.y, a * rw0.z + bb * rw1.z));
+    }
+    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+    for (int i = lane + PBHC_G; i < Bx; i += PBHC_G) {            // bodies beyond the 32 lanes (29-DoF robots)
+      f3 p0 = ld3(r0 + o_pos + 3 * i), p1 = ld3(r1 + o_pos + 3 * i);
+      st3(rp + 3 * i, mk3(a * p0.x + bb * p1.x + origin.x, a * p0.y + bb * p1.y + origin.y, a * p0.z + bb * p1.z + origin.z));
+      st4(rq + 4 * i, slerp(ld4(r0 + o_rot + 4 * i), ld4(r1 + o_rot + 4 * i), bb));
+      f3 v0 = ld3(r0 + o_vel + 3 * i), v1 = ld3(r1 + o_vel + 3 * i);
+      st3(rv + 3 * i, mk3(a * v0.x + bb * v1.x, a * v0.y + bb * v1.y, a * v0.z + bb * v1.z));
+      f3 w0 = ld3(r0 + o_ang + 3 * i), w1 = ld3(r1 + o_ang + 3 * i);
+      st3(rw + 3 * i, mk3(a * w0.x + bb * w1.x, a * w0.y + bb * w1.y, a * w0.z + bb * w1.z));
+    }
   }
   __syncthreads();
 
+  STAMP(4);
   // ---------------- phase E: tracking differences + lane-parallel partial sums -------------------
   // (motion_tracking.py:645-731 and the reductions of the _reward_* terms)
   float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
@@ -351,10 +461,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       s_maxjp = fmaxf(s_maxjp, fabsf(dj));
       s_jp2 += dj * dj; s_jv2 += djv * djv;
       s_tau2 += tau[d] * tau[d];
-      float la = io.last_actions[eD + d] - act[d];
+      float la = pf_last_act - act[d];
       s_ar += la * la;
       s_qd2 += qd[d] * qd[d];
-      float acc = (io.last_dof_vel[eD + d] - qd[d]) / dt;
+      float acc = (pf_last_qd - qd[d]) / dt;
       s_qacc2 += acc * acc;
       float lo_l, hi_l;
       if (c.soft_pos_curriculum) {
@@ -394,7 +504,37 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   }
   __syncthreads();
 
+  STAMP(5);
   // ---------------- phase F: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ----
+  // (a) lane k < 10: e_k = exp(-err_k / sigma_k); lanes 10.. : per-foot norms.  (b) lane i <-> term i: cheap selects.
+  if (valid) {
+    if (lane < PBHC_NUM_SIGMA) {
+      float e;
+      switch (lane) {
+        case PBHC_S_MAX_JOINT_POS: e = red[R_MAXJP]; break;
+        case PBHC_S_UPPER_BODY_POS: e = red[R_UP]; break;
+        case PBHC_S_LOWER_BODY_POS: e = red[R_LO]; break;
+        case PBHC_S_VR_3POINT_POS: e = red[R_VR]; break;
+        case PBHC_S_FEET_POS: e = red[R_FEET]; break;
+        case PBHC_S_BODY_ROT: e = red[R_ROT]; break;
+        case PBHC_S_BODY_VEL: e = red[R_VEL]; break;
+        case PBHC_S_BODY_ANG_VEL: e = red[R_ANG]; break;
+        case PBHC_S_JOINT_POS: e = red[R_JP2] / (float)D; break;
+        default: e = red[R_JV2] / (float)D; break;
+      }
+      red[R_EXP0 + lane] = expf(-e / (float)glob[PBHC_G_SIGMA + lane]);
+    } else if (lane < PBHC_NUM_SIGMA + NF) {
+      const int f = lane - PBHC_NUM_SIGMA;
+      const float* fc = cf + 3 * c.feet[f];
+      const float* fv = bv + 3 * c.feet[f];
+      red[R_FOOT0 + 4 * f + 0] = norm3(ld3(fc));
+      red[R_FOOT0 + 4 * f + 1] = sqrtf(fc[0] * fc[0] + fc[1] * fc[1]);
+      red[R_FOOT0 + 4 * f + 2] = fc[2];
+      red[R_FOOT0 + 4 * f + 3] = norm3(ld3(fv));
+      red[R_FOOT0 + 8 + f] = sqrtf(fv[0] * fv[0] + fv[1] * fv[1]);
+    }
+  }
+  __syncthreads();
   float err[PBHC_NUM_SIGMA];
 #pragma unroll
   for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
@@ -404,25 +544,24 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     float myrew = 0.0f;
     if (lane < c.num_terms) {
       float raw = 0.0f;
-      const int id = c.term_id[lane];
-#define SIG(k) ((float)glob[PBHC_G_SIGMA + (k)])
+      const int id = pf_tid;
+      const float* ex = red + R_EXP0;
+      const float* ft = red + R_FOOT0;
       switch (id) {
         case PBHC_R_TELEOP_CONTACT_MASK: {
           float e = 0.0f;
           for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
           raw = 1.0f - e / (float)NF;
         } break;
-        case PBHC_R_TELEOP_MAX_JOINT_POSITION: raw = expf(-red[R_MAXJP] / SIG(PBHC_S_MAX_JOINT_POS)); break;
-        case PBHC_R_TELEOP_BODY_POSITION_EXTEND:
-          raw = expf(-red[R_LO] / SIG(PBHC_S_LOWER_BODY_POS)) * c.body_pos_lower_weight + expf(-red[R_UP] / SIG(PBHC_S_UPPER_BODY_POS)) * c.body_pos_upper_weight;
-          break;
-        case PBHC_R_TELEOP_VR_3POINT: raw = expf(-red[R_VR] / SIG(PBHC_S_VR_3POINT_POS)); break;
-        case PBHC_R_TELEOP_BODY_POSITION_FEET: raw = expf(-red[R_FEET] / SIG(PBHC_S_FEET_POS)); break;
-        case PBHC_R_TELEOP_BODY_ROTATION_EXTEND: raw = expf(-red[R_ROT] / SIG(PBHC_S_BODY_ROT)); break;
-        case PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND: raw = expf(-red[R_ANG] / SIG(PBHC_S_BODY_ANG_VEL)); break;
-        case PBHC_R_TELEOP_BODY_VELOCITY_EXTEND: raw = expf(-red[R_VEL] / SIG(PBHC_S_BODY_VEL)); break;
-        case PBHC_R_TELEOP_JOINT_POSITION: raw = expf(-(red[R_JP2] / (float)D) / SIG(PBHC_S_JOINT_POS)); break;
-        case PBHC_R_TELEOP_JOINT_VELOCITY: raw = expf(-(red[R_JV2] / (float)D) / SIG(PBHC_S_JOINT_VEL)); break;
+        case PBHC_R_TELEOP_MAX_JOINT_POSITION: raw = ex[PBHC_S_MAX_JOINT_POS]; break;
+        case PBHC_R_TELEOP_BODY_POSITION_EXTEND: raw = ex[PBHC_S_LOWER_BODY_POS] * c.body_pos_lower_weight + ex[PBHC_S_UPPER_BODY_POS] * c.body_pos_upper_weight; break;
+        case PBHC_R_TELEOP_VR_3POINT: raw = ex[PBHC_S_VR_3POINT_POS]; break;
+        case PBHC_R_TELEOP_BODY_POSITION_FEET: raw = ex[PBHC_S_FEET_POS]; break;
+        case PBHC_R_TELEOP_BODY_ROTATION_EXTEND: raw = ex[PBHC_S_BODY_ROT]; break;
+        case PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND: raw = ex[PBHC_S_BODY_ANG_VEL]; break;
+        case PBHC_R_TELEOP_BODY_VELOCITY_EXTEND: raw = ex[PBHC_S_BODY_VEL]; break;
+        case PBHC_R_TELEOP_JOINT_POSITION: raw = ex[PBHC_S_JOINT_POS]; break;
+        case PBHC_R_TELEOP_JOINT_VELOCITY: raw = ex[PBHC_S_JOINT_VEL]; break;
         case PBHC_R_PENALTY_TORQUES: raw = red[R_TAU2]; break;
         case PBHC_R_PENALTY_DOF_VEL: raw = red[R_QD2]; break;
         case PBHC_R_PENALTY_DOF_ACC: raw = red[R_QACC2]; break;
@@ -430,7 +569,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
         case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
           for (int f = 0; f < NF; ++f) {
-            bool contact = cf[3 * c.feet[f] + 2] > 1.0f;
+            bool contact = ft[4 * f + 2] > 1.0f;
             bool cfilt = contact || (misc[M_LASTC0 + f] != 0.0f);
             float fat = misc[M_FAT0 + f];
             float first = (fat > 0.0f && cfilt) ? 1.0f : 0.0f;
@@ -440,22 +579,17 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
           }
         } break;
         case PBHC_R_PENALTY_FEET_CONTACT_FORCES:
-          for (int f = 0; f < NF; ++f) raw += fmaxf(norm3(ld3(cf + 3 * c.feet[f])) - c.max_contact_force, 0.0f);
+          for (int f = 0; f < NF; ++f) raw += fmaxf(ft[4 * f] - c.max_contact_force, 0.0f);
           break;
         case PBHC_R_PENALTY_STUMBLE:
-          for (int f = 0; f < NF; ++f) {
-            const float* fc = cf + 3 * c.feet[f];
-            if (sqrtf(fc[0] * fc[0] + fc[1] * fc[1]) > 5.0f * fabsf(fc[2])) raw = 1.0f;
-          }
+          for (int f = 0; f < NF; ++f)
+            if (ft[4 * f + 1] > 5.0f * fabsf(ft[4 * f + 2])) raw = 1.0f;
           break;
         case PBHC_R_PENALTY_SLIPPAGE:
-          for (int f = 0; f < NF; ++f) raw += norm3(ld3(bv + 3 * c.feet[f])) * (norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f);
+          for (int f = 0; f < NF; ++f) raw += ft[4 * f + 3] * (ft[4 * f] > 1.0f ? 1.0f : 0.0f);
           break;
         case PBHC_R_FOOT_SLIP_PENALTY:
-          for (int f = 0; f < NF; ++f) {
-            const float* v = bv + 3 * c.feet[f];
-            raw += (norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f) * sqrtf(v[0] * v[0] + v[1] * v[1]);
-          }
+          for (int f = 0; f < NF; ++f) raw += (ft[4 * f] > 1.0f ? 1.0f : 0.0f) * ft[8 + f];
           break;
         case PBHC_R_LIMITS_DOF_POS: raw = red[R_LIMPOS]; break;
         case PBHC_R_LIMITS_DOF_VEL: raw = red[R_LIMVEL]; break;
@@ -464,11 +598,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_R_ALIVE: raw = 1.0f; break;
         default: raw = 0.0f;
       }
-#undef SIG
-      myrew = raw * c.term_scale[lane];
-      if (c.term_penalty[lane]) myrew = myrew * pen_scale;
-      float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
-      sum[c.term_sum_col[lane]] += myrew;
+      myrew = raw * pf_tscale;
+      if (pf_tpen) myrew = myrew * pen_scale;
+      io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol] = pf_sum + myrew;
     }
     if (c.use_vec_reward) {
       if (lane < c.num_rew_cols) {
@@ -518,6 +650,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       for (int i = lane; i < B * 3; i += PBHC_G) io.contact_forces[(size_t)env * B * 3 + i] = cf[i];
   }
 
+  STAMP(6);
   // ---------------- phase G: reset_envs_idx for terminated envs (legged_robot_base.py:491-517,
   // 599-686; motion_tracking.py:265-287,369-378,445-543) ------------------------------------------
   const bool do_reset = valid && misc[M_RESET] != 0.0f;
@@ -570,7 +703,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
     // invalidated, motion_tracking.py:378,536-543,477-507)
     float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
-    motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, red + 30, rp, rq, rv, rw);
+    motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, red + 46, rp, rq, rv, rw);
   }
   __syncthreads();
   if (do_reset && lane == 0) {
@@ -581,6 +714,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   }
   if (valid && lane == 0) etr_val = io.end_time_ratio_buf[env];
 
+  STAMP(7);
   // ---------------- phase H: remaining features ---------------------------------------------------
   if (valid) {
     const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
@@ -596,22 +730,39 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   }
   __syncthreads();
 
+  STAMP(8);
   // ---------------- phase I: observation groups + history write-back ------------------------------
   // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
   if (valid) {
     const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
     for (int g = 0; g < c.num_groups; ++g) {
-      const PbhcOutMap& m = c.groups[g];
-      float* out = io.obs[g] + (size_t)env * m.dim;
-      for (int j = lane; j < m.dim; j += PBHC_G) {
-        float x = feat[m.src[j]];
-        float ns = m.noise[j];
-        if (ns != 0.0f) x = x + (rng_uniform(c.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns * noise_cur);
-        x = x * m.scale[j];
-        if (m.clip) x = clampf(x, -c.clip_observations, c.clip_observations);
-        out[j] = x;
+      const int dim = c.groups[g].dim, clip = c.groups[g].clip;
+      const int* __restrict__ msrc = c.groups[g].src;
+      const float* __restrict__ mscale = c.groups[g].scale;
+      const float* __restrict__ mnoise = c.groups[g].noise;
+      float* __restrict__ out = io.obs[g] + (size_t)env * dim;
+      for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
+        int si[8]; float sc[8], ns[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * PBHC_G;
+          const bool ok = j < dim;
+          si[u] = ok ? msrc[j] : 0; sc[u] = ok ? mscale[j] : 0.0f; ns[u] = ok ? mnoise[j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * PBHC_G;
+          if (j < dim) {
+            float x = feat[si[u]];
+            if (ns[u] != 0.0f) x = x + (rng_uniform(c.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
+            x = x * sc[u];
+            if (clip) x = clampf(x, -c.clip_observations, c.clip_observations);
+            out[j] = x;
+          }
+        }
       }
     }
+    STAMP(9);
     // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
     for (int d = lane; d < D; d += PBHC_G) {
       io.actions[eD + d] = act[d];
@@ -639,6 +790,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     }
   }
 
+  STAMP(10);
   // ---------------- workgroup partial sums for the host-side scalars of the reference ------------
   if (lane == 0) {
     float* bpq = blockpart + le * PBHC_NP;
@@ -661,22 +813,31 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];
     partials[(size_t)blockIdx.x * PBHC_NP + threadIdx.x] = v;
   }
+  STAMP(11);
 }
 
 // =================================================================================================
 //  k_env_finalize: the scalars the reference updates on the host each step
 // =================================================================================================
-__global__ void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks) {
+#define PBHC_FIN_CHUNKS 16
+__global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks) {
+  __shared__ double acc[PBHC_FIN_CHUNKS][64];
   __shared__ double tot[PBHC_NP];
   const PbhcEnvConfig& c = *cfgp;
-  int k = threadIdx.x;
-  if (k < PBHC_NP) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * PBHC_NP + k];
-    tot[k] = s;
+  const int k = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+  // column sums of the workgroup partials in a FIXED order (chunk-strided, then chunk order): deterministic
+  double s = 0.0;
+  if (k < PBHC_NP)
+    for (int b = chunk; b < nblocks; b += PBHC_FIN_CHUNKS) s += (double)partials[(size_t)b * PBHC_NP + k];
+  acc[chunk][k] = s;
+  __syncthreads();
+  if (threadIdx.x < PBHC_NP) {
+    double t = 0.0;
+    for (int ch = 0; ch < PBHC_FIN_CHUNKS; ++ch) t += acc[ch][threadIdx.x];
+    tot[threadIdx.x] = t;
   }
   __syncthreads();
-  if (k != 0) return;
+  if (threadIdx.x != 0) return;
   const double N = (double)c.num_envs;
   // adaptive sigma (motion_tracking.py:1030-1048, type "origin")
   if (c.adaptive_sigma)
@@ -728,11 +889,15 @@ __global__ void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* _
 // =================================================================================================
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_sim_fk(PbhcSkeleton sk, const float* __restrict__ root_states, const float* __restrict__ dof_pos,
                                                             const float* __restrict__ dof_vel, int dof_stride, int n, float* __restrict__ out) {
-  __shared__ float sm[PBHC_EPB][16 + 64 + 40 * 13];
+  __shared__ float sm[PBHC_EPB][16 + 64 + PBHC_MAX_BODIES * 17];
+  __shared__ float skc[SKC_WORDS];
   const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G, env = blockIdx.x * PBHC_EPB + le;
   const bool valid = env < n;
   float* root = sm[le];
-  float *q = root + 16, *qd = q + 32, *bp = qd + 32, *bq = bp + 120, *bv = bq + 160, *bw = bv + 120;
+  float *q = root + 16, *qd = q + 32, *bp = qd + 32, *bq = bp + 3 * PBHC_MAX_BODIES, *bv = bq + 4 * PBHC_MAX_BODIES, *bw = bv + 3 * PBHC_MAX_BODIES;
+  float* relq = bw + 3 * PBHC_MAX_BODIES;
+  stage_skeleton(sk, skc);
+
   if (valid) {
     if (lane < 13) root[lane] = root_states[(size_t)env * 13 + lane];
     for (int d = lane; d < sk.num_dof; d += PBHC_G) {
@@ -741,7 +906,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_sim_fk(PbhcSkeleton sk, co
     }
   }
   __syncthreads();
-  fk_chain(sk, lane, valid, root, q, qd, bp, bq, bv, bw);
+  fk_walk(skc, sk.num_bodies, sk.num_bodies, lane, valid, root, q, qd, relq, bp, bq, bv, bw);
   if (valid)
     for (int b = lane; b < sk.num_bodies; b += PBHC_G) {
       float* o = out + ((size_t)env * sk.num_bodies + b) * 13;
@@ -751,11 +916,11 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_sim_fk(PbhcSkeleton sk, co
 
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_motion_state(PbhcMotionTable tbl, int Bx, int D, const int64_t* __restrict__ ids, const float* __restrict__ times,
                                                                   const float* __restrict__ offset, int n, float* __restrict__ out) {
-  __shared__ float sm[PBHC_EPB][64 + 8 + 40 * 13];
+  __shared__ float sm[PBHC_EPB][64 + 8 + PBHC_MAX_BODIES * 13];
   const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G, i = blockIdx.x * PBHC_EPB + le;
   const bool valid = i < n;
   float* rdof = sm[le];
-  float *rdofv = rdof + 32, *rc = rdofv + 32, *rp = rc + 8, *rq = rp + 120, *rv = rq + 160, *rw = rv + 120;
+  float *rdofv = rdof + 32, *rc = rdofv + 32, *rp = rc + 8, *rq = rp + 3 * PBHC_MAX_BODIES, *rv = rq + 4 * PBHC_MAX_BODIES, *rw = rv + 3 * PBHC_MAX_BODIES;
   if (valid) {
     f3 off = offset ? ld3(offset + (size_t)i * 3) : mk3(0.f, 0.f, 0.f);
     motion_lookup(tbl, D, Bx, lane, (int)ids[i], times[i], off, true, rdof, rdofv, rc, rp, rq, rv, rw);
@@ -948,6 +1113,13 @@ struct PbhcEnv {
 extern "C" {
 
 int pbhc_abi_version(void) { return PBHC_ABI_VERSION; }
+#ifdef PBHC_STAMPS
+int pbhc_debug_read_stamps(unsigned long long* out, int n) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32)));
+  return PBHC_OK;
+}
+#endif
 const char* pbhc_last_error(void) { return g_err; }
 int pbhc_sizeof_env_config(void) { return (int)sizeof(PbhcEnvConfig); }
 int pbhc_sizeof_step_io(void) { return (int)sizeof(PbhcStepIO); }
@@ -959,6 +1131,13 @@ static int check_skel(const PbhcSkeleton* sk) {
   ARG_CHECK(sk->parent[0] == -1);
   for (int i = 1; i < sk->num_bodies_ext; ++i) ARG_CHECK(sk->parent[i] >= 0 && sk->parent[i] < i && sk->parent[i] < sk->num_bodies);
   for (int i = 1; i < sk->num_bodies; ++i) ARG_CHECK(sk->depth[i] == sk->depth[sk->parent[i]] + 1 && sk->depth[i] <= sk->max_depth);
+  for (int b = 0; b < sk->num_bodies_ext; ++b) {
+    const int node = b < sk->num_bodies ? b : sk->parent[b];
+    ARG_CHECK(sk->chain_len[b] == sk->depth[node] && sk->chain_len[b] <= PBHC_MAX_DEPTH);
+    int cur = node;
+    for (int k = sk->chain_len[b] - 1; k >= 0; --k) { ARG_CHECK(sk->chain[b][k] == cur && cur >= 1 && cur < sk->num_bodies); cur = sk->parent[cur]; }
+    ARG_CHECK(cur == 0);
+  }
   return PBHC_OK;
 }
 
@@ -1024,7 +1203,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->d_glob = globals;
   e->nblocks = (cfg->num_envs + PBHC_EPB - 1) / PBHC_EPB;
   e->lds_stride = Lds::FEAT + ((cfg->feat_dim + 3) & ~3);
-  e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+  e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + SKC_WORDS + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
   e->step_ctr = 0;
   e->profile = 0;
   e->prof_count = 0;
@@ -1090,7 +1269,7 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   hipLaunchKernelGGL(k_env_step, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials,
                      e->lds_stride, e->step_ctr);
   if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
-  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks);
   e->step_ctr++;
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;

@@ -257,12 +257,28 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
         "RELYAW": 1, "BASE_POS_Z": 1, "DIF_JOINT_ANGLES": D, "DIF_JOINT_VELOCITIES": D, "LOCAL_REF_RIGID_BODY_VEL": 3 * Bx,
         "GLOBAL_REF_RIGID_BODY_VEL": 3 * Bx, "HISTORY": c.hist_dim, "ZERO": 1,
     }
+    # which features do the observation maps read?  the kernel skips the others (feat_off = -1)
+    used = {"HISTORY", "ZERO"}
+    for keys in ob.obs_dict.values():
+        for key in keys:
+            k = key[:-4] if key.endswith("_raw") else key
+            if k in OBS_FEATURES:
+                used.add(OBS_FEATURES[k])
+    for hk in hist_keys:
+        if hk in OBS_FEATURES:
+            used.add(OBS_FEATURES[hk])
     off = 0
     feat_off = {}
     for name, n in fdim.items():
-        feat_off[name] = off
-        c.feat_off[K["PBHC_F_" + name]] = off
-        off += n
+        if name in used:
+            feat_off[name] = off
+            c.feat_off[K["PBHC_F_" + name]] = off
+            off += n
+    trash = off                       # features nobody reads share one scratch region at the end of the row
+    for name, n in fdim.items():
+        if name not in used:
+            c.feat_off[K["PBHC_F_" + name]] = trash
+            off = max(off, trash + n)
     c.feat_dim = off
     c.dr_link_mass_dim = sim_link_mass_dim
     L.feat_off, L.feat_dim_each = feat_off, fdim

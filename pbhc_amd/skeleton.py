@@ -127,4 +127,16 @@ class Skeleton:
         for d in range(self.num_dof):
             for k in range(3):
                 s.dof_axis[d][k] = float(self.dof_axis[d, k])
+        for b in range(self.num_bodies_ext):
+            node = b if b < self.num_bodies else int(self.parents[b])
+            path = []
+            while node > 0:
+                path.append(node)
+                node = int(self.parents[node])
+            path.reverse()
+            if len(path) > K["PBHC_MAX_DEPTH"]:
+                raise _lib.PbhcError("kinematic chain deeper than PBHC_MAX_DEPTH")
+            s.chain_len[b] = len(path)
+            for k, a in enumerate(path):
+                s.chain[b][k] = a
         return s

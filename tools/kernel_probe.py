@@ -1,0 +1,36 @@
+"""Diagnostic: average k_env_step time and (with PBHC_LIB=pbhc_amd/libpbhc_hip_stamps.so) the per-phase
+shader-clock shares of workgroup 0.  Not part of the product or the tests."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from bench import build, make_replay_on_device
+from pbhc_amd import _lib
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg, env, _ = build(N, "cuda:0", 0)
+env.reset_all()
+env.simulator.set_replay(*make_replay_on_device(env, 130, 1))
+lib = _lib.lib()
+act = torch.zeros(N, env.num_dof, device="cuda:0")
+for _ in range(20):
+    env.step({"actions": act})
+_lib.check(lib.pbhc_env_profile(env._env, 1))
+for _ in range(100):
+    env.step({"actions": act})
+buf = (C.c_float * 512)(); cnt = C.c_int(0)
+_lib.check(lib.pbhc_env_profile_read(env._env, buf, 100, C.byref(cnt)))
+ms = sorted(buf[i] for i in range(cnt.value))
+print(f"k_env_step N={N}: median {ms[len(ms)//2]*1e3:.1f} us  min {ms[0]*1e3:.1f} us  mean {sum(ms)/len(ms)*1e3:.1f} us")
+if hasattr(lib, "pbhc_debug_read_stamps"):
+    st = (C.c_ulonglong * 32)()
+    lib.pbhc_debug_read_stamps(st, 32)
+    names = ["A load+torque", "B fk", "C scalars", "D lookup", "E diffs", "F reward", "G reset", "H features", "I obs", "J writeback", "partials"]
+    tot = st[11] - st[0]
+    for i, n in enumerate(names):
+        d = st[i + 1] - st[i]
+        print(f"  {n:16s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
+    print(f"  total {tot} cycles")
