@@ -305,6 +305,25 @@ int pbhc_env_profile_read(PbhcEnv* env, float* ms_out, int max_count, int* count
 int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int T, int N, int R,
              float gamma, float lam, float* returns, float* advantages, double* stats, void* stream);
 
+/* Fused forward + backward of the MHPPO losses (mh_ppo.py:433-480,509-511) on the network outputs of one minibatch.
+ * mu [B,A], std [A] (the actor's `std` parameter), value [B,R]; batch tensors as the reference's storage keys
+ * (actions [B,A], old_logp [B], old_mu/old_sigma [B,A], adv [B], returns/old_values [B,R]).
+ * Out: grad_mu = d(actor_loss)/d(mu) [B,A], grad_value = d(critic_loss)/d(value) [B,R], grad_std [A] (surrogate part and the
+ * entropy bonus), scalars[4] = {surrogate loss, value loss, entropy, mean KL}.  If adapt_lr != 0 the adaptive-KL rule
+ * (mh_ppo.py:455-466) is applied to lr[0] (actor) and lr[1] (critic) on the device.
+ * scratch: pbhc_ppo_loss_scratch_floats(B) floats. */
+int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
+                  const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,
+                  float value_coef, float entropy_coef, int use_clipped_value_loss, float desired_kl, int adapt_lr, float* grad_mu, float* grad_value,
+                  float* grad_std, float* scalars, float* lr, float* scratch, void* stream);
+int pbhc_ppo_loss_scratch_floats(int B);
+
+/* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524) over ONE flat fp32 segment of n
+ * parameters (param/grad/exp_avg/exp_avg_sq flat views; lr and step are device scalars, step is incremented).
+ * scratch: 512 doubles.  norm_out (may be NULL): the pre-clip gradient norm. */
+int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
+                   float beta2, float eps, double* scratch, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

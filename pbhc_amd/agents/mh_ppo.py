@@ -47,6 +47,45 @@ def _make_writer(log_dir):
         return _NullWriter()
 
 
+class _FlatAdamView:
+    """torch.optim.Adam-format state_dict()/load_state_dict() over one network's slice of the flat Adam buffers, so
+    checkpoints keep the reference's `*_optimizer_state_dict` entries (mh_ppo.py:195-204)."""
+
+    def __init__(self, algo, which):
+        self.algo, self.which = algo, which
+
+    def _range(self):
+        a = self.algo
+        n_actor_params = len(list(a.actor.parameters()))
+        sl = a._slices[:n_actor_params] if self.which == 0 else a._slices[n_actor_params:]
+        return sl
+
+    def state_dict(self):
+        a = self.algo
+        state = {}
+        for i, (o, k) in enumerate(self._range()):
+            shape = a._params[i if self.which == 0 else i + len(list(a.actor.parameters()))].shape
+            state[i] = {"step": a._adam_step[self.which].detach().clone().cpu(), "exp_avg": a._mflat[o:o + k].view(shape).clone(),
+                        "exp_avg_sq": a._vflat[o:o + k].view(shape).clone()}
+        group = {"lr": float(a._lr[self.which]), "betas": tuple(a.betas), "eps": a.adam_eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        a = self.algo
+        for i, (o, k) in enumerate(self._range()):
+            if i in sd["state"]:
+                e = sd["state"][i]
+                a._mflat[o:o + k].copy_(e["exp_avg"].reshape(-1).to(a.device))
+                a._vflat[o:o + k].copy_(e["exp_avg_sq"].reshape(-1).to(a.device))
+                a._adam_step[self.which] = float(e["step"])
+        a._lr[self.which] = float(sd["param_groups"][0]["lr"])
+
+    @property
+    def param_groups(self):
+        return [{"lr": float(self.algo._lr[self.which])}]
+
+
 class MHPPO:
     def __init__(self, env, config, log_dir=None, device="cpu"):
         self.device = torch.device(device)
@@ -117,12 +156,42 @@ class MHPPO:
         if self.world_size > 1:      # replicas start from rank 0's weights
             for p in list(self.actor.parameters()) + list(self.critic.parameters()):
                 dist.broadcast(p.data, src=0)
-        self._lr_a = torch.tensor(float(self.actor_learning_rate), device=self.device)
-        self._lr_c = torch.tensor(float(self.critic_learning_rate), device=self.device)
-        self.actor_optimizer = optim.Adam(self.actor.parameters(), lr=self._lr_a, capturable=True, foreach=True)
-        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self._lr_c, capturable=True, foreach=True)
-        self._params = list(self.actor.parameters()) + list(self.critic.parameters())
-        self._grad_bucket = torch.zeros(sum(p.numel() for p in self._params), device=self.device)
+        self._flatten_parameters()
+
+    def _flatten_parameters(self):
+        """All actor+critic parameters (and their grads / Adam moments) live in ONE flat fp32 buffer each:
+        one RCCL all-reduce over the gradient bucket, one clip+Adam launch per network."""
+        dev = self.device
+        pa, pc = list(self.actor.parameters()), list(self.critic.parameters())
+        self._params = pa + pc
+        self._n_actor = sum(p.numel() for p in pa)
+        self._n_critic = sum(p.numel() for p in pc)
+        n = self._n_actor + self._n_critic
+        self._pflat = torch.zeros(n, device=dev)
+        self._gflat = torch.zeros(n, device=dev)
+        self._mflat = torch.zeros(n, device=dev)
+        self._vflat = torch.zeros(n, device=dev)
+        o = 0
+        self._slices = []
+        for p in self._params:
+            k = p.numel()
+            self._pflat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self._pflat[o:o + k].view_as(p)
+            p.grad = self._gflat[o:o + k].view_as(p)
+            self._slices.append((o, k))
+            o += k
+        std_idx = [i for i, (nme, _) in enumerate(self.actor.named_parameters()) if nme == "std"][0]
+        self._std_slice = self._slices[std_idx]
+        self._lr = torch.tensor([float(self.actor_learning_rate), float(self.critic_learning_rate)], device=dev)
+        self._lr_a, self._lr_c = self._lr[0:1], self._lr[1:2]
+        self._adam_step = torch.zeros(2, device=dev)          # [actor, critic] step counts (float, like torch's `step` tensors)
+        self._adam_scratch = torch.zeros(2, 512, dtype=torch.float64, device=dev)
+        self._grad_norms = torch.zeros(2, device=dev)
+        self._loss_scalars = torch.zeros(4, device=dev)
+        self.betas, self.adam_eps = (0.9, 0.999), 1e-8
+        # kept for checkpoint (de)serialisation in torch.optim.Adam's format
+        self.actor_optimizer = _FlatAdamView(self, 0)
+        self.critic_optimizer = _FlatAdamView(self, 1)
 
     def _setup_storage(self):
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
@@ -142,6 +211,11 @@ class MHPPO:
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
+        mb = (T * N) // self.num_mini_batches
+        self._mb = mb
+        self._loss_scratch = torch.zeros(_lib.lib().pbhc_ppo_loss_scratch_floats(mb), device=self.device)
+        self._grad_mu = torch.zeros(mb, self.num_act, device=self.device)
+        self._grad_value = torch.zeros(mb, self.num_rew_fn, device=self.device)
 
     def _eval_mode(self):
         self.actor.eval(); self.critic.eval()
@@ -165,10 +239,7 @@ class MHPPO:
         return d["infos"]
 
     def _opt_state_for_save(self, opt, lr):
-        sd = opt.state_dict()
-        for g in sd["param_groups"]:
-            g["lr"] = float(lr)              # the reference stores a python float
-        return sd
+        return opt.state_dict()
 
     def save(self, path, infos=None):
         torch.save({
@@ -182,8 +253,8 @@ class MHPPO:
 
     def set_learning_rate(self, actor_learning_rate, critic_learning_rate):
         self.actor_learning_rate, self.critic_learning_rate = actor_learning_rate, critic_learning_rate
-        self._lr_a.fill_(float(actor_learning_rate))
-        self._lr_c.fill_(float(critic_learning_rate))
+        self._lr[0] = float(actor_learning_rate)
+        self._lr[1] = float(critic_learning_rate)
 
     # ---- learn loop (mh_ppo.py:206-250) ----------------------------------------------------
     def learn(self, num_iterations=None):
@@ -293,22 +364,52 @@ class MHPPO:
         return {k: v / n for k, v in loss.items()}
 
     def _allreduce_grads(self):
-        """ONE RCCL all-reduce of the flat actor+critic gradient bucket (≈5 MB fp32), then average."""
-        flat = self._grad_bucket
-        o = 0
-        for p in self._params:
-            n = p.numel()
-            flat[o:o + n].copy_(p.grad.reshape(-1))
-            o += n
-        dist.all_reduce(flat)
-        flat.div_(self.world_size)
-        o = 0
-        for p in self._params:
-            n = p.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p.grad))
-            o += n
+        """ONE RCCL all-reduce of the flat actor+critic gradient buffer (≈5 MB fp32), then average."""
+        dist.all_reduce(self._gflat)
+        self._gflat.div_(self.world_size)
 
     def _update_ppo(self, b, loss):
+        if self._need_next:
+            return self._update_ppo_eager(b, loss)
+        lib = _lib.lib()
+        c = self
+        mu = self.actor.actor_module(b["actor_obs"])
+        value = self.critic.critic_module(b["critic_obs"])
+        B = mu.shape[0]
+        if B != self._mb:
+            raise _lib.PbhcError("minibatch size changed")
+        self._gflat.zero_()
+        so, sn = self._std_slice
+        adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
+        on_device_lr = adapt if self.world_size == 1 else 0
+        st = _lib.current_stream()
+        _lib.check(lib.pbhc_ppo_loss(mu.data_ptr(), self.actor.std.data_ptr(), value.data_ptr(), b["actions"].data_ptr(), b["actions_log_prob"].data_ptr(),
+                                     b["action_mean"].data_ptr(), b["action_sigma"].data_ptr(), b["advantages"].data_ptr(), b["returns"].data_ptr(),
+                                     b["values"].data_ptr(), B, self.num_act, self.num_rew_fn, float(self.clip_param), float(self.value_loss_coef),
+                                     float(self.entropy_coef), int(self.use_clipped_value_loss), float(self.desired_kl or 0.0), on_device_lr,
+                                     self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._gflat[so:so + sn].data_ptr(), self._loss_scalars.data_ptr(),
+                                     self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
+        torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+        if self.world_size > 1:
+            if adapt:
+                kl_mean = self._loss_scalars[3].clone()
+                dist.all_reduce(kl_mean)
+                kl_mean = kl_mean / self.world_size
+                up = kl_mean > self.desired_kl * 2.0
+                down = (kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0)
+                self._lr.copy_(torch.where(up, torch.clamp(self._lr / 1.5, min=1e-5), torch.where(down, torch.clamp(self._lr * 1.5, max=1e-2), self._lr)))
+            self._allreduce_grads()
+        na, nc = self._n_actor, self._n_critic
+        for k, (o, n) in enumerate(((0, na), (na, nc))):
+            _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
+                                          self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
+                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, self._adam_scratch[k].data_ptr(),
+                                          self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
+        loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
+        return loss
+
+    def _update_ppo_eager(self, b, loss):
+        """Eager PyTorch form of the update (used only for the optional L2C2 regulariser, mh_ppo.py:488-507)."""
         self.actor.update_distribution(b["actor_obs"])
         logp = self.actor.get_actions_log_prob(b["actions"])
         value = self.critic.evaluate(b["critic_obs"])
@@ -323,8 +424,7 @@ class MHPPO:
                     kl_mean = kl_mean / self.world_size
                 up = kl_mean > self.desired_kl * 2.0
                 down = (kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0)
-                for lr in (self._lr_a, self._lr_c):
-                    lr.copy_(torch.where(up, torch.clamp(lr / 1.5, min=1e-5), torch.where(down, torch.clamp(lr * 1.5, max=1e-2), lr)))
+                self._lr.copy_(torch.where(up, torch.clamp(self._lr / 1.5, min=1e-5), torch.where(down, torch.clamp(self._lr * 1.5, max=1e-2), self._lr)))
         adv = b["advantages"].squeeze(-1)
         ratio = torch.exp(logp - b["actions_log_prob"].squeeze(-1))
         surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
@@ -344,16 +444,18 @@ class MHPPO:
             l2c2_p = self.cfg_l2c2.lambda_policy * (b["actions"] - u_mu).pow(2).mean()
         actor_loss = surrogate - self.entropy_coef * entropy_loss + l2c2_p
         critic_loss = self.value_loss_coef * value_loss + l2c2_v
-        self.actor_optimizer.zero_grad(set_to_none=False)
-        self.critic_optimizer.zero_grad(set_to_none=False)
+        self._gflat.zero_()
         actor_loss.backward()
         critic_loss.backward()
         if self.world_size > 1:
             self._allreduce_grads()
-        nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm, foreach=True)
-        nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm, foreach=True)
-        self.actor_optimizer.step()
-        self.critic_optimizer.step()
+        lib, st = _lib.lib(), _lib.current_stream()
+        na, nc = self._n_actor, self._n_critic
+        for k, (o, n) in enumerate(((0, na), (na, nc))):
+            _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
+                                          self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
+                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, self._adam_scratch[k].data_ptr(),
+                                          self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
         with torch.no_grad():
             loss["Value"] += value_loss.detach(); loss["Surrogate"] += surrogate.detach(); loss["Entropy"] += entropy_loss.detach()
             loss["L2C2_Value"] += l2c2_v.detach(); loss["L2C2_Policy"] += l2c2_p.detach()

@@ -21,7 +21,8 @@ using namespace pbhc;
 #define PBHC_EPB 4    // envs per workgroup
 #define PBHC_NP 48    // partial sums per workgroup
 
-static thread_local char g_err[512] = "";
+thread_local char g_pbhc_err[512] = "";
+#define g_err g_pbhc_err
 
 // Diagnostic build only (-DPBHC_STAMPS, libpbhc_hip_stamps.so): shader-clock stamps of workgroup 0 at the phase
 // boundaries of k_env_step, written to a buffer nothing else reads.  The product build contains none of this.

@@ -1,0 +1,258 @@
+// pbhc_ppo.hip — fused PPO-update kernels (gfx950): the elementwise / reduction work of
+// MHPPO._update_ppo (reference: humanoidverse/agents/mh_ppo/mh_ppo.py:433-533) that eager PyTorch runs as
+// ~100 tiny launches per minibatch.  The MLP GEMMs stay on PyTorch-ROCm (rocBLAS/hipBLASLt); these kernels
+// consume the network outputs (mu, value) and hand back d(loss)/d(mu), d(loss)/d(value), d(loss)/d(std).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/pbhc_hip.h"
+
+extern thread_local char g_pbhc_err[512];
+#define HIP_CHECK(x)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (x);                                                                                 \
+    if (e_ != hipSuccess) {                                                                              \
+      snprintf(g_pbhc_err, sizeof(g_pbhc_err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      return PBHC_EHIP;                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define ARG_CHECK(c)                                                                         \
+  do {                                                                                       \
+    if (!(c)) {                                                                              \
+      snprintf(g_pbhc_err, sizeof(g_pbhc_err), "%s:%d bad argument: %s", __FILE__, __LINE__, #c); \
+      return PBHC_EINVAL;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+#define LOSS_ROWS 8          // rows (samples) per 256-thread workgroup, 32 lanes per row
+#define LOSS_NP 8            // scalar partial sums per workgroup: surrogate, value, kl, (pad)
+
+__device__ __forceinline__ float gsum32(float v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+  return v;
+}
+
+// One row per 32-lane group: lane a < A <-> action dim a, lane r < R <-> value head r.
+// partial[blk][0..2] = sum over the block's rows of (max(s1,s2), sum_r max(l1,l2), kl);
+// gstd_part[blk][a] = sum over the block's rows of d(surrogate)/d(sigma_a) (before the 1/B).
+__global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, const float* __restrict__ stdp, const float* __restrict__ value,
+                                                  const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                                  const float* __restrict__ old_sigma, const float* __restrict__ adv, const float* __restrict__ returns,
+                                                  const float* __restrict__ old_values, int B, int A, int R, float clip, float value_coef,
+                                                  int clipped_value, float* __restrict__ grad_mu, float* __restrict__ grad_value,
+                                                  float* __restrict__ partial, float* __restrict__ gstd_part) {
+  __shared__ float sh_s[LOSS_ROWS][4];
+  __shared__ float sh_g[LOSS_ROWS][32];
+  const int lane = threadIdx.x & 31, lr = threadIdx.x >> 5;
+  const int row = blockIdx.x * LOSS_ROWS + lr;
+  const bool valid = row < B;
+  const float invB = 1.0f / (float)B;
+  float lp = 0.0f, kl = 0.0f, dmu_c = 0.0f, dsig_c = 0.0f;     // per-lane pieces
+  float sigma = 1.0f;
+  if (valid && lane < A) {
+    sigma = stdp[lane];                                          // Normal(mean, mean*0 + std): sigma is the parameter itself
+    const size_t i = (size_t)row * A + lane;
+    const float m = mu[i], x = actions[i], om = old_mu[i], os = old_sigma[i];
+    const float var = sigma * sigma;
+    const float d = x - m;
+    // torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(sigma) - log(sqrt(2 pi))
+    lp = -(d * d) / (2.0f * var) - logf(sigma) - 0.9189385332046727f;
+    kl = logf(sigma / os + 1.0e-5f) + (os * os + (om - m) * (om - m)) / (2.0f * sigma * sigma) - 0.5f;   // mh_ppo.py:453
+    dmu_c = d / var;                       // d logp / d mu
+    dsig_c = d * d / (var * sigma) - 1.0f / sigma;   // d logp / d sigma
+  }
+  const float logp = gsum32(lp);
+  const float klrow = gsum32(kl);
+  float surr = 0.0f, coef = 0.0f;
+  if (valid) {
+    const float a = adv[row];
+    const float ratio = expf(logp - old_logp[row]);
+    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    const float s1 = -a * ratio, s2 = -a * rc;
+    surr = fmaxf(s1, s2);
+    // d max(s1,s2)/d logp : torch.max splits ties evenly; inside the clip range s2 == s1 and d s2 = d s1
+    const bool inrange = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+    float g;
+    if (s1 > s2) g = -a * ratio;
+    else if (s1 < s2) g = inrange ? -a * ratio : 0.0f;
+    else g = 0.5f * (-a * ratio) + 0.5f * (inrange ? -a * ratio : 0.0f);
+    coef = g * invB;
+  }
+  if (valid && lane < A) grad_mu[(size_t)row * A + lane] = coef * dmu_c;
+  // value loss (summed over heads, mean over rows) and its gradient
+  float vl = 0.0f;
+  if (valid && lane < R) {
+    const size_t i = (size_t)row * R + lane;
+    const float v = value[i], ov = old_values[i], ret = returns[i];
+    float g;
+    if (clipped_value) {
+      const float dv = v - ov;
+      const float dc = fminf(fmaxf(dv, -clip), clip);
+      const float vc = ov + dc;
+      const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+      vl = fmaxf(l1, l2);
+      const float g1 = 2.0f * (v - ret);
+      const float g2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - ret) : 0.0f;
+      g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
+    } else {
+      vl = (ret - v) * (ret - v);
+      g = 2.0f * (v - ret);
+    }
+    grad_value[i] = value_coef * g * invB;
+  }
+  const float vlrow = gsum32(vl);
+  if (lane == 0) { sh_s[lr][0] = valid ? surr : 0.0f; sh_s[lr][1] = valid ? vlrow : 0.0f; sh_s[lr][2] = valid ? klrow : 0.0f; }
+  sh_g[lr][lane] = (valid && lane < A) ? coef * dsig_c : 0.0f;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.0f;
+    for (int r = 0; r < LOSS_ROWS; ++r) s += sh_s[r][threadIdx.x];
+    partial[(size_t)blockIdx.x * LOSS_NP + threadIdx.x] = s;
+  }
+  if (threadIdx.x >= 32 && threadIdx.x < 32 + A) {
+    const int a = threadIdx.x - 32;
+    float s = 0.0f;
+    for (int r = 0; r < LOSS_ROWS; ++r) s += sh_g[r][a];
+    gstd_part[(size_t)blockIdx.x * 32 + a] = s;
+  }
+}
+
+// Fixed-order second stage: loss scalars, d(loss)/d(std) (surrogate part + entropy bonus), and the adaptive-KL
+// learning-rate rule (mh_ppo.py:455-466) on the device.
+#define RED_T 1024
+__global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ partial, const float* __restrict__ gstd_part, const float* __restrict__ stdp,
+                                                      int nblocks, int B, int A, float entropy_coef, float desired_kl, int adapt_lr,
+                                                      float* __restrict__ grad_std, float* __restrict__ scalars, float* __restrict__ lr) {
+  __shared__ double acc[RED_T / 32][33];
+  const int col = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 32 chunks
+  // columns 0..A-1: gstd ; then 3 scalar columns handled by chunk-strided threads with col < 3 on `partial`
+  double s = 0.0;
+  if (col < A)
+    for (int b = chunk; b < nblocks; b += RED_T / 32) s += (double)gstd_part[(size_t)b * 32 + col];
+  acc[chunk][col] = s;
+  __syncthreads();
+  if (threadIdx.x < A) {
+    double t = 0.0;
+    for (int ch = 0; ch < RED_T / 32; ++ch) t += acc[ch][threadIdx.x];
+    // actor_loss = surrogate - entropy_coef * entropy ; entropy = sum_a (0.5 + 0.5 log(2 pi) + log sigma_a)
+    grad_std[threadIdx.x] = (float)t - entropy_coef / stdp[threadIdx.x];
+  }
+  __syncthreads();
+  s = 0.0;
+  if (col < 3)
+    for (int b = chunk; b < nblocks; b += RED_T / 32) s += (double)partial[(size_t)b * LOSS_NP + col];
+  acc[chunk][col] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k)
+      for (int ch = 0; ch < RED_T / 32; ++ch) t[k] += acc[ch][k];
+    float ent = 0.0f;
+    for (int a = 0; a < A; ++a) ent += 0.5f + 0.9189385332046727f + logf(stdp[a]);
+    const float kl_mean = (float)(t[2] / (double)B);
+    scalars[0] = (float)(t[0] / (double)B);      // surrogate loss
+    scalars[1] = (float)(t[1] / (double)B);      // value loss
+    scalars[2] = ent;                            // entropy (mean over rows of identical values)
+    scalars[3] = kl_mean;
+    if (adapt_lr) {
+      for (int k = 0; k < 2; ++k) {
+        float l = lr[k];
+        if (kl_mean > desired_kl * 2.0f) l = fmaxf(1e-5f, l / 1.5f);
+        else if (kl_mean < desired_kl / 2.0f && kl_mean > 0.0f) l = fminf(1e-2f, l * 1.5f);
+        lr[k] = l;
+      }
+    }
+  }
+}
+
+// ---- global-norm clipping + Adam over a flat parameter segment ---------------------------------
+#define ADAM_T 256
+__global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(const float* __restrict__ g, int n, double* __restrict__ part) {
+  __shared__ double sh[ADAM_T];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * ADAM_T + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * ADAM_T) {
+    const float v = g[i];
+    s += (double)v * (double)v;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = ADAM_T / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay), after nn.utils.clip_grad_norm_(max_norm):
+//   clip = min(1, max_norm / (||g|| + 1e-6));  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                                                      const double* __restrict__ part, int nparts, const float* __restrict__ lr, float* __restrict__ step,
+                                                      float max_norm, float b1, float b2, float eps, float* __restrict__ norm_out) {
+  __shared__ float s_clip, s_bc1, s_bc2s, s_lr;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += part[i];
+    const float norm = (float)sqrt(t);
+    const float c = max_norm / (norm + 1e-6f);
+    s_clip = c < 1.0f ? c : 1.0f;
+    const float st = step[0] + 1.0f;                 // every block reads the pre-increment value; block 0 writes it back below
+    s_bc1 = 1.0f - powf(b1, st);
+    s_bc2s = sqrtf(1.0f - powf(b2, st));
+    s_lr = lr[0];
+    if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+  }
+  __syncthreads();
+  const float clipc = s_clip, step_size = s_lr / s_bc1, bc2s = s_bc2s;
+  for (size_t i = (size_t)blockIdx.x * ADAM_T + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * ADAM_T) {
+    const float gi = g[i] * clipc;
+    g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+__global__ void k_step_inc(float* step) { step[0] += 1.0f; }
+
+extern "C" {
+
+int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
+                  const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,
+                  float value_coef, float entropy_coef, int use_clipped_value_loss, float desired_kl, int adapt_lr, float* grad_mu, float* grad_value,
+                  float* grad_std, float* scalars, float* lr, float* scratch, void* stream) {
+  ARG_CHECK(mu && std && value && actions && old_logp && old_mu && old_sigma && adv && returns && old_values);
+  ARG_CHECK(grad_mu && grad_value && grad_std && scalars && lr && scratch);
+  ARG_CHECK(B >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (B + LOSS_ROWS - 1) / LOSS_ROWS;
+  float* partial = scratch;                       // [nb][LOSS_NP]
+  float* gstd_part = scratch + (size_t)nb * LOSS_NP;   // [nb][32]
+  hipLaunchKernelGGL(k_ppo_loss, dim3(nb), dim3(256), 0, st, mu, std, value, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, B, A, R,
+                     clip, value_coef, use_clipped_value_loss, grad_mu, grad_value, partial, gstd_part);
+  hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr, grad_std, scalars, lr);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_ppo_loss_scratch_floats(int B) { return ((B + LOSS_ROWS - 1) / LOSS_ROWS) * (LOSS_NP + 32); }
+
+int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
+                   float beta2, float eps, double* scratch, float* norm_out, void* stream) {
+  ARG_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step && scratch && n >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (n + ADAM_T * 8 - 1) / (ADAM_T * 8);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(nb), dim3(ADAM_T), 0, st, grad, n, scratch);
+  int nb2 = (n + ADAM_T * 4 - 1) / (ADAM_T * 4);
+  if (nb2 > 1024) nb2 = 1024;
+  hipLaunchKernelGGL(k_adam_clip, dim3(nb2), dim3(ADAM_T), 0, st, param, grad, exp_avg, exp_avg_sq, n, scratch, nb, lr, step, max_norm, beta1, beta2, eps, norm_out);
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+}  // extern "C"

@@ -279,10 +279,13 @@ def test_mhppo_update_matches_reference():
     for k in ["Value", "Surrogate", "Entropy"]:
         assert abs(float(loss[k]) - float(g["loss__" + k])) < 2e-4 * max(1.0, abs(float(g["loss__" + k]))), k
     assert abs(float(algo._lr_a) - float(g["lr_actor"])) < 1e-9 and abs(float(algo._lr_c) - float(g["lr_critic"])) < 1e-9
-    for k, v in algo.actor.state_dict().items():
-        close(v, g["actor1__" + k], 5e-5, "actor " + k, rtol=2e-4)
-    for k, v in algo.critic.state_dict().items():
-        close(v, g["critic1__" + k], 5e-5, "critic " + k, rtol=2e-4)
+    # Adam moves a weight by ~lr per step whatever the gradient's size, so an element whose gradient sign is decided by fp32
+    # rounding can drift by a few lr (lr: 1e-3 -> 1e-5 over the 20 steps): elementwise bound 2e-4, whole-tensor bound 1e-4 relative.
+    for name, sd in (("actor", algo.actor.state_dict()), ("critic", algo.critic.state_dict())):
+        for k, v in sd.items():
+            ref = g[f"{name}1__" + k]
+            close(v, ref, 2e-4, f"{name} {k}", rtol=2e-4)
+            assert float((v.cpu() - ref).norm() / ref.norm().clamp(min=1e-6)) < 1e-4, (name, k)
 
 
 def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
