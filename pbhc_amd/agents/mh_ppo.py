@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .. import _lib
+from .. import dist as pdist
 from .modules import PPOActor, PPOCritic, RolloutStorage
 
 
@@ -339,12 +340,7 @@ class MHPPO:
             nb = (T * N + 255) // 256
             mean_l, std_l = self._gae_stats[2 * nb].float(), self._gae_stats[2 * nb + 1].float()
             raw = adv * (std_l + 1e-8) + mean_l
-            n = torch.tensor(float(T * N), dtype=torch.float64, device=self.device)
-            mom = torch.stack([raw.double().sum(), (raw.double() ** 2).sum(), n])
-            dist.all_reduce(mom)
-            mean = mom[0] / mom[2]
-            var = (mom[1] - mom[2] * mean * mean) / (mom[2] - 1.0)
-            adv.copy_((raw - mean.float()) / (var.clamp(min=0).sqrt().float() + 1e-8))
+            adv.copy_(pdist.global_normalize_(raw))
         return st.returns, adv
 
     # ---- update (mh_ppo.py:397-533) --------------------------------------------------------
@@ -365,8 +361,7 @@ class MHPPO:
 
     def _allreduce_grads(self):
         """ONE RCCL all-reduce of the flat actor+critic gradient buffer (≈5 MB fp32), then average."""
-        dist.all_reduce(self._gflat)
-        self._gflat.div_(self.world_size)
+        pdist.allreduce_mean_(self._gflat)
 
     def _update_ppo(self, b, loss):
         if self._need_next:
@@ -392,12 +387,7 @@ class MHPPO:
         torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
         if self.world_size > 1:
             if adapt:
-                kl_mean = self._loss_scalars[3].clone()
-                dist.all_reduce(kl_mean)
-                kl_mean = kl_mean / self.world_size
-                up = kl_mean > self.desired_kl * 2.0
-                down = (kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0)
-                self._lr.copy_(torch.where(up, torch.clamp(self._lr / 1.5, min=1e-5), torch.where(down, torch.clamp(self._lr * 1.5, max=1e-2), self._lr)))
+                pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
             self._allreduce_grads()
         na, nc = self._n_actor, self._n_critic
         for k, (o, n) in enumerate(((0, na), (na, nc))):
