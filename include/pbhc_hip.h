@@ -225,10 +225,15 @@ typedef struct PbhcMotionTable {
 typedef struct PbhcStepIO {
   /* inputs */
   const float* actions_in;        /* [N,D]   policy actions                                    */
-  const float* frame_root;        /* [N,13]  replay frame the sim switches to this step       */
-  const float* frame_dof_pos;     /* [N,D]                                                     */
-  const float* frame_dof_vel;     /* [N,D]                                                     */
-  const float* frame_contact;     /* [N,B,3] net contact forces                                */
+  /* replay window of the sim-stub: frame k = frame_cursor[0] % num_frames lands this step; the cursor lives on the device and is
+   * advanced by the step itself (pointer bump without a host round trip, so a rollout can be captured in a hipGraph). */
+  const float* frame_root;        /* [T,N,13]                                                  */
+  const float* frame_dof_pos;     /* [T,N,D]                                                   */
+  const float* frame_dof_vel;     /* [T,N,D]                                                   */
+  const float* frame_contact;     /* [T,N,B,3] net contact forces                              */
+  int32_t* frame_cursor;          /* device int32[1]                                           */
+  int32_t num_frames;             /* T                                                         */
+  int32_t pad0_;
   /* optional injected random draws (NULL -> in-kernel Philox) */
   const float* u_rfi;             /* [N,D] uniforms of the torque RFI noise                    */
   const float* ovr_start_time;    /* [N]   values consumed by resetting envs                   */
@@ -298,6 +303,18 @@ int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
 #define PBHC_PROFILE_RING 512
 int pbhc_env_profile(PbhcEnv* env, int enable);
 int pbhc_env_profile_read(PbhcEnv* env, float* ms_out, int max_count, int* count);
+
+/* Rollout-side fusions of MHPPO._rollout_step (mh_ppo.py:270-342).
+ * pbhc_policy_sample: a ~ Normal(mu, std) (Philox keyed by seed / counter[0] / env), log-prob, and the writes of one rollout-buffer
+ * step: actions, action_mean, action_sigma [N,A], actions_log_prob [N], values [N,R] (copied from `value`).
+ * counter: device double, read (not advanced) — pass the env globals' step counter. */
+int pbhc_policy_sample(const float* mu, const float* std, const float* value, int N, int A, int R, uint64_t seed, const double* counter,
+                       float* actions, float* action_mean, float* action_sigma, float* logp, float* values_out, void* stream);
+/* pbhc_rollout_post: rewards_stored = rew + gamma * values * time_out (bootstrap, :300-305), dones = reset_buf != 0, and the
+ * episode book-keeping (:311-323) kept on the device: cur_reward_sum/cur_episode_length [N], ep_stats double[3] +=
+ * (sum of finished returns, sum of finished lengths, count). */
+int pbhc_rollout_post(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
+                      float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, void* stream);
 
 /* GAE + returns + normalised advantages.  Replaces MHPPO._compute_returns (mh_ppo.py:348-395).
  * rewards/values/returns [T,N,R], dones [T,N] bool, last_values [N,R], advantages [T,N].

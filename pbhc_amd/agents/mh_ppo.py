@@ -212,6 +212,10 @@ class MHPPO:
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
+        self._last_obs = {k: torch.zeros(N, d, device=self.device) for k, d in self.algo_obs_dim_dict.items()}
+        self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
+        if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
+            raise _lib.PbhcError("pbhc_amd MHPPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
         mb = (T * N) // self.num_mini_batches
         self._mb = mb
         self._loss_scratch = torch.zeros(_lib.lib().pbhc_ppo_loss_scratch_floats(mb), device=self.device)
@@ -288,43 +292,39 @@ class MHPPO:
         return self.critic.evaluate(obs_dict["critic_obs"])
 
     def _rollout_step(self, obs_dict):
-        st = self.storage
+        """mh_ppo.py:270-342.  Per control step: actor + critic forward (GEMMs), ONE sample/log-prob/buffer-write kernel, the fused
+        env step — which writes the next observations straight into the next rollout-buffer slab — and ONE bootstrap /
+        done / episode-statistics kernel.  No host synchronisation."""
+        st, env, lib = self.storage, self.env, _lib.lib()
+        T, N, A, R = self.num_steps_per_env, env.num_envs, self.num_act, self.num_rew_fn
+        keys = list(obs_dict.keys())
+        K = _lib.K
+        counter = env.globals[K["PBHC_G_STEP_COUNTER"]:].data_ptr()
+        std = self.actor.std
+        stream = _lib.current_stream()
         with torch.inference_mode():
-            for _ in range(self.num_steps_per_env):
-                actions = self._actor_act_step(obs_dict)
-                values = self._critic_eval_step(obs_dict)
-                for k in obs_dict:
-                    st.update_key(k, obs_dict[k])
-                st.update_key("actions", actions)
-                st.update_key("action_mean", self.actor.action_mean)
-                st.update_key("action_sigma", self.actor.action_std)
-                st.update_key("actions_log_prob", self.actor.get_actions_log_prob(actions).unsqueeze(1))
-                st.update_key("values", values)
-                obs_dict, rewards, dones, infos = self.env.step({"actions": actions})
+            for k in keys:
+                getattr(st, k)[0].copy_(obs_dict[k])
+            for t in range(T):
+                mu = self.actor.actor_module(getattr(st, "actor_obs")[t])
+                value = self.critic.critic_module(getattr(st, "critic_obs")[t])
+                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
+                                                  st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
+                                                  st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
+                env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
+                nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
                 if self._need_next:
-                    for k in obs_dict:
-                        st.update_key("next_" + k, obs_dict[k])
-                rew = rewards.reshape(self.env.num_envs, self.num_rew_fn)
-                # bootstrap on time-outs (mh_ppo.py:300-305)
-                stored = rew + self.gamma * values * infos["time_outs"].unsqueeze(1)
-                st.update_key("rewards", stored)
-                st.update_key("dones", dones.unsqueeze(1))
-                st.increment_step()
-                # episode book-keeping on the device (reference: per-step .cpu() round trip, :311-323)
-                self.cur_reward_sum += rew.sum(dim=-1)
-                self.cur_episode_length += 1
-                done_f = (dones > 0).to(torch.float64)
-                self._ep_stats[0] += (self.cur_reward_sum.double() * done_f).sum()
-                self._ep_stats[1] += (self.cur_episode_length.double() * done_f).sum()
-                self._ep_stats[2] += done_f.sum()
-                keep = (dones == 0).float()
-                self.cur_reward_sum *= keep
-                self.cur_episode_length *= keep
+                    for k in keys:
+                        getattr(st, "next_" + k)[t].copy_(nxt[k])
+                _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                 float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                 self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+            st.step = T
             self.stop_time = time.time()
             self.collection_time = self.stop_time - self.start_time
             self.start_time = self.stop_time
-            self._compute_returns(obs_dict)
-        return obs_dict
+            self._compute_returns(self._last_obs)
+        return self._last_obs
 
     def _compute_returns(self, last_obs_dict):
         """mh_ppo.py:348-395 in one HIP pass over the [T,N,R] slab."""

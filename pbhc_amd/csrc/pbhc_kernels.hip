@@ -230,7 +230,7 @@ extern __shared__ float smem[];
 
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
-                                                              int lds_stride, uint32_t step_ctr) {
+                                                              int lds_stride) {
   const PbhcEnvConfig& c = *cfgp;
   const PbhcSkeleton& sk = c.skel;
   const int N = c.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
@@ -243,6 +243,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float *bp = S + Lds::BP, *bq = S + Lds::BQ, *bv = S + Lds::BV, *bw = S + Lds::BW;
   float *rp = S + Lds::RP, *rq = S + Lds::RQ, *rv = S + Lds::RV, *rw = S + Lds::RW;
   float *red = S + Lds::RED, *feat = S + Lds::FEAT;
+  const size_t fk = (size_t)(io.frame_cursor[0] % io.num_frames) * (size_t)N;   // replay frame of this step (device-side cursor)
+  const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
   float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
   const float dt = c.dt;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
       const float qp = io.dof_state[(eD + d) * 2], qv = io.dof_state[(eD + d) * 2 + 1];
       const float kp = io.kp_scale[eD + d], kd = io.kd_scale[eD + d], rfs = io.rfi_lim_scale[eD + d], ras = io.rao_scale[eD + d];
-      const float fq = io.frame_dof_pos[eD + d], fqd = io.frame_dof_vel[eD + d];
+      const float fq = io.frame_dof_pos[fk * D + eD + d], fqd = io.frame_dof_vel[fk * D + eD + d];
       const float u = c.randomize_torque_rfi ? (io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(c.seed, env, step_ctr, 1, d)) : 0.5f;
       const float tl = c.torque_limits[d];
       const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       q[d] = fq;
       qd[d] = fqd;
     }
-    if (lane < 13) root[lane] = io.frame_root[(size_t)env * 13 + lane];
-    copy_g2l(cf, io.frame_contact + (size_t)env * B * 3, B * 3, lane);
+    if (lane < 13) root[lane] = io.frame_root[(fk + env) * 13 + lane];
+    copy_g2l(cf, io.frame_contact + (fk + env) * (size_t)(B * 3), B * 3, lane);
     if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = io.dr_base_com[(size_t)env * 3 + lane];
     copy_g2l(feat + c.feat_off[PBHC_F_DR_LINK_MASS], io.dr_link_mass + (size_t)env * c.dr_link_mass_dim, c.dr_link_mass_dim, lane);
     if (lane == 0) {
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
 //  k_env_finalize: the scalars the reference updates on the host each step
 // =================================================================================================
 #define PBHC_FIN_CHUNKS 16
-__global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks) {
+__global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks, int32_t* frame_cursor, int num_frames) {
   __shared__ double acc[PBHC_FIN_CHUNKS][64];
   __shared__ double tot[PBHC_NP];
   const PbhcEnvConfig& c = *cfgp;
@@ -883,6 +885,7 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
     }
   }
   glob[PBHC_G_STEP_COUNTER] += 1.0;
+  frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
 }
 
 // =================================================================================================
@@ -1256,7 +1259,7 @@ int pbhc_env_profile_read(PbhcEnv* e, float* ms_out, int max_count, int* count) 
 
 int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(e && io);
-  ARG_CHECK(io->actions_in && io->frame_root && io->frame_dof_pos && io->frame_dof_vel && io->frame_contact);
+  ARG_CHECK(io->actions_in && io->frame_root && io->frame_dof_pos && io->frame_dof_vel && io->frame_contact && io->frame_cursor && io->num_frames >= 1);
   ARG_CHECK(io->root_states && io->dof_state && io->actions && io->last_actions && io->actions_after_delay && io->action_queue);
   ARG_CHECK(io->last_dof_pos && io->last_dof_vel && io->torques && io->feet_air_time && io->contacts && io->contacts_filt);
   ARG_CHECK(io->last_contacts && io->last_contacts_filt && io->kp_scale && io->kd_scale && io->rfi_lim_scale && io->rao_scale);
@@ -1268,9 +1271,9 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   const int slot = e->prof_count % PBHC_PROFILE_RING;
   if (e->profile) HIP_CHECK(hipEventRecord(e->ev0[slot], st));
   hipLaunchKernelGGL(k_env_step, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials,
-                     e->lds_stride, e->step_ctr);
+                     e->lds_stride);
   if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
-  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames);
   e->step_ctr++;
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;

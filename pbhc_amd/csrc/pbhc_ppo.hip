@@ -218,7 +218,85 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
 }
 __global__ void k_step_inc(float* step) { step[0] += 1.0f; }
 
+// ---- rollout-side fusions (mh_ppo.py:270-342) ------------------------------------------------------
+#include "pbhc_math.h"
+__global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__ mu, const float* __restrict__ stdp, const float* __restrict__ value, int N, int A,
+                                                       int R, uint64_t seed, const double* __restrict__ counter, float* __restrict__ actions,
+                                                       float* __restrict__ action_mean, float* __restrict__ action_sigma, float* __restrict__ logp,
+                                                       float* __restrict__ values_out) {
+  const int lane = threadIdx.x & 31, row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool valid = row < N;
+  const uint32_t ctr = (uint32_t)counter[0];
+  float lp = 0.0f;
+  if (valid && lane < A) {
+    const size_t i = (size_t)row * A + lane;
+    const float m = mu[i], sg = stdp[lane];
+    uint32_t o[4];
+    pbhc::philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)row, ctr, 0x5A4Du, (uint32_t)lane, o);
+    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);           // Box-Muller
+    const float a = m + sg * z;
+    actions[i] = a; action_mean[i] = m; action_sigma[i] = sg;
+    const float d = a - m;
+    lp = -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
+  }
+  lp = gsum32(lp);
+  if (valid && lane == 0) logp[row] = lp;
+  if (valid && lane < R) values_out[(size_t)row * R + lane] = value[(size_t)row * R + lane];
+}
+
+__global__ __launch_bounds__(256) void k_rollout_post(const float* __restrict__ rew, const float* __restrict__ values, const int64_t* __restrict__ reset_buf,
+                                                      const uint8_t* __restrict__ time_outs, int N, int R, float gamma, float* __restrict__ rewards_out,
+                                                      uint8_t* __restrict__ dones_out, float* __restrict__ cur_rew, float* __restrict__ cur_len,
+                                                      double* __restrict__ ep_stats) {
+  __shared__ double sh[3][8];
+  const int lane = threadIdx.x & 31, lr = threadIdx.x >> 5, row = blockIdx.x * 8 + lr;
+  const bool valid = row < N;
+  float r = 0.0f;
+  const float to = valid ? (time_outs[row] ? 1.0f : 0.0f) : 0.0f;
+  if (valid && lane < R) {
+    const size_t i = (size_t)row * R + lane;
+    r = rew[i];
+    rewards_out[i] = r + gamma * values[i] * to;
+  }
+  const float rsum = gsum32(r);
+  double a = 0.0, b = 0.0, c = 0.0;
+  if (valid && lane == 0) {
+    const bool done = reset_buf[row] > 0;
+    dones_out[row] = done ? 1 : 0;
+    const float cr = cur_rew[row] + rsum, cl = cur_len[row] + 1.0f;
+    if (done) { a = (double)cr; b = (double)cl; c = 1.0; }
+    cur_rew[row] = done ? 0.0f : cr;
+    cur_len[row] = done ? 0.0f : cl;
+  }
+  if (lane == 0) { sh[0][lr] = a; sh[1][lr] = b; sh[2][lr] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int k = 0; k < 8; ++k) t += sh[threadIdx.x][k];
+    if (t != 0.0) atomicAdd(&ep_stats[threadIdx.x], t);        // logging statistics only
+  }
+}
+
 extern "C" {
+
+int pbhc_policy_sample(const float* mu, const float* std, const float* value, int N, int A, int R, uint64_t seed, const double* counter,
+                       float* actions, float* action_mean, float* action_sigma, float* logp, float* values_out, void* stream) {
+  ARG_CHECK(mu && std && value && counter && actions && action_mean && action_sigma && logp && values_out && N >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
+  hipLaunchKernelGGL(k_policy_sample, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, mu, std, value, N, A, R, seed, counter, actions, action_mean,
+                     action_sigma, logp, values_out);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_rollout_post(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
+                      float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, void* stream) {
+  ARG_CHECK(rew && values && reset_buf && time_outs && rewards_out && dones_out && cur_reward_sum && cur_episode_length && ep_stats && N >= 1 && R >= 1 && R <= 32);
+  hipLaunchKernelGGL(k_rollout_post, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, rew, values, reset_buf, time_outs, N, R, gamma, rewards_out, dones_out,
+                     cur_reward_sum, cur_episode_length, ep_stats);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
 
 int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
                   const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,

@@ -144,7 +144,8 @@ class LeggedRobotMotionTracking:
         self.time_out_buf = torch.zeros(N, dtype=torch.bool, device=dev)
         self.motion_ids = torch.arange(N, device=dev)
         self.rew_buf = f(N, L.num_rew_fn) if self.config.use_vec_reward else f(N)
-        self.obs_buf_dict = {g: f(N, L.group_dims[g]) for g in L.group_names[:-1]}
+        self._own_obs = {g: f(N, L.group_dims[g]) for g in L.group_names[:-1]}
+        self.obs_buf_dict = dict(self._own_obs)
         Bx = self.skeleton.num_bodies_ext
         self.ref_body_pos_extend, self.ref_body_rot_extend = f(N, Bx, 3), f(N, Bx, 4)
         self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(D)], device=dev).repeat(N, 1)
@@ -199,6 +200,16 @@ class LeggedRobotMotionTracking:
         io.episode_rew_out = p(self._episode_rew_out)
         self._io = io
         self._overrides = {}
+        self._replay_version = -1
+
+    def set_obs_outputs(self, tensors):
+        """Point the observation outputs of the next step(s) at caller-owned `[N, dim]` tensors (e.g. the rollout-buffer slab of
+        the next step) instead of the env-owned ones; `None` restores the env-owned buffers."""
+        L = self.layout
+        for i, g in enumerate(L.group_names[:-1]):
+            t = self._own_obs[g] if tensors is None else _lib.require_gpu_tensor(tensors[g], g, torch.float32, (self.num_envs, L.group_dims[g]))
+            self.obs_buf_dict[g] = t
+            self._io.obs[i] = t.data_ptr()
 
     # ---- test / replay hooks: inject the random draws instead of the in-kernel Philox ---------
     def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None):
@@ -286,14 +297,15 @@ class LeggedRobotMotionTracking:
             raise _lib.PbhcError(f"actions must be [{self.num_envs},{self.num_dof}], got {tuple(actions.shape)}")
         self._actions_in = actions
         s = self.simulator
-        k = s.next_frame_index()
-        r = s.replay
         io = self._io
         io.actions_in = actions.data_ptr()
-        io.frame_root = r["root"][k].data_ptr()
-        io.frame_dof_pos = r["dof_pos"][k].data_ptr()
-        io.frame_dof_vel = r["dof_vel"][k].data_ptr()
-        io.frame_contact = r["contact"][k].data_ptr()
+        if self._replay_version != s.replay_version or s.replay is None:
+            s.ensure_replay()
+            r = s.replay
+            io.frame_root, io.frame_dof_pos = r["root"].data_ptr(), r["dof_pos"].data_ptr()
+            io.frame_dof_vel, io.frame_contact = r["dof_vel"].data_ptr(), r["contact"].data_ptr()
+            io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
+            self._replay_version = s.replay_version
         _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
         self.common_step_counter += 1
         self.extras["time_outs"] = self.time_out_buf

@@ -36,6 +36,8 @@ class ReplaySimStub:
         self._substep = 0
         self._frame = 0
         self.replay = None
+        self.replay_version = 0
+        self.frame_cursor = torch.zeros(1, dtype=torch.int32, device=self.device)     # device-side cursor, advanced by the step kernel
 
     # ---- bring-up ------------------------------------------------------------------------
     def set_headless(self, headless):
@@ -131,16 +133,23 @@ class ReplaySimStub:
                            dof_vel=chk(dof_vel, "dof_vel", torch.float32, (T, N, D)), contact=chk(contact, "contact", torch.float32, (T, N, B, 3)))
         self.replay_len = T
         self._frame = start_frame
+        self.frame_cursor.fill_(start_frame % T)
+        self.replay_version += 1
 
-    def next_frame_index(self):
-        """Index of the frame the next control step lands on; advances the cursor (pointer bump)."""
+    def ensure_replay(self):
         if self.replay is None:
             # nothing to replay yet (e.g. the reset_all() inside MHPPO.__init__): hold the current state
             self.replay = dict(root=self.robot_root_states.clone()[None], dof_pos=self.dof_pos.clone()[None].contiguous(),
                                dof_vel=self.dof_vel.clone()[None].contiguous(), contact=self.contact_forces.clone()[None])
             self.replay_len = 1
-        k = self._frame % self.replay_len
-        self._frame += 1
+            self.frame_cursor.zero_()
+            self.replay_version += 1
+
+    def next_frame_index(self):
+        """Host-side stepping (reference-style `simulate` loop only): frame index, cursor advanced on both sides."""
+        self.ensure_replay()
+        k = int(self.frame_cursor.item())
+        self.frame_cursor.copy_((self.frame_cursor + 1) % self.replay_len)
         return k
 
     def refresh_sim_tensors(self):

@@ -317,3 +317,52 @@ def test_learn_runs_two_iterations():
         assert torch.isfinite(p).all()
     log = env.read_log()
     assert np.isfinite(log["reward_mean"])
+
+
+def test_policy_sample_and_rollout_post():
+    """pbhc_policy_sample: log-prob equals torch.distributions.Normal on the sampled action, samples are N(mu, std);
+    pbhc_rollout_post: time-out bootstrap, dones and the device-side episode book-keeping (mh_ppo.py:300-323)."""
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    N, A, R = 4096, 23, 21
+    g = torch.Generator(device=DEV).manual_seed(0)
+    mu = torch.randn(N, A, device=DEV, generator=g)
+    std = 0.2 + torch.rand(A, device=DEV, generator=g)
+    value = torch.randn(N, R, device=DEV, generator=g)
+    counter = torch.tensor([7.0], dtype=torch.float64, device=DEV)
+    act, am, asg = torch.zeros(N, A, device=DEV), torch.zeros(N, A, device=DEV), torch.zeros(N, A, device=DEV)
+    lp, vout = torch.zeros(N, device=DEV), torch.zeros(N, R, device=DEV)
+    st = _lib.current_stream()
+    _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), value.data_ptr(), N, A, R, 1234, counter.data_ptr(), act.data_ptr(), am.data_ptr(),
+                                      asg.data_ptr(), lp.data_ptr(), vout.data_ptr(), st))
+    torch.cuda.synchronize()
+    ref_lp = torch.distributions.Normal(mu, mu * 0 + std).log_prob(act).sum(-1)
+    close(lp, ref_lp, 2e-4, "logp", rtol=1e-5)
+    assert torch.equal(am, mu) and torch.equal(vout, value) and torch.equal(asg, std.expand(N, A))
+    z = (act - mu) / std
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01 and abs(float((z ** 4).mean()) - 3.0) < 0.1
+    act2 = torch.zeros_like(act)
+    counter.fill_(8.0)
+    _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), value.data_ptr(), N, A, R, 1234, counter.data_ptr(), act2.data_ptr(), am.data_ptr(),
+                                      asg.data_ptr(), lp.data_ptr(), vout.data_ptr(), st))
+    assert float((act2 - act).abs().mean()) > 0.1                      # a new counter gives new draws
+    # rollout_post
+    rew = torch.randn(N, R, device=DEV, generator=g)
+    reset = (torch.rand(N, device=DEV, generator=g) < 0.1).long()
+    tout = ((torch.rand(N, device=DEV, generator=g) < 0.5) & (reset > 0))
+    cur_r, cur_l = torch.rand(N, device=DEV, generator=g), torch.randint(0, 50, (N,), device=DEV, generator=g).float()
+    cr0, cl0 = cur_r.clone(), cur_l.clone()
+    out_r = torch.zeros(N, R, device=DEV); dones = torch.zeros(N, 1, dtype=torch.bool, device=DEV)
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    _lib.check(lib.pbhc_rollout_post(rew.data_ptr(), value.data_ptr(), reset.data_ptr(), tout.data_ptr(), N, R, 0.99, out_r.data_ptr(), dones.data_ptr(),
+                                     cur_r.data_ptr(), cur_l.data_ptr(), stats.data_ptr(), st))
+    torch.cuda.synchronize()
+    close(out_r, rew + 0.99 * value * tout.unsqueeze(1), 1e-6, "bootstrap")
+    assert torch.equal(dones[:, 0], reset > 0)
+    nr, nl = cr0 + rew.sum(-1), cl0 + 1
+    d = reset > 0
+    close(cur_r, torch.where(d, torch.zeros_like(nr), nr), 1e-5, "cur_reward_sum")
+    close(cur_l, torch.where(d, torch.zeros_like(nl), nl), 0, "cur_episode_length")
+    ref = torch.stack([nr[d].double().sum(), nl[d].double().sum(), d.double().sum()])
+    assert torch.allclose(stats, ref, rtol=1e-6)
