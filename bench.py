@@ -97,8 +97,25 @@ def build(num_envs, device, seed):
     return cfg, env, MHPPO
 
 
-def cpu_baseline(num_envs_sample=2048):
-    """The oracle ('port') timed on the host cores: one full PPO iteration at `num_envs_sample` envs."""
+def pmc_traffic_bytes():
+    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC passes (profiles/round1_k_env_step_pmc_*.csv, collected
+    in separate --pmc runs of tools/kernel_probe.py on the same 4096-env workload): FETCH_SIZE and WRITE_SIZE are in KiB; on
+    gfx950 FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md §HBM; calibrated there for 16 B/lane, ours are
+    4 B/lane, so the read side is an estimate).  None if the files are absent."""
+    import csv
+    import statistics
+
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(ROOT, "profiles", f"round1_k_env_step_pmc_{name}.csv")
+        if not os.path.exists(f):
+            return None
+        vals[name] = statistics.median(float(r["Counter_Value"]) for r in csv.DictReader(open(f)))
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def cpu_baseline(num_envs_sample=4096, iterations=2):
+    """The oracle ('port') timed on the host cores: full PPO iterations at `num_envs_sample` envs."""
     from oracle.cpu_loop import run_iteration
     from tests.helpers import clip_from_env_golden, fixture_config, load_env_golden, skel_from_golden
 
@@ -106,10 +123,11 @@ def cpu_baseline(num_envs_sample=2048):
     cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     cfg = fixture_config(WORKLOAD_CFG, num_envs_sample)
-    r = run_iteration(cfg, skel_from_golden(), clip_from_env_golden(load_env_golden("walk")), num_envs_sample)
-    return {"value": r["env_steps"] / r["seconds"], "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 PPO iteration (24 steps + GAE + 5x4 minibatch updates) of {num_envs_sample} envs on the CPU oracle, "
-                      f"{r['seconds']:.1f} s (rollout {r['rollout_s']:.1f} s, update {r['update_s']:.1f} s)"}
+    rs = [run_iteration(cfg, skel_from_golden(), clip_from_env_golden(load_env_golden("walk")), num_envs_sample, seed=i) for i in range(iterations)]
+    steps, secs = sum(r["env_steps"] for r in rs), sum(r["seconds"] for r in rs)
+    return {"value": steps / secs, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{iterations} PPO iterations (24 steps + GAE + 5x4 minibatch updates) of {num_envs_sample} envs on the CPU oracle, "
+                      f"{secs:.1f} s (rollout {sum(r['rollout_s'] for r in rs):.1f} s, update {sum(r['update_s'] for r in rs):.1f} s)"}
 
 
 def main():
@@ -189,7 +207,7 @@ def main():
                        "envs_per_gpu": N, "global_envs": N * world, "num_steps_per_env": T, "parallelism": f"dp{world}"},
             "rollout_ms": rollout_ms, "update_ms": update_ms,
             "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_ms, "launches_timed": cnt.value,
+                         "traffic": pmc_traffic_bytes() if N == 4096 else None, "kernel_ms": kern_ms, "launches_timed": cnt.value,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -135,13 +135,20 @@ enum PbhcLog {
  *  legged_robot_base.py:787-793 + clip :326-328; group PBHC_MAX_GROUPS-1 is conventionally the
  *  history write-back, history_handler.py:40-44, not clipped) */
 typedef struct PbhcOutMap {
-  int32_t dim;
+  int32_t dim;               /* number of elements this map writes */
   int32_t clip;              /* 1: clip to +-clip_observations */
+  int32_t pitch;             /* floats per env row of the output tensor */
+  int32_t pad_;
+  const int32_t* dst;        /* device [dim] position inside the row, or NULL = identity */
   const int32_t* src;        /* device [dim] index into the feature row */
   const float* scale;        /* device [dim] */
   const float* noise;        /* device [dim] noise scale (0 = none) */
 } PbhcOutMap;
 
+/* ---- early history scatter.  Old history (HistoryHandler buffers, history_handler.py:10-48) feeds the outputs unchanged
+ * (scale 1, no noise): element i of the packed history row goes to position p_g(i) of output group g — the history_* slices
+ * of the observation groups and, shifted by one step, the history write-back.  hist_pack[i*words + w] packs, `bits` bits per
+ * group, the values p_g(i)+1 (0 = group g does not carry element i), group g in word g / (32/bits), field g % (32/bits). --- */
 /* ---- static configuration of the v1 env (LeggedRobotMotionTracking) ------------------------
  * Filled by the host from the reference's YAML config tree (same keys); copied to the device by
  * pbhc_env_create. */
@@ -202,6 +209,9 @@ typedef struct PbhcEnvConfig {
   int32_t hist_dim;                          /* floats of history state per env */
   int32_t num_groups;
   PbhcOutMap groups[PBHC_MAX_GROUPS];
+  int32_t hist_pack_bits;                    /* 0: no early history scatter (everything goes through the maps); else 10 or 16 */
+  int32_t hist_pack_words;
+  const int32_t* hist_pack;                  /* device [hist_dim * hist_pack_words] */
   int32_t has_contact_mask;
   float ref_init_yaw;
   int32_t dr_link_mass_dim;
@@ -219,6 +229,9 @@ typedef struct PbhcMotionTable {
   const int32_t* num_frames;    /* device [M]                           */
   const float* motion_dt;       /* device [M] 1/fps                     */
   const float* motion_len;      /* device [M] (F-1)/fps                 */
+  /* when num_motions == 1 the clip's meta also travels by value (saves a dependent load in the step kernel) */
+  int32_t single_num_frames;
+  float single_dt, single_len;
 } PbhcMotionTable;
 
 /* ---- per-step tensors of the fused env step ------------------------------------------------ */

@@ -17,6 +17,10 @@
 
 using namespace pbhc;
 
+#ifdef PBHC_STATIC_CFG
+#include PBHC_STATIC_CFG
+#endif
+
 #define PBHC_G 32     // lanes per env
 #define PBHC_EPB 4    // envs per workgroup
 #define PBHC_NP 48    // partial sums per workgroup
@@ -89,6 +93,11 @@ enum {
   M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ
 };
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
+// flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
+// data through LDS only; same-address global accesses stay inside one wave, where program order holds.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
@@ -113,6 +122,21 @@ __device__ __forceinline__ void copy_g2l(float* dst, const float* __restrict__ s
     for (int u = 0; u < 8; ++u) { const int i = i0 + u * PBHC_G; v[u] = i < n ? src[i] : 0.0f; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const int i = i0 + u * PBHC_G; if (i < n) dst[i] = v[u]; }
+  }
+}
+
+// Old-history element of one env -> every output row that carries it unchanged (see hist_pack in pbhc_hip.h): observation
+// groups (clipped) and the one-step-shifted history write-back.  The reset path rewrites those positions with zeros.
+__device__ __forceinline__ void hist_scatter(const PbhcEnvConfig& c, const PbhcStepIO& io, int env, const int* words, float v) {
+  const int bits = c.hist_pack_bits, per = 32 / bits;
+  const unsigned mask = (1u << bits) - 1u;
+  for (int g = 0; g < c.num_groups; ++g) {
+    const unsigned f = ((unsigned)words[g / per] >> (bits * (g % per))) & mask;
+    if (f) {
+      float x = v;
+      if (c.groups[g].clip) x = clampf(x, -c.clip_observations, c.clip_observations);
+      io.obs[g][(size_t)env * c.groups[g].pitch + (f - 1)] = x;
+    }
   }
 }
 
@@ -156,7 +180,7 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
       f3 axis = ld3(k + 7);
       st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_axis(q[b - 1], axis)));
     }
-  __syncthreads();
+  LDS_BARRIER();
   if (valid)
     for (int b = lane; b < Bx; b += PBHC_G) {
       const float* kb = skc + b * SKC_W;
@@ -183,7 +207,7 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
       }
       st3(bp + 3 * b, p); st4(bq + 4 * b, r); st3(bv + 3 * b, v); st3(bw + 3 * b, w);
     }
-  __syncthreads();
+  LDS_BARRIER();
 }
 
 // ---- frame blend (motion_lib_base.py:503-513) -------------------------------------------------
@@ -231,9 +255,16 @@ extern __shared__ float smem[];
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride) {
-  const PbhcEnvConfig& c = *cfgp;
+  // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
+  // whose scalars fold into the instruction stream; pointers, seed, env count and reference yaw always come from `rt`.
+  const PbhcEnvConfig& rt = *cfgp;
+#ifdef PBHC_STATIC_CFG
+  const PbhcEnvConfig& c = kStaticCfg;
+#else
+  const PbhcEnvConfig& c = rt;
+#endif
   const PbhcSkeleton& sk = c.skel;
-  const int N = c.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
+  const int N = rt.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
   const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G;
   const int env = blockIdx.x * PBHC_EPB + le;
   const bool valid = env < N;
@@ -249,11 +280,15 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
   const float dt = c.dt;
   const size_t eD = (size_t)env * D;
+  STAMP(0);
   stage_skeleton(sk, skc);
 
-  // ---------------- prologue: every load that does not depend on this step's compute is issued here, into
-  // registers, so that the kernel pays ONE global round trip up front (plus the dependent reference rows,
-  // whose latency hides behind the FK chain).  All lanes of an env compute the frame address redundantly.
+  // ---------------- prologue + phase A: every global load that does not depend on this step's compute is ISSUED here,
+  // in the order it is needed (frame q / q-dot / root first: the FK chain waits only for them; the history, the per-dof
+  // state and the reference rows stay in flight behind the chain).  _pre_physics_step (motion_tracking.py:749-768) and the
+  // torques from the pre-step state (legged_robot_base.py:795-838) are computed when their operands land.
+  // All lanes of an env compute the reference-frame address redundantly (no LDS round trip).
+#define PBHC_HREG 12                                    // history words per lane held in registers (hist_dim <= 384)
   long long ep1 = 0;
   float start = 0.0f, mlen_env = 0.0f, tref = 0.0f, blend = 0.0f;
   int mid = 0;
@@ -261,26 +296,90 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   f3 rp0 = mk3(0, 0, 0), rp1 = rp0, rv0 = rp0, rv1 = rp0, rw0 = rp0, rw1 = rp0;
   f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
   float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
-  float pf_last_act = 0, pf_last_qd = 0, pf_sum = 0, pf_tscale = 0;
+  float pf_last_act = 0, pf_last_qd = 0, pf_sum = 0, pf_tscale = 0, pf_sigma = 1.0f, pf_termsum = 0;
   int pf_tid = 0, pf_tpen = 0, pf_tcol = 0;
+  const float pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE], pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
+  const float pf_soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], pf_soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], pf_soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
+  const float pf_noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
   const float* r0 = nullptr;
   const float* r1 = nullptr;
+  float clipcnt = 0.0f;
+  const int hoff = c.feat_off[PBHC_F_HISTORY];
+  const int Q = c.queue_len;
   if (valid) {
+    const int d = lane;                       // D <= 32: one dof per lane
+    // (1) what the FK chain needs
+    float fq = 0, fqd = 0, froot = 0;
+    if (d < D) { fq = io.frame_dof_pos[fk * D + eD + d]; fqd = io.frame_dof_vel[fk * D + eD + d]; }
+    if (lane < 13) froot = io.frame_root[(fk + env) * 13 + lane];
+    // (2) env scalars -> reference-frame address
     ep1 = io.episode_length_buf[env] + 1;
     start = io.motion_start_times[env];
     mlen_env = io.motion_len[env];
     mid = (int)io.motion_ids[env];
     origin = ld3(io.env_origins + (size_t)env * 3);
-    if (lane < D) { pf_last_act = io.last_actions[eD + lane]; pf_last_qd = io.last_dof_vel[eD + lane]; }
+    // (3) everything else of this step, into registers
+    float hreg[PBHC_HREG];
+    int hpk[PBHC_HREG][2];
+    {
+      const float* __restrict__ hsrc = io.hist + (size_t)env * c.hist_dim;
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) {
+        const int i = lane + u * PBHC_G;
+        const bool ok = i < c.hist_dim;
+        hreg[u] = ok ? hsrc[i] : 0.0f;
+        hpk[u][0] = (ok && c.hist_pack_bits) ? rt.hist_pack[(size_t)i * c.hist_pack_words] : 0;
+        hpk[u][1] = (ok && c.hist_pack_bits && c.hist_pack_words > 1) ? rt.hist_pack[(size_t)i * c.hist_pack_words + 1] : 0;
+      }
+    }
+    float creg[4];
+    {
+      const float* __restrict__ csrc = io.frame_contact + (fk + env) * (size_t)(B * 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = lane + u * PBHC_G; creg[u] = i < B * 3 ? csrc[i] : 0.0f; }
+    }
+    float a_in = 0, qp = 0, qv = 0, kp = 0, kd = 0, rfs = 0, ras = 0, u_rfi = 0.5f, qold[PBHC_MAX_QUEUE];
+    int didx = 0;
+    float* qu = io.action_queue + (size_t)env * Q * D + d;
+#pragma unroll
+    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = 0.0f;
+    if (d < D) {
+      a_in = io.actions_in[eD + d];
+#pragma unroll
+      for (int k = 0; k < PBHC_MAX_QUEUE; ++k) if (c.randomize_ctrl_delay && k < Q) qold[k] = qu[(size_t)k * D];
+      qp = io.dof_state[(eD + d) * 2]; qv = io.dof_state[(eD + d) * 2 + 1];
+      kp = io.kp_scale[eD + d]; kd = io.kd_scale[eD + d]; rfs = io.rfi_lim_scale[eD + d]; ras = io.rao_scale[eD + d];
+      if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(rt.seed, env, step_ctr, 1, d);
+      pf_last_act = io.last_actions[eD + d]; pf_last_qd = io.last_dof_vel[eD + d];
+    }
+    didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
+    float lmreg = 0, combias = 0, fric = 0, fat = 0, lastc = 0;
+    if (lane < c.dr_link_mass_dim) lmreg = io.dr_link_mass[(size_t)env * c.dr_link_mass_dim + lane];
+    if (lane < 3) combias = io.dr_base_com[(size_t)env * 3 + lane];
+    if (lane == 0) fric = io.dr_friction[env];
+    if (lane < NF) { fat = io.feet_air_time[(size_t)env * NF + lane]; lastc = io.last_contacts[(size_t)env * NF + lane]; }
     if (lane < c.num_terms) {
       pf_tid = c.term_id[lane]; pf_tscale = c.term_scale[lane]; pf_tpen = c.term_penalty[lane]; pf_tcol = c.term_sum_col[lane];
       pf_sum = io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol];
     }
+    if (lane < PBHC_NUM_SIGMA) pf_sigma = (float)glob[PBHC_G_SIGMA + lane];
+    if (c.has_termination && lane == c.num_terms - 1) pf_termsum = io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col];
+
+    // ---- consume (1): frame state -> LDS for the FK chain
+    if (d < D) { q[d] = fq; qd[d] = fqd; }
+    if (lane < 13) root[lane] = froot;
+    // ---- consume (2): reference rows, issued now, consumed after the FK chain
     tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
     int f0, f1;
-    frame_blend(tref, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &blend);
-    r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
-    r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+    if (tbl.num_motions == 1) {                                 // single clip: its meta travels in the kernel arguments
+      frame_blend(tref, tbl.single_len, tbl.single_num_frames, tbl.single_dt, &f0, &f1, &blend);
+      r0 = tbl.frames + (size_t)f0 * tbl.row;
+      r1 = tbl.frames + (size_t)f1 * tbl.row;
+    } else {
+      frame_blend(tref, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &blend);
+      r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
+      r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+    }
     const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
     if (lane < Bx) {
       rp0 = ld3(r0 + o_pos + 3 * lane); rp1 = ld3(r1 + o_pos + 3 * lane);
@@ -290,29 +389,20 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     }
     if (lane < D) { rd0 = r0[lane]; rd1 = r1[lane]; rdv0 = r0[D + lane]; rdv1 = r1[D + lane]; }
     if (lane < 2) { rc0 = r0[2 * D + lane]; rc1 = r1[2 * D + lane]; }
-  }
 
-  STAMP(0);
-  // ---------------- phase A: _pre_physics_step (motion_tracking.py:749-768), torques from the
-  // pre-step state (legged_robot_base.py:795-838), then the replay frame lands ------------------
-  float clipcnt = 0.0f;
-  if (valid) {
-    const int Q = c.queue_len;
-    const int d = lane;                       // D <= 32: one dof per lane
-    // history (largest read) first, all loads of this phase are independent: issue them before any store
-    const int hoff = c.feat_off[PBHC_F_HISTORY];
-    copy_g2l(feat + hoff, io.hist + (size_t)env * c.hist_dim, c.hist_dim, lane);
-    if (d < D) {
-      const float a_in = io.actions_in[eD + d];
-      float qold[PBHC_MAX_QUEUE];
-      float* qu = io.action_queue + (size_t)env * Q * D + d;
+    // ---- consume (3): LDS staging + torques
 #pragma unroll
-      for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = (c.randomize_ctrl_delay && k < Q) ? qu[(size_t)k * D] : 0.0f;
-      const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
-      const float qp = io.dof_state[(eD + d) * 2], qv = io.dof_state[(eD + d) * 2 + 1];
-      const float kp = io.kp_scale[eD + d], kd = io.kd_scale[eD + d], rfs = io.rfi_lim_scale[eD + d], ras = io.rao_scale[eD + d];
-      const float fq = io.frame_dof_pos[fk * D + eD + d], fqd = io.frame_dof_vel[fk * D + eD + d];
-      const float u = c.randomize_torque_rfi ? (io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(c.seed, env, step_ctr, 1, d)) : 0.5f;
+    for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
+    if (c.hist_dim > PBHC_HREG * PBHC_G)
+      copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * c.hist_dim + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
+    // old history goes to its outputs NOW (stores are fire-and-forget; a reset later rewrites these positions with zeros)
+    if (c.hist_pack_bits) {
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) hist_scatter(c, io, env, hpk[u], hreg[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
+    if (d < D) {
       const float tl = c.torque_limits[d];
       const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
       if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
@@ -329,28 +419,22 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       }
       actd[d] = delayed;
       float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
-      if (c.randomize_torque_rfi) tq = tq + (u * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
+      if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
       if (c.use_rao) tq = tq + ras * tl;
       if (c.clip_torques) tq = clampf(tq, -tl, tl);
       tau[d] = tq;
-      q[d] = fq;
-      qd[d] = fqd;
     }
-    if (lane < 13) root[lane] = io.frame_root[(fk + env) * 13 + lane];
-    copy_g2l(cf, io.frame_contact + (fk + env) * (size_t)(B * 3), B * 3, lane);
-    if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = io.dr_base_com[(size_t)env * 3 + lane];
-    copy_g2l(feat + c.feat_off[PBHC_F_DR_LINK_MASS], io.dr_link_mass + (size_t)env * c.dr_link_mass_dim, c.dr_link_mass_dim, lane);
+    if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
+    if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
     if (lane == 0) {
-      feat[c.feat_off[PBHC_F_DR_FRICTION]] = io.dr_friction[env];
+      feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
       feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
-      misc[M_FAT0] = io.feet_air_time[(size_t)env * NF + 0];
-      misc[M_FAT1] = NF > 1 ? io.feet_air_time[(size_t)env * NF + 1] : 0.0f;
-      misc[M_LASTC0] = io.last_contacts[(size_t)env * NF + 0];
-      misc[M_LASTC1] = NF > 1 ? io.last_contacts[(size_t)env * NF + 1] : 0.0f;
     }
+    if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
+    if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
   }
   clipcnt = group_sum(clipcnt);
-  __syncthreads();
+  LDS_BARRIER();
 
   STAMP(1);
   // ---------------- phase B: rigid-body state of the new frame (sim-stub FK) -------------------
@@ -371,7 +455,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
       f3 e = euler_xyz(rq4);
       misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
-      feat[c.feat_off[PBHC_F_RELYAW]] = e.z - c.ref_init_yaw;
+      feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
       feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];
       st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
     } else if (lane == 1) {
@@ -385,12 +469,12 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     } else if (lane >= 4 && lane < 4 + NF) {
       int f = lane - 4;
       float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
-      float lastc = io.last_contacts[(size_t)env * NF + f];
+      float lastc = misc[M_LASTC0 + f];
       misc[M_CONTACT0 + f] = cn;
       misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
 
   STAMP(3);
   // ---------------- phase D: reference frame (a6) ------------------------------------------------
@@ -416,7 +500,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       st3(rw + 3 * i, mk3(a * w0.x + bb * w1.x, a * w0.y + bb * w1.y, a * w0.z + bb * w1.z));
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
 
   STAMP(4);
   // ---------------- phase E: tracking differences + lane-parallel partial sums -------------------
@@ -456,7 +540,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       st3(feat + o_gv + 3 * b, rvel);
       st3(feat + o_lv + 3 * b, quat_rotate(hinv, rvel));
     }
-    const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
+    const float soft_pos = pf_soft_pos, soft_vel = pf_soft_vel, soft_tau = pf_soft_tau;
     const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
     for (int d = lane; d < D; d += PBHC_G) {
       float dj = rdof[d] - q[d], djv = rdofv[d] - qd[d];
@@ -497,7 +581,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
     float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
     if (c.terminate_by_gravity) grav = sqrtf(misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]) > c.termination_gravity ? 1.0f : 0.0f;
-    if (c.terminate_when_motion_far) far = s_maxn > (float)glob[PBHC_G_MOTION_FAR_THR] ? 1.0f : 0.0f;
+    if (c.terminate_when_motion_far) far = s_maxn > pf_far_thr ? 1.0f : 0.0f;
     tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
     if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
     float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
@@ -505,7 +589,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     misc[M_TIMEOUT] = tout;
     misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f) ? 1.0f : 0.0f;
   }
-  __syncthreads();
+  LDS_BARRIER();
 
   STAMP(5);
   // ---------------- phase F: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ----
@@ -525,7 +609,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_S_JOINT_POS: e = red[R_JP2] / (float)D; break;
         default: e = red[R_JV2] / (float)D; break;
       }
-      red[R_EXP0 + lane] = expf(-e / (float)glob[PBHC_G_SIGMA + lane]);
+      red[R_EXP0 + lane] = expf(-e / pf_sigma);
     } else if (lane < PBHC_NUM_SIGMA + NF) {
       const int f = lane - PBHC_NUM_SIGMA;
       const float* fc = cf + 3 * c.feet[f];
@@ -537,13 +621,13 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       red[R_FOOT0 + 8 + f] = sqrtf(fv[0] * fv[0] + fv[1] * fv[1]);
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
   float err[PBHC_NUM_SIGMA];
 #pragma unroll
   for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
   float rew_total = 0.0f;
   if (valid) {
-    const float pen_scale = (float)glob[PBHC_G_PENALTY_SCALE];
+    const float pen_scale = pf_pen_scale;
     float myrew = 0.0f;
     if (lane < c.num_terms) {
       float raw = 0.0f;
@@ -612,7 +696,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
           float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
           v += tr;
-          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] += tr;
+          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] = pf_termsum + tr;
         }
         io.rew_buf[(size_t)env * c.num_rew_cols + lane] = v;
         rew_total = v;
@@ -636,7 +720,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     err[PBHC_S_BODY_VEL] = red[R_VEL]; err[PBHC_S_BODY_ANG_VEL] = red[R_ANG]; err[PBHC_S_JOINT_POS] = red[R_JP2] / (float)D;
     err[PBHC_S_JOINT_VEL] = red[R_JV2] / (float)D;
   }
-  __syncthreads();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
+  LDS_BARRIER();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
 
   // optional outputs of the pre-reset state
   if (valid) {
@@ -664,18 +748,23 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     for (int d = lane; d < D; d += PBHC_G) {
       act[d] = 0.0f; actd[d] = 0.0f;
       if (c.randomize_pd_gain) {
-        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * rng_uniform(c.seed, env, step_ctr, 2, d) + c.kp_range[0];
-        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * rng_uniform(c.seed, env, step_ctr, 3, d) + c.kd_range[0];
+        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * rng_uniform(rt.seed, env, step_ctr, 2, d) + c.kp_range[0];
+        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * rng_uniform(rt.seed, env, step_ctr, 3, d) + c.kd_range[0];
       }
       if (c.randomize_rfi_lim)
-        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * rng_uniform(c.seed, env, step_ctr, 4, d) + c.rfi_lim_range[0];
+        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * rng_uniform(rt.seed, env, step_ctr, 4, d) + c.rfi_lim_range[0];
       if (c.use_rao)
-        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * rng_uniform(c.seed, env, step_ctr, 5, d) + (-c.rao_lim);
+        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * rng_uniform(rt.seed, env, step_ctr, 5, d) + (-c.rao_lim);
       if (c.randomize_ctrl_delay)
         for (int k = 0; k < Q; ++k) io.action_queue[((size_t)env * Q + k) * D + d] *= 0.0f;
     }
-    const int hoff = c.feat_off[PBHC_F_HISTORY];
-    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] *= 0.0f;
+    for (int i = lane; i < c.hist_dim; i += PBHC_G) {
+      feat[hoff + i] *= 0.0f;
+      if (c.hist_pack_bits) {
+        int w[2] = {rt.hist_pack[(size_t)i * c.hist_pack_words], c.hist_pack_words > 1 ? rt.hist_pack[(size_t)i * c.hist_pack_words + 1] : 0};
+        hist_scatter(c, io, env, w, 0.0f);
+      }
+    }
     float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
     for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
       if (io.episode_rew_out) io.episode_rew_out[(size_t)env * c.num_sum_cols + i] = sum[i] / c.max_episode_length_s;
@@ -689,26 +778,26 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       io.end_time_ratio_buf[env] = etr;
       float mlen = tbl.motion_len[mid];
       io.motion_len[env] = mlen;
-      float ns = io.ovr_start_time ? io.ovr_start_time[env] : rng_uniform(c.seed, env, step_ctr, 6, 0) * mlen;   // sample_time motion_lib_base.py:486-495
+      float ns = io.ovr_start_time ? io.ovr_start_time[env] : rng_uniform(rt.seed, env, step_ctr, 6, 0) * mlen;   // sample_time motion_lib_base.py:486-495
       io.motion_start_times[env] = ns;
       misc[M_NEWSTART] = ns;
       if (c.randomize_ctrl_delay) {
         long long nd = io.ovr_delay ? io.ovr_delay[env]
-                                    : (long long)c.ctrl_delay_range[0] + (long long)(rng_uniform(c.seed, env, step_ctr, 7, 0) * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
+                                    : (long long)c.ctrl_delay_range[0] + (long long)(rng_uniform(rt.seed, env, step_ctr, 7, 0) * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
         io.action_delay_idx[env] = nd;
         misc[M_DELAY] = (float)nd;
       }
       misc[M_EPLEN] = 0.0f;
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
   if (do_reset) {
     // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
     // invalidated, motion_tracking.py:378,536-543,477-507)
     float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
     motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, red + 46, rp, rq, rv, rw);
   }
-  __syncthreads();
+  LDS_BARRIER();
   if (do_reset && lane == 0) {
     st3(root, ld3(rp));
     st4(root + 3, quat_mul(mk4(0.f, 0.f, 0.f, 1.f), ld4(rq)));       // quat_mul(small_random_quaternions(max_angle=0), root_rot)
@@ -731,36 +820,38 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     }
     if (lane == 0) feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
   }
-  __syncthreads();
+  LDS_BARRIER();
 
   STAMP(8);
   // ---------------- phase I: observation groups + history write-back ------------------------------
   // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
   if (valid) {
-    const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
+    const float noise_cur = pf_noise_cur;
     for (int g = 0; g < c.num_groups; ++g) {
       const int dim = c.groups[g].dim, clip = c.groups[g].clip;
-      const int* __restrict__ msrc = c.groups[g].src;
-      const float* __restrict__ mscale = c.groups[g].scale;
-      const float* __restrict__ mnoise = c.groups[g].noise;
-      float* __restrict__ out = io.obs[g] + (size_t)env * dim;
+      const int* __restrict__ mdst = rt.groups[g].dst;
+      const int* __restrict__ msrc = rt.groups[g].src;
+      const float* __restrict__ mscale = rt.groups[g].scale;
+      const float* __restrict__ mnoise = rt.groups[g].noise;
+      float* __restrict__ out = io.obs[g] + (size_t)env * c.groups[g].pitch;
       for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
-        int si[8]; float sc[8], ns[8];
+        int si[8], di[8]; float sc[8], ns[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = j0 + u * PBHC_G;
           const bool ok = j < dim;
           si[u] = ok ? msrc[j] : 0; sc[u] = ok ? mscale[j] : 0.0f; ns[u] = ok ? mnoise[j] : 0.0f;
+          di[u] = ok ? (mdst ? mdst[j] : j) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = j0 + u * PBHC_G;
           if (j < dim) {
             float x = feat[si[u]];
-            if (ns[u] != 0.0f) x = x + (rng_uniform(c.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
+            if (ns[u] != 0.0f) x = x + (rng_uniform(rt.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
             x = x * sc[u];
             if (clip) x = clampf(x, -c.clip_observations, c.clip_observations);
-            out[j] = x;
+            out[di[u]] = x;
           }
         }
       }
@@ -810,7 +901,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       bpq[P_REW_SUM] = rew_total;
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
   if (threadIdx.x < PBHC_NP) {
     float v = 0.0f;
     for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];

@@ -104,6 +104,9 @@ class MotionLib:
         self.table.num_frames = self.num_frames.data_ptr()
         self.table.motion_dt = self._motion_dt.data_ptr()
         self.table.motion_len = self._motion_lengths.data_ptr()
+        self.table.single_num_frames = int(nframes[0])
+        self.table.single_dt = float(torch.tensor(dts[0], dtype=torch.float32))
+        self.table.single_len = float(torch.tensor(lens[0], dtype=torch.float32))
 
     @classmethod
     def from_config(cls, mcfg, skeleton, num_envs, device):
