@@ -67,6 +67,8 @@ class MotionTrackingOracle:
         self.lower_id = [self.body_list.index(l) for l in m.lower_body_link]
         self.upper_id = [self.body_list.index(l) for l in m.upper_body_link]
         # --- gains / limits (legged_robot_base.py:74-108, isaacgym.py:_process_dof_props) ---
+        asc = rc.control.action_scale                      # scalar, or per-joint-group dict (legged_robot_base.py:99-100,805-808)
+        self.action_scale = asc if isinstance(asc, (int, float)) else torch.ones(D)
         self.default_dof_pos = torch.zeros(D)
         self.p_gains = torch.zeros(D)
         self.d_gains = torch.zeros(D)
@@ -76,7 +78,8 @@ class MotionTrackingOracle:
                 if k in name:
                     self.p_gains[i] = rc.control.stiffness[k]
                     self.d_gains[i] = rc.control.damping[k]
-        self.action_scale = rc.control.action_scale
+                    if not isinstance(asc, (int, float)):
+                        self.action_scale[i] = asc[k]
         lo = _f(list(rc.dof_pos_lower_limit_list))
         hi = _f(list(rc.dof_pos_upper_limit_list))
         self.hard_limits = torch.stack([lo, hi], -1)

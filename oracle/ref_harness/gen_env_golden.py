@@ -60,7 +60,7 @@ def snapshot(env):
         episode_length_buf=env.episode_length_buf, last_episode_length_buf=env.last_episode_length_buf,
         motion_start_times=env.motion_start_times, motion_len=env.motion_len, end_time_ratio_buf=env.end_time_ratio_buf,
         reset_buf=env.reset_buf, time_out_buf=env.time_out_buf,
-        reward_penalty_scale=np.float64(env.reward_penalty_scale), average_episode_length=np.float64(float(env.average_episode_length)),
+        reward_penalty_scale=np.float64(getattr(env, "reward_penalty_scale", env.config.rewards.reward_initial_penalty_scale)), average_episode_length=np.float64(float(env.average_episode_length)),
         motion_far_threshold=np.float64(env.terminate_when_motion_far_threshold), common_step_counter=np.int64(env.common_step_counter),
     )
     for k, v in env.episode_sums.items():
