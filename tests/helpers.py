@@ -29,8 +29,8 @@ def clip_from_env_golden(g):
     return clip
 
 
-def fixture_config(name, num_envs):
-    cfg = load_config(os.path.join(GOLDEN, "configs", name), {"num_envs": num_envs}, now="test")
+def fixture_config(name, num_envs, overrides=None):
+    cfg = load_config(os.path.join(GOLDEN, "configs", name), dict({"num_envs": num_envs}, **(overrides or {})), now="test")
     for k in list(cfg.obs.noise_scales.keys()):
         cfg.obs.noise_scales[k] = 0.0
     return cfg
@@ -43,6 +43,19 @@ def state_dict_from_golden(g, prefix="state0__", step=None):
             v = g[k]
             out[k[len(prefix):]] = v if step is None else v[step]
     return out
+
+
+# the narrowed layer sizes the ppo_v2 golden was generated with (oracle/ref_harness/gen_ppo_v2_golden.py)
+PPO_V2_NARROW = {
+    "algo.config.module_dict.actor.layer_config.hidden_dims": [64, 48, 32],
+    "algo.config.module_dict.critic.layer_config.hidden_dims": [64, 48, 32],
+    "algo.config.module_dict.actor.motion_encoder.hidden_dim": 12,
+    "algo.config.module_dict.actor.motion_encoder.output_dim": 16,
+    "algo.config.module_dict.actor.history_encoder.hidden_dim": 10,
+    "algo.config.module_dict.actor.history_encoder.output_dim": 8,
+    "algo.config.module_dict.actor.priv_encoder.layer_config.hidden_dims": [16],
+    "algo.config.num_steps_per_env": 8,
+}
 
 
 # ---- HIP-side helpers (GPU tests, smoke, bench) ---------------------------------------------------
