@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 1
+#define PBHC_ABI_VERSION 2
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -35,8 +35,10 @@ extern "C" {
 #define PBHC_MAX_IDX 36
 #define PBHC_MAX_GROUPS 6    /* observation groups + the history write-back map */
 #define PBHC_MAX_QUEUE 8     /* control-delay queue depth */
-#define PBHC_NUM_SIGMA 10
-#define PBHC_NUM_GLOBALS 64
+#define PBHC_NUM_SIGMA 20
+#define PBHC_NUM_GLOBALS 128
+#define PBHC_MAX_FUTURE 32   /* future reference steps of the general-tracking observations */
+#define PBHC_MAX_BODY_Z 8
 #define PBHC_NUM_LOG 32
 
 /* ---- skeleton (reference: Humanoid_Batch.__init__/from_mjcf,
@@ -84,13 +86,27 @@ enum PbhcRewardTerm {
   PBHC_R_LIMITS_TORQUE,
   PBHC_R_COLLISION,
   PBHC_R_ALIVE,
+  /* general tracking (reference: envs/motion_tracking/general_tracking.py:1088-1279) */
+  PBHC_R_TELEOP_CONTACT_MASK_V2,
+  PBHC_R_TELEOP_KEY_BODY_POSITION,
+  PBHC_R_TELEOP_ANCHOR_BODY_POSITION,
+  PBHC_R_TELEOP_ANCHOR_BODY_ROTATION,
+  PBHC_R_LOCAL_KEY_BODY_POSITION,
+  PBHC_R_LOCAL_KEY_BODY_ROTATION,
+  PBHC_R_KEY_BODY_VELOCITY,
+  PBHC_R_KEY_BODY_ANG_VELOCITY,
+  PBHC_R_TELEOP_ROOT_VEL,
+  PBHC_R_TELEOP_ROOT_POSE,
   PBHC_R_NUM_TERMS
 };
 
 /* ---- tracking-sigma slots (reference: rewards.reward_tracking_sigma keys) ------------------ */
 enum PbhcSigma {
   PBHC_S_MAX_JOINT_POS = 0, PBHC_S_UPPER_BODY_POS, PBHC_S_LOWER_BODY_POS, PBHC_S_VR_3POINT_POS,
-  PBHC_S_FEET_POS, PBHC_S_BODY_ROT, PBHC_S_BODY_VEL, PBHC_S_BODY_ANG_VEL, PBHC_S_JOINT_POS, PBHC_S_JOINT_VEL
+  PBHC_S_FEET_POS, PBHC_S_BODY_ROT, PBHC_S_BODY_VEL, PBHC_S_BODY_ANG_VEL, PBHC_S_JOINT_POS, PBHC_S_JOINT_VEL,
+  /* general tracking */
+  PBHC_S_KEY_BODY_POS, PBHC_S_ANCHOR_BODY_POS, PBHC_S_ANCHOR_BODY_ROT, PBHC_S_LOCAL_KEY_BODY_POS, PBHC_S_LOCAL_KEY_BODY_ROT,
+  PBHC_S_KEY_BODY_VEL, PBHC_S_KEY_BODY_ANG_VEL, PBHC_S_ROOT_VEL, PBHC_S_ROOT_POSE
 };
 
 /* ---- feature ids: the per-env scalars/vectors an observation key can read
@@ -102,6 +118,11 @@ enum PbhcFeature {
   PBHC_F_VR_3POINT_POS, PBHC_F_DR_BASE_COM, PBHC_F_DR_LINK_MASS, PBHC_F_DR_KP, PBHC_F_DR_KD, PBHC_F_DR_FRICTION,
   PBHC_F_DR_CTRL_DELAY, PBHC_F_RELYAW, PBHC_F_BASE_POS_Z, PBHC_F_DIF_JOINT_ANGLES, PBHC_F_DIF_JOINT_VELOCITIES,
   PBHC_F_LOCAL_REF_RIGID_BODY_VEL, PBHC_F_GLOBAL_REF_RIGID_BODY_VEL, PBHC_F_HISTORY, PBHC_F_ZERO,
+  /* general tracking (getters general_tracking.py:821-954): per-body tables [Bx,3] / [Bx,6], the observation maps pick the key bodies;
+   * future targets [S,dim] (general_tracking.py:500-565) */
+  PBHC_F_ROLL_PITCH, PBHC_F_CONTACT_MASK, PBHC_F_DR_BASE_MASS, PBHC_F_LOCAL_BODY_POS, PBHC_F_LOCAL_BODY_ROT, PBHC_F_ANCHOR_REF_POS,
+  PBHC_F_ANCHOR_REF_ROT, PBHC_F_DIF_ROOT_VELOCITY, PBHC_F_DIF_ROOT_ROT, PBHC_F_DIF_ROOT_HEIGHT, PBHC_F_REF_CONTACT_MASK,
+  PBHC_F_FUT_ROOT_HEIGHT, PBHC_F_FUT_ROLL_PITCH, PBHC_F_FUT_BASE_LIN_VEL, PBHC_F_FUT_BASE_ANG_VEL, PBHC_F_FUT_DOF_POS, PBHC_F_FUT_LOCAL_KEY_POS,
   PBHC_F_NUM
 };
 
@@ -110,23 +131,25 @@ enum PbhcFeature {
  *      legged_robot_base.py:882-900, average_episode_length :875-879, motion-far threshold
  *      motion_tracking.py:309-317).  double[PBHC_NUM_GLOBALS]. -------------------------------- */
 enum PbhcGlobal {
-  PBHC_G_SIGMA = 0,                       /* [10] */
-  PBHC_G_EMA = 10,                        /* [10] */
-  PBHC_G_PENALTY_SCALE = 20,
-  PBHC_G_AVG_EP_LEN = 21,
-  PBHC_G_MOTION_FAR_THR = 22,
-  PBHC_G_SOFT_POS_VAL = 23,
-  PBHC_G_SOFT_VEL_VAL = 24,
-  PBHC_G_SOFT_TAU_VAL = 25,
-  PBHC_G_STEP_COUNTER = 26,
-  PBHC_G_NOISE_CURRICULUM = 27,
-  PBHC_G_LOG = 32                         /* [PBHC_NUM_LOG] per-step log means, see PbhcLog */
+  PBHC_G_SIGMA = 0,                       /* [PBHC_NUM_SIGMA] */
+  PBHC_G_EMA = 20,                        /* [PBHC_NUM_SIGMA] */
+  PBHC_G_PENALTY_SCALE = 40,
+  PBHC_G_AVG_EP_LEN = 41,
+  PBHC_G_MOTION_FAR_THR = 42,
+  PBHC_G_SOFT_POS_VAL = 43,
+  PBHC_G_SOFT_VEL_VAL = 44,
+  PBHC_G_SOFT_TAU_VAL = 45,
+  PBHC_G_STEP_COUNTER = 46,
+  PBHC_G_NOISE_CURRICULUM = 47,
+  PBHC_G_LOG = 64                         /* [PBHC_NUM_LOG] per-step log means, see PbhcLog */
 };
 
 enum PbhcLog {
   PBHC_L_UPPER_BODY_DIFF_NORM = 0, PBHC_L_LOWER_BODY_DIFF_NORM, PBHC_L_VR_3POINT_DIFF_NORM, PBHC_L_JOINT_POS_DIFF_NORM,
   PBHC_L_ACTION_CLIP_FRAC, PBHC_L_RESET_FRAC, PBHC_L_TERM_GRAVITY, PBHC_L_TERM_MOTION_FAR, PBHC_L_TERM_TIME_OUT,
   PBHC_L_TERM_MOTION_END, PBHC_L_END_TIME_RATIO, PBHC_L_END_TIME_RATIO_STD, PBHC_L_NUM_RESETS, PBHC_L_REW_MEAN,
+  PBHC_L_KEY_BODY_DIFF_NORM, PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM, PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM, PBHC_L_LOCAL_VR_3POINT_DIFF_NORM,
+  PBHC_L_LOCAL_KEY_BODY_DIFF_NORM, PBHC_L_TERM_REF_POS_Z, PBHC_L_TERM_REF_ORI, PBHC_L_TERM_BODY_Z,
   PBHC_L_NUM
 };
 
@@ -149,7 +172,7 @@ typedef struct PbhcOutMap {
  * (scale 1, no noise): element i of the packed history row goes to position p_g(i) of output group g — the history_* slices
  * of the observation groups and, shifted by one step, the history write-back.  hist_pack[i*words + w] packs, `bits` bits per
  * group, the values p_g(i)+1 (0 = group g does not carry element i), group g in word g / (32/bits), field g % (32/bits). --- */
-/* ---- static configuration of the v1 env (LeggedRobotMotionTracking) ------------------------
+/* ---- static configuration of the env (tracking_mode 0: LeggedRobotMotionTracking, 1: LeggedRobotGeneralTracking) -----
  * Filled by the host from the reference's YAML config tree (same keys); copied to the device by
  * pbhc_env_create. */
 typedef struct PbhcEnvConfig {
@@ -177,7 +200,7 @@ typedef struct PbhcEnvConfig {
   int32_t num_upper, upper[PBHC_MAX_IDX];
   int32_t num_lower, lower[PBHC_MAX_IDX];
   int32_t num_track, track[PBHC_MAX_IDX];
-  int32_t body_flags[PBHC_MAX_BODIES];       /* bit0 upper, bit1 lower, bit2 tracked(vr 3-point), bit3 foot */
+  int32_t body_flags[PBHC_MAX_BODIES];       /* bit0 upper, bit1 lower, bit2 tracked(vr 3-point), bit3 foot, bit4 key body, bit5 body_z list */
   int32_t track_slot[PBHC_MAX_BODIES];       /* position of the body inside `track`, or -1 */
   /* termination (legged_robot_base.py:408-489, motion_tracking.py:330-357) */
   int32_t terminate_by_gravity, terminate_when_motion_far, terminate_when_motion_end, motion_far_curriculum;
@@ -193,7 +216,10 @@ typedef struct PbhcEnvConfig {
   int32_t has_termination, termination_sum_col, only_positive_rewards, num_sum_cols;
   float termination_scale;
   float body_pos_lower_weight, body_pos_upper_weight, desired_feet_air_time, max_contact_force;
-  int32_t adaptive_sigma;                    /* rewards.adaptive_tracking_sigma.enable, type "origin" */
+  int32_t adaptive_sigma;                    /* rewards.adaptive_tracking_sigma.enable */
+  int32_t adaptive_type;                     /* 0 "origin" (min(ema, sigma)), 1 "mean" (v1: (min+ema)/2 motion_tracking.py:1040-1045; v2: ema
+                                                general_tracking.py:988-989), 2 "scale" (min(ema*scale, sigma)) */
+  float adaptive_scale;
   int32_t sigma_active[PBHC_NUM_SIGMA];      /* 1 if a configured reward term updates this sigma */
   float adaptive_alpha;
   int32_t penalty_curriculum;
@@ -215,6 +241,14 @@ typedef struct PbhcEnvConfig {
   int32_t has_contact_mask;
   float ref_init_yaw;
   int32_t dr_link_mass_dim;
+  /* general tracking (general_tracking.py:86-98,226-262,500-507) */
+  int32_t tracking_mode;
+  int32_t num_key, key[PBHC_MAX_IDX];        /* robot.key_bodies as indices into the extended body list */
+  int32_t key_slot[PBHC_MAX_BODIES];         /* position of the body inside `key`, or -1 */
+  int32_t anchor_index;                      /* find_rigid_body_indice(anchor_link) + 1, sic */
+  int32_t future_num_steps, future_steps[PBHC_MAX_FUTURE];   /* linspace(1, future_max_steps, future_num_steps) as long */
+  int32_t terminate_by_ref_pos_z, terminate_by_ref_ori, terminate_by_body_z;
+  float ref_pos_z_threshold, ref_ori_threshold, body_z_threshold;
   uint64_t seed;
 } PbhcEnvConfig;
 
@@ -270,6 +304,7 @@ typedef struct PbhcStepIO {
   uint8_t* time_out_buf;          /* [N] bool */
   const float* env_origins;       /* [N,3] */
   const float* dr_base_com; const float* dr_link_mass; const float* dr_friction;        /* [N,3] [N,L] [N,1] */
+  const float* dr_base_mass;      /* [N,1] (general tracking priv_obs), may be NULL -> 1.0 */
   /* outputs */
   float* obs[PBHC_MAX_GROUPS];    /* [N,dim_g]; group num_groups-1 may alias `hist` semantics (see PbhcOutMap) */
   float* rew_buf;                 /* [N,num_rew_cols] */

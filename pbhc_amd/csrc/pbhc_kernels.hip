@@ -23,7 +23,7 @@ using namespace pbhc;
 
 #define PBHC_G 32     // lanes per env
 #define PBHC_EPB 4    // envs per workgroup
-#define PBHC_NP 48    // partial sums per workgroup
+#define PBHC_NP 64    // partial sums per workgroup
 
 thread_local char g_pbhc_err[512] = "";
 #define g_err g_pbhc_err
@@ -55,9 +55,10 @@ __device__ unsigned long long g_stamps[32];
 // ------------------------------------------------------------------------------------------------
 // partial-sum columns written per workgroup by k_env_step, reduced by k_env_finalize
 enum {
-  P_ERR = 0,            // [10] tracking errors (adaptive sigma)
-  P_UPPER_NORM = 10, P_LOWER_NORM, P_VR_NORM, P_JOINT_NORM, P_CLIP_CNT, P_RESET_CNT, P_TERM_GRAVITY, P_TERM_FAR,
+  P_ERR = 0,            // [PBHC_NUM_SIGMA] tracking errors (adaptive sigma)
+  P_UPPER_NORM = PBHC_NUM_SIGMA, P_LOWER_NORM, P_VR_NORM, P_JOINT_NORM, P_CLIP_CNT, P_RESET_CNT, P_TERM_GRAVITY, P_TERM_FAR,
   P_TERM_TIMEOUT, P_TERM_END, P_RESET_EPLEN, P_ETR_SUM, P_ETR_SQ, P_REW_SUM,
+  P_KEY_NORM, P_LUP_NORM, P_LLO_NORM, P_LVR_NORM, P_LKEY_NORM, P_TERM_REFZ, P_TERM_REFORI, P_TERM_BODYZ,      // general tracking
   P_NUM
 };
 static_assert(P_NUM <= PBHC_NP, "partials");
@@ -66,11 +67,13 @@ static_assert(P_NUM <= PBHC_NP, "partials");
 enum {
   R_UP = 0, R_LO, R_VR, R_FEET, R_ROT, R_VEL, R_ANG, R_MAXNORM, R_UPN, R_LON, R_VRN,
   R_MAXJP, R_JP2, R_JV2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
-  R_EXP0,                      // [10] exp(-err_k / sigma_k)
-  R_FOOT0 = R_EXP0 + 10,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2)
+  // general tracking: key-body / anchor / root errors, local-frame log norms, body_z flag
+  R_KEY, R_KEYN, R_LKEY, R_LKEYN, R_LKROT, R_KVEL, R_KANG, R_APOS, R_AROT, R_RVEL, R_RPOSE, R_LUPN, R_LLON, R_LVRN, R_BODYZ,
+  R_EXP0,                                  // [PBHC_NUM_SIGMA] exp(-err_k / sigma_k)
+  R_FOOT0 = R_EXP0 + PBHC_NUM_SIGMA,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2)
   R_NUM = R_FOOT0 + 10
 };
-static_assert(R_NUM <= 48, "RED region");
+static_assert(R_NUM <= 80, "RED region");
 
 // per-env LDS layout (floats); body arrays sized for PBHC_MAX_BODIES = 36
 struct Lds {
@@ -81,16 +84,19 @@ struct Lds {
     CF = 288,                                                                        // 108 contact forces
     BP = 396, BQ = 504, BV = 648, BW = 756,                                          // body pos3/quat4/vel3/ang3 x36
     RP = 864, RQ = 972, RV = 1116, RW = 1224,                                        // reference, same shapes
-    RED = 1332,                                                                      // 48
-    FEAT = 1380
+    RED = 1332,                                                                      // 80
+    FUT = 1412,                                                                      // general tracking: 10 x PBHC_MAX_FUTURE per-step scratch
+    FEAT_V1 = 1412, FEAT_V2 = 1412 + 10 * PBHC_MAX_FUTURE
   };
+  static __host__ __device__ constexpr int feat(int mode) { return mode ? FEAT_V2 : FEAT_V1; }
 };
 // MISC slots
 enum {
   M_HINV = 0,   // 4 heading-inverse quaternion
   M_TIME = 4, M_PHASE, M_MLEN, M_START, M_RESET, M_TIMEOUT, M_EPLEN, M_CONTACT0, M_CONTACT1, M_CFILT0, M_CFILT1,
   M_RCONTACT0, M_RCONTACT1, M_GRAV, M_FAR, M_END, M_TOUT_LEN, M_LASTEP, M_NEWSTART, M_DELAY, M_FAT0, M_FAT1,
-  M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ
+  M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ,
+  M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI                      // general tracking: termination causes, anchor z / gravity-z differences
 };
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
@@ -252,6 +258,8 @@ __device__ __forceinline__ void motion_lookup(const PbhcMotionTable& tbl, int D,
 // =================================================================================================
 extern __shared__ float smem[];
 
+// MODE 0: LeggedRobotMotionTracking (motion_tracking.py), MODE 1: LeggedRobotGeneralTracking (general_tracking.py)
+template <int MODE>
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride) {
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float *rdof = S + Lds::RDOF, *rdofv = S + Lds::RDOFV, *root = S + Lds::ROOT, *misc = S + Lds::MISC, *cf = S + Lds::CF;
   float *bp = S + Lds::BP, *bq = S + Lds::BQ, *bv = S + Lds::BV, *bw = S + Lds::BW;
   float *rp = S + Lds::RP, *rq = S + Lds::RQ, *rv = S + Lds::RV, *rw = S + Lds::RW;
-  float *red = S + Lds::RED, *feat = S + Lds::FEAT;
+  float *red = S + Lds::RED, *feat = S + Lds::feat(MODE);
   const size_t fk = (size_t)(io.frame_cursor[0] % io.num_frames) * (size_t)N;   // replay frame of this step (device-side cursor)
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
@@ -353,7 +361,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       pf_last_act = io.last_actions[eD + d]; pf_last_qd = io.last_dof_vel[eD + d];
     }
     didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
-    float lmreg = 0, combias = 0, fric = 0, fat = 0, lastc = 0;
+    float lmreg = 0, combias = 0, fric = 0, fat = 0, lastc = 0, bmass = 1.0f;
+    if (MODE && lane == 0 && io.dr_base_mass) bmass = io.dr_base_mass[env];
     if (lane < c.dr_link_mass_dim) lmreg = io.dr_link_mass[(size_t)env * c.dr_link_mass_dim + lane];
     if (lane < 3) combias = io.dr_base_com[(size_t)env * 3 + lane];
     if (lane == 0) fric = io.dr_friction[env];
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     if (lane == 0) {
       feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
       feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
+      if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
     }
     if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
     if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       f3 e = euler_xyz(rq4);
       misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
       feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
-      feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];
+      if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
       st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
     } else if (lane == 1) {
       st3(feat + c.feat_off[PBHC_F_BASE_LIN_VEL], quat_rotate_inverse(rq4, ld3(root + 7)));
@@ -482,7 +492,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   if (valid) {
     const float a = 1.0f - blend, bb = blend;
     if (lane < D) { rdof[lane] = a * rd0 + bb * rd1; rdofv[lane] = a * rdv0 + bb * rdv1; }
-    if (lane < 2) misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
+    if (lane < 2) {
+      misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
+      if (MODE) feat[c.feat_off[PBHC_F_REF_CONTACT_MASK] + lane] = a * rc0 + bb * rc1;
+    }
     if (lane < Bx) {
       st3(rp + 3 * lane, mk3(a * rp0.x + bb * rp1.x + origin.x, a * rp0.y + bb * rp1.y + origin.y, a * rp0.z + bb * rp1.z + origin.z));
       st4(rq + 4 * lane, slerp(rq0, rq1, bb));
@@ -507,9 +520,22 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // (motion_tracking.py:645-731 and the reductions of the _reward_* terms)
   float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
   float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
+  float s_key = 0, s_keyn = 0, s_lkey = 0, s_lkeyn = 0, s_lkrot = 0, s_kvel = 0, s_kang = 0, s_lupn = 0, s_llon = 0, s_lvrn = 0, s_bodyz = 0;
   if (valid) {
     f4 hinv = ld4(misc + M_HINV);
     f3 rootp = ld3(root);
+    // general tracking: anchor ("beyondmimic") frame, general_tracking.py:738-767 — every lane derives it redundantly (no LDS
+    // round trip).  delta_pos aliases robot_anchor_pos in the reference (:748-749): (robot x, robot y, REF z) is used by both.
+    f4 a_rq = mk4(0, 0, 0, 1), a_bq = a_rq, dori = a_rq, ainv = a_rq;
+    f3 a_rp = mk3(0, 0, 0), a_bp = a_rp, dpos = a_rp;
+    if (MODE) {
+      const int an = c.anchor_index;
+      a_rq = ld4(rq + 4 * an); a_bq = ld4(bq + 4 * an); a_rp = ld3(rp + 3 * an); a_bp = ld3(bp + 3 * an);
+      dori = yaw_quat(quat_mul(a_bq, quat_conj(a_rq)));
+      dpos = mk3(a_bp.x, a_bp.y, a_rp.z);
+      ainv = quat_conj(a_bq);
+    }
+    const int o_lbp = c.feat_off[PBHC_F_LOCAL_BODY_POS], o_lbr = c.feat_off[PBHC_F_LOCAL_BODY_ROT];
     const int o_dif = c.feat_off[PBHC_F_DIF_LOCAL_RIGID_BODY_POS], o_loc = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_POS];
     const int o_vr = c.feat_off[PBHC_F_VR_3POINT_POS], o_lv = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_VEL], o_gv = c.feat_off[PBHC_F_GLOBAL_REF_RIGID_BODY_VEL];
     for (int b = lane; b < Bx; b += PBHC_G) {
@@ -525,12 +551,35 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       if (fl & 8) s_feet += msq;
       s_maxn = fmaxf(s_maxn, nrm);
       f4 dq = ld4(rq + 4 * b), cq = ld4(bq + 4 * b);
-      float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (:651)
-      s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) / 4.0f;
       f3 dv = sub3(ld3(rv + 3 * b), ld3(bv + 3 * b));
-      s_vel += (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) / 3.0f;
+      const float dv2 = (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) / 3.0f;
+      s_vel += dv2;
       f3 dw3 = sub3(ld3(rw + 3 * b), ld3(bw + 3 * b));
-      s_ang += (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) / 3.0f;
+      const float dw2 = (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) / 3.0f;
+      s_ang += dw2;
+      if (!MODE) {
+        float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (motion_tracking.py:651)
+        s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) / 4.0f;
+      } else {
+        // true quaternion difference + its angle (general_tracking.py:643-647,1144,1203); anchor-relative target :750-767
+        const f3 bpos = ld3(bp + 3 * b);
+        const float ang = quat_angle(quat_mul(dq, quat_conj(cq)));
+        s_rot += ang * ang;
+        if (b == c.anchor_index) { red[R_AROT] = ang * ang; red[R_APOS] = msq; }
+        const f3 dl = sub3(add3(dpos, quat_apply(dori, sub3(rpos, a_rp))), bpos);
+        const float l2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z, lnrm = sqrtf(l2);
+        const float lang = quat_angle(quat_mul(quat_mul(dori, dq), quat_conj(cq)));
+        if (fl & 16) {
+          s_key += msq; s_keyn += nrm; s_lkey += l2 / 3.0f; s_lkeyn += lnrm;
+          s_lkrot += lang * lang; s_kvel += dv2; s_kang += dw2;
+        }
+        if (fl & 1) s_lupn += lnrm;
+        if (fl & 2) s_llon += lnrm;
+        if (fl & 4) s_lvrn += lnrm;
+        if ((fl & 32) && fabsf(dl.z) > c.body_z_threshold) s_bodyz = 1.0f;
+        st3(feat + o_lbp + 3 * b, quat_apply(ainv, sub3(bpos, dpos)));           // :779-782
+        quat_to_mat6(quat_mul(ainv, cq), feat + o_lbr + 6 * b);                 // :771-778
+      }
       st3(feat + o_dif + 3 * b, quat_rotate(hinv, dp));
       f3 gl = sub3(rpos, rootp);
       f3 loc = quat_rotate(hinv, gl);
@@ -567,12 +616,40 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     }
     for (int i = lane; i < c.num_penalised; i += PBHC_G)
       if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
+    if (MODE && lane == 0) {
+      // root differences (general_tracking.py:655-666) and the anchor observations / termination signals (:784-803)
+      const f4 rootq = ld4(root + 3);
+      const f3 drv = sub3(quat_rotate_inverse(ld4(rq), ld3(rv)), quat_rotate_inverse(rootq, ld3(root + 7)));
+      st3(feat + c.feat_off[PBHC_F_DIF_ROOT_VELOCITY], drv);
+      red[R_RVEL] = (drv.x * drv.x + drv.y * drv.y + drv.z * drv.z) / 3.0f;
+      const f4 drr = quat_mul(ld4(rq), quat_conj(rootq));
+      st4(feat + c.feat_off[PBHC_F_DIF_ROOT_ROT], drr);
+      const float drh = rp[2] - root[2];
+      feat[c.feat_off[PBHC_F_DIF_ROOT_HEIGHT]] = drh;
+      const float ra = quat_angle(drr);
+      red[R_RPOSE] = ra * ra + drh * drh;
+      quat_to_mat6(quat_mul(ainv, a_rq), feat + c.feat_off[PBHC_F_ANCHOR_REF_ROT]);
+      st3(feat + c.feat_off[PBHC_F_ANCHOR_REF_POS], quat_apply(ainv, sub3(a_rp, a_bp)));
+      const f3 gv = mk3(0.0f, 0.0f, -1.0f);
+      misc[M_ADZ] = a_rp.z - a_bp.z;
+      misc[M_AORI] = quat_rotate_inverse(a_rq, gv).z - quat_rotate_inverse(a_bq, gv).z;
+    }
   }
 #define GSUM(v) v = group_sum(v)
   GSUM(s_up); GSUM(s_lo); GSUM(s_vr); GSUM(s_feet); GSUM(s_rot); GSUM(s_vel); GSUM(s_ang); GSUM(s_upn); GSUM(s_lon); GSUM(s_vrn);
   GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
   s_maxn = group_max(s_maxn); s_maxjp = group_max(s_maxjp);
+  if (MODE) {
+    GSUM(s_key); GSUM(s_keyn); GSUM(s_lkey); GSUM(s_lkeyn); GSUM(s_lkrot); GSUM(s_kvel); GSUM(s_kang); GSUM(s_lupn); GSUM(s_llon); GSUM(s_lvrn);
+    s_bodyz = group_max(s_bodyz);
+  }
   if (valid && lane == 0) {
+    if (MODE) {
+      const float nk = (float)c.num_key;
+      red[R_KEY] = s_key / nk; red[R_KEYN] = s_keyn / nk; red[R_LKEY] = s_lkey / nk; red[R_LKEYN] = s_lkeyn / nk; red[R_LKROT] = s_lkrot / nk;
+      red[R_KVEL] = s_kvel / nk; red[R_KANG] = s_kang / nk;
+      red[R_LUPN] = s_lupn / (float)c.num_upper; red[R_LLON] = s_llon / (float)c.num_lower; red[R_LVRN] = s_lvrn / (float)c.num_track;
+    }
     red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
     red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
     red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
@@ -585,9 +662,16 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
     if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
     float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
+    float refz = 0.0f, refori = 0.0f, bodyz = 0.0f;
+    if (MODE) {                                   // general_tracking.py:241-254
+      if (c.terminate_by_ref_pos_z) refz = fabsf(misc[M_ADZ]) > c.ref_pos_z_threshold ? 1.0f : 0.0f;
+      if (c.terminate_by_ref_ori) refori = fabsf(misc[M_AORI]) > c.ref_ori_threshold ? 1.0f : 0.0f;
+      if (c.terminate_by_body_z) bodyz = s_bodyz;
+      misc[M_REFZ] = refz; misc[M_REFORI] = refori; misc[M_BODYZ] = bodyz;
+    }
     misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
     misc[M_TIMEOUT] = tout;
-    misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f) ? 1.0f : 0.0f;
+    misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f) ? 1.0f : 0.0f;
   }
   LDS_BARRIER();
 
@@ -607,8 +691,19 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_S_BODY_VEL: e = red[R_VEL]; break;
         case PBHC_S_BODY_ANG_VEL: e = red[R_ANG]; break;
         case PBHC_S_JOINT_POS: e = red[R_JP2] / (float)D; break;
-        default: e = red[R_JV2] / (float)D; break;
+        case PBHC_S_JOINT_VEL: e = red[R_JV2] / (float)D; break;
+        case PBHC_S_KEY_BODY_POS: e = red[R_KEY]; break;
+        case PBHC_S_ANCHOR_BODY_POS: e = red[R_APOS]; break;
+        case PBHC_S_ANCHOR_BODY_ROT: e = red[R_AROT]; break;
+        case PBHC_S_LOCAL_KEY_BODY_POS: e = red[R_LKEY]; break;
+        case PBHC_S_LOCAL_KEY_BODY_ROT: e = red[R_LKROT]; break;
+        case PBHC_S_KEY_BODY_VEL: e = red[R_KVEL]; break;
+        case PBHC_S_KEY_BODY_ANG_VEL: e = red[R_KANG]; break;
+        case PBHC_S_ROOT_VEL: e = red[R_RVEL]; break;
+        case PBHC_S_ROOT_POSE: e = red[R_RPOSE]; break;
+        default: e = 0.0f; break;
       }
+      if (!MODE && lane >= PBHC_S_KEY_BODY_POS) e = 0.0f;
       red[R_EXP0 + lane] = expf(-e / pf_sigma);
     } else if (lane < PBHC_NUM_SIGMA + NF) {
       const int f = lane - PBHC_NUM_SIGMA;
@@ -683,6 +778,20 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_R_LIMITS_TORQUE: raw = red[R_LIMTAU]; break;
         case PBHC_R_COLLISION: raw = red[R_COLL]; break;
         case PBHC_R_ALIVE: raw = 1.0f; break;
+        case PBHC_R_TELEOP_CONTACT_MASK_V2: {
+          float e = 0.0f;
+          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
+          raw = 0.5f - e / (float)NF;
+        } break;
+        case PBHC_R_TELEOP_KEY_BODY_POSITION: raw = ex[PBHC_S_KEY_BODY_POS]; break;
+        case PBHC_R_TELEOP_ANCHOR_BODY_POSITION: raw = ex[PBHC_S_ANCHOR_BODY_POS]; break;
+        case PBHC_R_TELEOP_ANCHOR_BODY_ROTATION: raw = ex[PBHC_S_ANCHOR_BODY_ROT]; break;
+        case PBHC_R_LOCAL_KEY_BODY_POSITION: raw = ex[PBHC_S_LOCAL_KEY_BODY_POS]; break;
+        case PBHC_R_LOCAL_KEY_BODY_ROTATION: raw = ex[PBHC_S_LOCAL_KEY_BODY_ROT]; break;
+        case PBHC_R_KEY_BODY_VELOCITY: raw = ex[PBHC_S_KEY_BODY_VEL]; break;
+        case PBHC_R_KEY_BODY_ANG_VELOCITY: raw = ex[PBHC_S_KEY_BODY_ANG_VEL]; break;
+        case PBHC_R_TELEOP_ROOT_VEL: raw = ex[PBHC_S_ROOT_VEL]; break;
+        case PBHC_R_TELEOP_ROOT_POSE: raw = ex[PBHC_S_ROOT_POSE]; break;
         default: raw = 0.0f;
       }
       myrew = raw * pf_tscale;
@@ -719,9 +828,75 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     err[PBHC_S_VR_3POINT_POS] = red[R_VR]; err[PBHC_S_FEET_POS] = red[R_FEET]; err[PBHC_S_BODY_ROT] = red[R_ROT];
     err[PBHC_S_BODY_VEL] = red[R_VEL]; err[PBHC_S_BODY_ANG_VEL] = red[R_ANG]; err[PBHC_S_JOINT_POS] = red[R_JP2] / (float)D;
     err[PBHC_S_JOINT_VEL] = red[R_JV2] / (float)D;
+    if (MODE) {
+      err[PBHC_S_KEY_BODY_POS] = red[R_KEY]; err[PBHC_S_ANCHOR_BODY_POS] = red[R_APOS]; err[PBHC_S_ANCHOR_BODY_ROT] = red[R_AROT];
+      err[PBHC_S_LOCAL_KEY_BODY_POS] = red[R_LKEY]; err[PBHC_S_LOCAL_KEY_BODY_ROT] = red[R_LKROT]; err[PBHC_S_KEY_BODY_VEL] = red[R_KVEL];
+      err[PBHC_S_KEY_BODY_ANG_VEL] = red[R_KANG]; err[PBHC_S_ROOT_VEL] = red[R_RVEL]; err[PBHC_S_ROOT_POSE] = red[R_RPOSE];
+    }
   }
   LDS_BARRIER();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
 
+  // ---------------- general tracking: future reference targets (general_tracking.py:500-565) ------
+  // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
+  // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
+  // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.
+  if (MODE && c.future_num_steps > 0) {
+    const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
+    float* fut = S + Lds::FUT;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
+    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+    int row0 = 0, nf_c = tbl.single_num_frames;
+    float len_c = tbl.single_len, dt_c = tbl.single_dt;
+    if (valid && tbl.num_motions != 1) { row0 = tbl.length_starts[mid]; nf_c = tbl.num_frames[mid]; len_c = tbl.motion_len[mid]; dt_c = tbl.motion_dt[mid]; }
+    const float tb = (float)ep1 * dt + start;
+    if (valid)
+      for (int st = lane; st < NS; st += PBHC_G) {
+        const float t = (float)c.future_steps[st] * dt + tb;
+        int f0, f1; float bl;
+        frame_blend(t, len_c, nf_c, dt_c, &f0, &f1, &bl);
+        const float* q0 = tbl.frames + (size_t)(row0 + f0) * tbl.row;
+        const float* q1 = tbl.frames + (size_t)(row0 + f1) * tbl.row;
+        const float al = 1.0f - bl;
+        const f4 rr = slerp(ld4(q0 + o_rot), ld4(q1 + o_rot), bl);
+        const f3 v0 = ld3(q0 + o_vel), v1 = ld3(q1 + o_vel), w0 = ld3(q0 + o_ang), w1 = ld3(q1 + o_ang);
+        const f3 e = euler_xyz(rr);
+        feat[c.feat_off[PBHC_F_FUT_ROOT_HEIGHT] + st] = al * q0[o_pos + 2] + bl * q1[o_pos + 2] + origin.z;
+        feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st] = e.x;
+        feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st + 1] = e.y;
+        st3(feat + c.feat_off[PBHC_F_FUT_BASE_LIN_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * v0.x + bl * v1.x, al * v0.y + bl * v1.y, al * v0.z + bl * v1.z)));
+        st3(feat + c.feat_off[PBHC_F_FUT_BASE_ANG_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * w0.x + bl * w1.x, al * w0.y + bl * w1.y, al * w0.z + bl * w1.z)));
+        const f4 aq = an == 0 ? rr : slerp(ld4(q0 + o_rot + 4 * an), ld4(q1 + o_rot + 4 * an), bl);
+        const f3 p0 = ld3(q0 + o_pos + 3 * an), p1 = ld3(q1 + o_pos + 3 * an);
+        float* fs = fut + 10 * st;
+        fs[0] = __int_as_float(f0); fs[1] = __int_as_float(f1); fs[2] = bl;
+        st4(fs + 3, quat_conj(aq));
+        st3(fs + 7, mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z));
+      }
+    LDS_BARRIER();
+    if (valid) {
+      const int o_fd = c.feat_off[PBHC_F_FUT_DOF_POS], o_fk = c.feat_off[PBHC_F_FUT_LOCAL_KEY_POS];
+      int st = 0, d = lane;                                        // (step, dof) without divisions: D may be < 32
+      while (d >= D) { d -= D; ++st; }
+      for (; st < NS;) {
+        const float* fs = fut + 10 * st;
+        const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+        const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+        feat[o_fd + st * D + d] = (1.0f - fs[2]) * q0[d] + fs[2] * q1[d];
+        d += PBHC_G;
+        while (d >= D) { d -= D; ++st; }
+      }
+      for (int i = lane; i < NS * Kn; i += PBHC_G) {
+        const int st2 = i / Kn, k = i - st2 * Kn, body = c.key[k];
+        const float* fs = fut + 10 * st2;
+        const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+        const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+        const float bl = fs[2], al = 1.0f - bl;
+        const f3 p0 = ld3(q0 + o_pos + 3 * body), p1 = ld3(q1 + o_pos + 3 * body);
+        const f3 pw = mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z);
+        st3(feat + o_fk + 3 * i, quat_apply(ld4(fs + 3), sub3(pw, ld3(fs + 7))));
+      }
+    }
+    LDS_BARRIER();
+  }
   // optional outputs of the pre-reset state
   if (valid) {
     if (io.ref_body_pos_extend)
@@ -795,7 +970,14 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
     // invalidated, motion_tracking.py:378,536-543,477-507)
     float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
-    motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, red + 46, rp, rq, rv, rw);
+    if (MODE) {
+      // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
+      // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
+      motion_lookup(tbl, D, Bx, lane, mid, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+      motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
+    } else {
+      motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+    }
   }
   LDS_BARRIER();
   if (do_reset && lane == 0) {
@@ -818,7 +1000,11 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       feat[o_kp + d] = io.kp_scale[eD + d];
       feat[o_kd + d] = io.kd_scale[eD + d];
     }
-    if (lane == 0) feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
+    if (lane == 0) {
+      feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
+      feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];              // a live view of the root state in the reference: reset envs show the reset height
+    }
+    if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
   }
   LDS_BARRIER();
 
@@ -899,6 +1085,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       bpq[P_RESET_EPLEN] = misc[M_RESET] != 0.0f ? misc[M_LASTEP] : 0.0f;
       bpq[P_ETR_SUM] = etr_val; bpq[P_ETR_SQ] = etr_val * etr_val;
       bpq[P_REW_SUM] = rew_total;
+      if (MODE) {
+        bpq[P_KEY_NORM] = red[R_KEYN]; bpq[P_LUP_NORM] = red[R_LUPN]; bpq[P_LLO_NORM] = red[R_LLON]; bpq[P_LVR_NORM] = red[R_LVRN];
+        bpq[P_LKEY_NORM] = red[R_LKEYN]; bpq[P_TERM_REFZ] = misc[M_REFZ]; bpq[P_TERM_REFORI] = misc[M_REFORI]; bpq[P_TERM_BODYZ] = misc[M_BODYZ];
+      }
     }
   }
   LDS_BARRIER();
@@ -933,14 +1123,22 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
   __syncthreads();
   if (threadIdx.x != 0) return;
   const double N = (double)c.num_envs;
-  // adaptive sigma (motion_tracking.py:1030-1048, type "origin")
+  // adaptive sigma (motion_tracking.py:1030-1048, general_tracking.py:972-996)
   if (c.adaptive_sigma)
     for (int i = 0; i < PBHC_NUM_SIGMA; ++i)
       if (c.sigma_active[i]) {
         double mean = (double)(float)(tot[P_ERR + i] / N);
         double ema = glob[PBHC_G_EMA + i] * (1.0 - (double)c.adaptive_alpha) + mean * (double)c.adaptive_alpha;
         glob[PBHC_G_EMA + i] = ema;
-        glob[PBHC_G_SIGMA + i] = fmin(ema, glob[PBHC_G_SIGMA + i]);
+        const double sg = glob[PBHC_G_SIGMA + i];
+        double nsg;
+        switch (c.adaptive_type) {
+          case 1: nsg = (fmin(ema, sg) + ema) / 2.0; break;
+          case 2: nsg = fmin(ema * (double)c.adaptive_scale, sg); break;
+          case 3: nsg = ema; break;
+          default: nsg = fmin(ema, sg);
+        }
+        glob[PBHC_G_SIGMA + i] = nsg;
       }
   double* L = glob + PBHC_G_LOG;
   const double nreset = tot[P_RESET_CNT];
@@ -952,6 +1150,13 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
   L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
   L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
   L[PBHC_L_REW_MEAN] = tot[P_REW_SUM] / N;
+  if (c.tracking_mode) {
+    L[PBHC_L_KEY_BODY_DIFF_NORM] = tot[P_KEY_NORM] / N; L[PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM] = tot[P_LUP_NORM] / N;
+    L[PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM] = tot[P_LLO_NORM] / N; L[PBHC_L_LOCAL_VR_3POINT_DIFF_NORM] = tot[P_LVR_NORM] / N;
+    L[PBHC_L_LOCAL_KEY_BODY_DIFF_NORM] = tot[P_LKEY_NORM] / N;
+    L[PBHC_L_TERM_REF_POS_Z] = (tot[P_TERM_REFZ] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_REF_ORI] = (tot[P_TERM_REFORI] / N) / (rfrac + 1e-15);
+    L[PBHC_L_TERM_BODY_Z] = (tot[P_TERM_BODYZ] / N) / (rfrac + 1e-15);
+  }
   if (nreset > 0.0) {
     // _update_average_episode_length (legged_robot_base.py:875-879), fp32 like the reference's 0-dim tensor
     float cur = (float)(tot[P_RESET_EPLEN] / nreset);
@@ -1288,7 +1493,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   ARG_CHECK(cfg->num_groups >= 1 && cfg->num_groups <= PBHC_MAX_GROUPS);
   ARG_CHECK(cfg->queue_len >= 1 && cfg->queue_len <= PBHC_MAX_QUEUE);
   ARG_CHECK(tbl->row == 2 * D + 2 + 13 * Bx && tbl->frames && tbl->num_motions >= 1);
-  ARG_CHECK(cfg->feat_dim > 0 && cfg->feat_dim < 8192);
+  ARG_CHECK(cfg->feat_dim > 0 && cfg->feat_dim < 16384);
   for (int g = 0; g < cfg->num_groups; ++g) ARG_CHECK(cfg->groups[g].dim > 0 && cfg->groups[g].src && cfg->groups[g].scale && cfg->groups[g].noise);
   for (int i = 0; i < PBHC_F_NUM; ++i) ARG_CHECK(cfg->feat_off[i] >= 0 && cfg->feat_off[i] < cfg->feat_dim);
   PbhcEnv* e = new (std::nothrow) PbhcEnv();
@@ -1297,7 +1502,14 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->tbl = *tbl;
   e->d_glob = globals;
   e->nblocks = (cfg->num_envs + PBHC_EPB - 1) / PBHC_EPB;
-  e->lds_stride = Lds::FEAT + ((cfg->feat_dim + 3) & ~3);
+  ARG_CHECK(cfg->tracking_mode == 0 || cfg->tracking_mode == 1);
+  if (cfg->tracking_mode) {
+    ARG_CHECK(cfg->num_key >= 1 && cfg->num_key <= PBHC_MAX_IDX && cfg->anchor_index >= 0 && cfg->anchor_index < Bx);
+    ARG_CHECK(cfg->future_num_steps >= 0 && cfg->future_num_steps <= PBHC_MAX_FUTURE);
+    for (int k = 0; k < cfg->num_key; ++k) ARG_CHECK(cfg->key[k] >= 0 && cfg->key[k] < Bx);
+    for (int k = 0; k < cfg->future_num_steps; ++k) ARG_CHECK(cfg->future_steps[k] >= 0);
+  }
+  e->lds_stride = Lds::feat(cfg->tracking_mode) + ((cfg->feat_dim + 3) & ~3);
   e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + SKC_WORDS + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
   e->step_ctr = 0;
   e->profile = 0;
@@ -1307,7 +1519,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
   HIP_CHECK(hipMemcpy(e->d_cfg, cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
   if (e->lds_bytes > 64 * 1024)
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_env_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+    HIP_CHECK(hipFuncSetAttribute(cfg->tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   *out = e;
   return PBHC_OK;
 }
@@ -1361,8 +1573,10 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int slot = e->prof_count % PBHC_PROFILE_RING;
   if (e->profile) HIP_CHECK(hipEventRecord(e->ev0[slot], st));
-  hipLaunchKernelGGL(k_env_step, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials,
-                     e->lds_stride);
+  if (e->cfg.tracking_mode)
+    hipLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride);
+  else
+    hipLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride);
   if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
   hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames);
   e->step_ctr++;

@@ -112,6 +112,35 @@ __device__ __forceinline__ f3 euler_xyz(f4 q) {
   return mk3(roll, pitch, atan2f(siny, cosy));
 }
 
+// ---- general-tracking helpers (humanoidverse/utils/torch_utils.py) ------------------------------
+// torch_utils.py:51-57 quat_apply: b + w t + xyz x t, t = 2 (xyz x b)
+__device__ __forceinline__ f3 quat_apply(f4 q, f3 b) {
+  f3 xyz = mk3(q.x, q.y, q.z);
+  f3 t = mul3(cross3(xyz, b), 2.0f);
+  f3 u = cross3(xyz, t);
+  return mk3(b.x + q.w * t.x + u.x, b.y + q.w * t.y + u.y, b.z + q.w * t.z + u.z);
+}
+// torch_utils.py:239-270 yaw_quat (xyzw)
+__device__ __forceinline__ f4 yaw_quat(f4 q) {
+  float yaw = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
+  return quat_unit(mk4(0.0f, 0.0f, sinf(yaw / 2.0f), cosf(yaw / 2.0f)));
+}
+// torch_utils.py:274-296 matrix_from_quat(...)[..., :2] flattened: m00 m01 m10 m11 m20 m21
+__device__ __forceinline__ void quat_to_mat6(f4 q, float* o) {
+  const float i = q.x, j = q.y, k = q.z, r = q.w;
+  const float two_s = 2.0f / (i * i + j * j + k * k + r * r);
+  o[0] = 1.0f - two_s * (j * j + k * k); o[1] = two_s * (i * j - k * r);
+  o[2] = two_s * (i * j + k * r);        o[3] = 1.0f - two_s * (i * i + k * k);
+  o[4] = two_s * (i * k - j * r);        o[5] = two_s * (j * k + i * r);
+}
+// rotations.py:185-207 quat_to_angle_axis(q)[0]: normalize_angle(2 acos w), zero where sqrt(1-w^2) <= 1e-5 (or NaN)
+__device__ __forceinline__ float quat_angle(f4 q) {
+  const float st = sqrtf(1.0f - q.w * q.w);
+  float a = 2.0f * acosf(q.w);
+  a = atan2f(sinf(a), cosf(a));
+  return (fabsf(st) > 1e-5f) ? a : 0.0f;
+}
+
 // ---- wxyz helpers of the motion-library FK (rotations.py:519-636) --------------------------
 struct m33 { float m[9]; };
 __device__ __forceinline__ m33 quat_wxyz_to_matrix(float r, float i, float j, float k) {

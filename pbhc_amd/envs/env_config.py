@@ -21,12 +21,19 @@ from .. import _lib
 K = _lib.K
 
 SIGMA_KEYS = ["teleop_max_joint_pos", "teleop_upper_body_pos", "teleop_lower_body_pos", "teleop_vr_3point_pos", "teleop_feet_pos",
-              "teleop_body_rot", "teleop_body_vel", "teleop_body_ang_vel", "teleop_joint_pos", "teleop_joint_vel"]
+              "teleop_body_rot", "teleop_body_vel", "teleop_body_ang_vel", "teleop_joint_pos", "teleop_joint_vel",
+              # general tracking (rewards/motion_tracking/general_main.yaml)
+              "teleop_key_body_pos", "teleop_anchor_body_pos", "teleop_anchor_body_rot", "local_key_body_pos", "local_key_body_rot",
+              "key_body_vel", "key_body_ang_vel", "teleop_root_vel", "teleop_root_pose"]
 TERM_SIGMAS = {
     "teleop_max_joint_position": [0], "teleop_body_position_extend": [1, 2], "teleop_vr_3point": [3], "teleop_body_position_feet": [4],
     "teleop_body_rotation_extend": [5], "teleop_body_velocity_extend": [6], "teleop_body_ang_velocity_extend": [7],
     "teleop_joint_position": [8], "teleop_joint_velocity": [9],
+    "teleop_key_body_position": [10], "teleop_anchor_body_position": [11], "teleop_anchor_body_rotation": [12], "local_key_body_position": [13],
+    "local_key_body_rotation": [14], "key_body_velocity": [15], "key_body_ang_velocity": [16], "teleop_root_vel": [17], "teleop_root_pose": [18],
 }
+V2_ONLY_TERMS = {"teleop_key_body_position", "teleop_anchor_body_position", "teleop_anchor_body_rotation", "local_key_body_position",
+                 "local_key_body_rotation", "key_body_velocity", "key_body_ang_velocity", "teleop_root_vel", "teleop_root_pose", "teleop_contact_mask_v2"}
 OBS_FEATURES = {
     "base_lin_vel": "BASE_LIN_VEL", "base_ang_vel": "BASE_ANG_VEL", "projected_gravity": "PROJECTED_GRAVITY", "dof_pos": "DOF_POS",
     "dof_vel": "DOF_VEL", "actions": "ACTIONS", "ref_motion_phase": "REF_MOTION_PHASE",
@@ -35,6 +42,20 @@ OBS_FEATURES = {
     "dr_friction": "DR_FRICTION", "dr_ctrl_delay": "DR_CTRL_DELAY", "relyaw": "RELYAW", "base_pos_z": "BASE_POS_Z",
     "dif_joint_angles": "DIF_JOINT_ANGLES", "dif_joint_velocities": "DIF_JOINT_VELOCITIES",
     "local_ref_rigid_body_vel": "LOCAL_REF_RIGID_BODY_VEL", "global_ref_rigid_body_vel": "GLOBAL_REF_RIGID_BODY_VEL",
+}
+# general tracking getters (general_tracking.py:821-954): plain features ...
+OBS_FEATURES_V2 = {
+    "roll_pitch": "ROLL_PITCH", "root_height": "BASE_POS_Z", "contact_mask": "CONTACT_MASK", "ref_contact_mask": "REF_CONTACT_MASK",
+    "dr_base_mass": "DR_BASE_MASS", "anchor_ref_pos": "ANCHOR_REF_POS", "anchor_ref_rot": "ANCHOR_REF_ROT",
+    "dif_root_velocity": "DIF_ROOT_VELOCITY", "dif_root_rot": "DIF_ROOT_ROT", "dif_root_height": "DIF_ROOT_HEIGHT",
+}
+# ... and keys that are gathers out of per-body / per-step feature tables: key -> features they read
+OBS_GATHERS_V2 = {
+    "local_key_body_pos": ["LOCAL_BODY_POS"], "local_key_body_rot": ["LOCAL_BODY_ROT"], "dif_local_key_body_pos": ["DIF_LOCAL_RIGID_BODY_POS"],
+    "local_ref_key_body_pos": ["LOCAL_REF_RIGID_BODY_POS"], "future_motion_root_height": ["FUT_ROOT_HEIGHT"], "future_motion_roll_pitch": ["FUT_ROLL_PITCH"],
+    "future_motion_base_lin_vel": ["FUT_BASE_LIN_VEL"], "future_motion_base_ang_vel": ["FUT_BASE_ANG_VEL"], "future_motion_base_yaw_vel": ["FUT_BASE_ANG_VEL"],
+    "future_motion_dof_pos": ["FUT_DOF_POS"], "future_motion_local_ref_key_body_pos": ["FUT_LOCAL_KEY_POS"],
+    "next_step_ref_motion": ["FUT_ROOT_HEIGHT", "FUT_ROLL_PITCH", "FUT_BASE_LIN_VEL", "FUT_BASE_ANG_VEL", "FUT_DOF_POS", "FUT_LOCAL_KEY_POS"],
 }
 
 
@@ -72,7 +93,8 @@ class EnvLayout:
     """Everything the host needs to know about the layouts the kernels use."""
 
 
-def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
+def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mode=0):
+    """mode 0: LeggedRobotMotionTracking, mode 1: LeggedRobotGeneralTracking."""
     ec = cfg.env.config
     rc = cfg.robot
     rw = cfg.rewards
@@ -84,6 +106,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
     c = _lib.PbhcEnvConfig()
     L = EnvLayout()
     c.abi_version = K["PBHC_ABI_VERSION"]
+    c.tracking_mode = mode
     c.num_envs = num_envs
     c.skel = skel.to_c()
     sim = cfg.simulator.config.sim
@@ -162,10 +185,21 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
         c.lower[i] = b
     for i, b in enumerate(track):
         c.track[i] = b
+    key_ids, body_z = [], []
+    if mode == 1:
+        key_ids = [ext.index(l) for l in rc.key_bodies]                      # general_tracking.py:94-95
+        anchor_link = m.get("anchor_link", "pelvis_link")
+        c.anchor_index = (names.index(anchor_link) if anchor_link in names else -1) + 1      # find_rigid_body_indice(...) + 1, sic (:97-98)
+        c.num_key = len(key_ids)
+        for i, b in enumerate(key_ids):
+            c.key[i] = b
+        body_z = [4, 10, 24, 25, 26]                                          # hard-coded in the reference (:253)
     for b in range(Bx):
-        c.body_flags[b] = (1 if b in upper else 0) | (2 if b in lower else 0) | (4 if b in track else 0) | (8 if b in feet else 0)
+        c.body_flags[b] = ((1 if b in upper else 0) | (2 if b in lower else 0) | (4 if b in track else 0) | (8 if b in feet else 0)
+                           | (16 if b in key_ids else 0) | (32 if b in body_z else 0))
         c.track_slot[b] = track.index(b) if b in track else -1
-    L.feet, L.penalised, L.upper, L.lower, L.track = feet, pen, upper, lower, track
+        c.key_slot[b] = key_ids.index(b) if b in key_ids else -1
+    L.feet, L.penalised, L.upper, L.lower, L.track, L.key = feet, pen, upper, lower, track, key_ids
     # ---- termination
     T = ec.termination
     for flag in ("terminate_by_contact", "terminate_by_low_height", "terminate_when_close_to_dof_pos_limit",
@@ -176,6 +210,20 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
     c.termination_gravity = float(ec.termination_scales.termination_gravity)
     c.terminate_when_motion_far = int(bool(T.terminate_when_motion_far))
     c.terminate_when_motion_end = int(bool(T.terminate_when_motion_end))
+    ts = ec.termination_scales
+    if mode == 1:                                                             # general_tracking.py:241-254
+        c.terminate_by_ref_pos_z = int(bool(T.get("terminate_by_ref_pos_z", False)))
+        c.terminate_by_ref_ori = int(bool(T.get("terminate_by_ref_ori", False)))
+        c.terminate_by_body_z = int(bool(T.get("terminate_by_body_z", False)))
+        c.ref_pos_z_threshold = float(ts.get("terminate_by_ref_pos_z_threshold", 0.25))
+        c.ref_ori_threshold = float(ts.get("terminate_by_ref_ori_threshold", 0.8))
+        c.body_z_threshold = float(ts.get("terminate_by_body_z_threshold", 0.25))
+        if c.terminate_by_body_z and max(body_z) >= Bx:
+            raise IndexError(f"terminate_by_body_z indexes body {max(body_z)} of {Bx}")      # the reference would raise the same way
+        if T.get("terminate_when_local_motion_far", False):
+            pass                                                              # read by nobody in the reference either
+    elif any(T.get(k, False) for k in ("terminate_by_ref_pos_z", "terminate_by_ref_ori", "terminate_by_body_z")):
+        raise NotImplementedError("general-tracking terminations need env._target_ ...general_tracking.LeggedRobotGeneralTracking")
     tc = ec.termination_curriculum
     c.motion_far_curriculum = int(bool(tc.terminate_when_motion_far_curriculum))
     c.motion_far_degree = float(tc.terminate_when_motion_far_curriculum_degree)
@@ -200,7 +248,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
     pen_names = set(rw.reward_penalty_reward_names)
     for i, name in enumerate(L.reward_names):
         key = "PBHC_R_" + name.upper()
-        if key not in K:
+        if key not in K or (mode == 0 and name in V2_ONLY_TERMS):
             raise NotImplementedError(f"reward term {name!r} has no HIP implementation")
         c.term_id[i] = K[key]
         c.term_scale[i] = float(scales[name])
@@ -220,8 +268,12 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
     c.max_contact_force = float(rw.get("locomotion_max_contact_force", 0.0))
     ats = rw.get("adaptive_tracking_sigma", {})
     c.adaptive_sigma = int(bool(ats.get("enable", False)))
-    if c.adaptive_sigma and ats.get("type", "origin") != "origin":
-        raise NotImplementedError("adaptive_tracking_sigma.type other than 'origin'")
+    atype = ats.get("type", "origin")
+    if atype not in ("origin", "mean", "scale"):
+        atype = None                                       # the reference's if/elif chain leaves sigma untouched (only the EMA moves)
+        raise NotImplementedError(f"adaptive_tracking_sigma.type {ats.get('type')!r}")
+    c.adaptive_type = {"origin": 0, "mean": 3 if mode == 1 else 1, "scale": 2}[atype]
+    c.adaptive_scale = float(ats.get("scale", 1.0))
     c.adaptive_alpha = float(ats.get("alpha", 0.0))
     c.penalty_curriculum = int(bool(rw.reward_penalty_curriculum))
     c.penalty_degree = float(rw.reward_penalty_degree)
@@ -241,7 +293,30 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
     c.soft_torque_limit = float(rw.reward_limit.soft_torque_limit)
     # ---- features
     groups, dims, aux = determine_obs_dim(cfg)
-    L.obs_dims, L.group_dims = dims, groups
+    S = int(ob.get("future_num_steps", 0)) if mode == 1 else 0
+    if S:
+        steps = torch.linspace(start=1, end=ob.future_max_steps, steps=S, dtype=torch.long).tolist()      # general_tracking.py:501-507
+        if S > K["PBHC_MAX_FUTURE"]:
+            raise _lib.PbhcError("too many future steps")
+        c.future_num_steps = S
+        for i, v in enumerate(steps):
+            c.future_steps[i] = int(v)
+        L.future_steps = steps
+    Kb = len(key_ids)
+    feats = dict(OBS_FEATURES)
+    if mode == 1:
+        feats.update(OBS_FEATURES_V2)
+    mult = lambda k: S if (k.startswith("future_motion_") and S) else 1       # future keys list their PER-STEP dim (obs_ppo_teacher.yaml)
+    # widths of the tensors the env hands out: the future group is [N, S * per-step dim] (ppo_mimic.py:206-216)
+    L.obs_dims = dims
+    L.group_dims = {}
+    for g, keys in ob.obs_dict.items():
+        tot = 0
+        for key_ in keys:
+            k_ = key_[:-4] if key_.endswith("_raw") else key_
+            tot += dims[k_] * mult(k_) if k_ in dims else aux[k_]
+        L.group_dims[g] = tot
+    groups = L.group_dims
     hist_len = {}
     for aux_cfg in ob.obs_auxiliary.values():
         for k, n in aux_cfg.items():
@@ -259,17 +334,24 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
         "DR_BASE_COM": 3, "DR_LINK_MASS": max(sim_link_mass_dim, 1), "DR_KP": D, "DR_KD": D, "DR_FRICTION": 1, "DR_CTRL_DELAY": 1,
         "RELYAW": 1, "BASE_POS_Z": 1, "DIF_JOINT_ANGLES": D, "DIF_JOINT_VELOCITIES": D, "LOCAL_REF_RIGID_BODY_VEL": 3 * Bx,
         "GLOBAL_REF_RIGID_BODY_VEL": 3 * Bx, "HISTORY": c.hist_dim, "ZERO": 1,
+        "ROLL_PITCH": 2, "CONTACT_MASK": 2, "DR_BASE_MASS": 1, "LOCAL_BODY_POS": 3 * Bx, "LOCAL_BODY_ROT": 6 * Bx, "ANCHOR_REF_POS": 3,
+        "ANCHOR_REF_ROT": 6, "DIF_ROOT_VELOCITY": 3, "DIF_ROOT_ROT": 4, "DIF_ROOT_HEIGHT": 1, "REF_CONTACT_MASK": 2,
+        "FUT_ROOT_HEIGHT": max(S, 1), "FUT_ROLL_PITCH": max(2 * S, 1), "FUT_BASE_LIN_VEL": max(3 * S, 1), "FUT_BASE_ANG_VEL": max(3 * S, 1),
+        "FUT_DOF_POS": max(S * D, 1), "FUT_LOCAL_KEY_POS": max(S * Kb * 3, 1),
     }
     # which features do the observation maps read?  the kernel skips the others (feat_off = -1)
     used = {"HISTORY", "ZERO"}
+    def mark(k):
+        if k in feats:
+            used.add(feats[k])
+        elif mode == 1 and k in OBS_GATHERS_V2:
+            used.update(OBS_GATHERS_V2[k])
+
     for keys in ob.obs_dict.values():
         for key in keys:
-            k = key[:-4] if key.endswith("_raw") else key
-            if k in OBS_FEATURES:
-                used.add(OBS_FEATURES[k])
+            mark(key[:-4] if key.endswith("_raw") else key)
     for hk in hist_keys:
-        if hk in OBS_FEATURES:
-            used.add(OBS_FEATURES[hk])
+        mark(hk)
     off = 0
     feat_off = {}
     for name, n in fdim.items():
@@ -296,12 +378,40 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0):
                 base = feat_off["HISTORY"] + hist_off[hk]
                 idx.extend(range(base, base + n * dims[hk]))
             return idx
-        if key not in OBS_FEATURES:
+        if mode == 1 and key in OBS_GATHERS_V2:
+            fo = lambda f: feat_off[f]
+            per_body = lambda f, w: [fo(f) + w * b + j for b in key_ids for j in range(w)]
+            if key == "local_key_body_pos":
+                idx = per_body("LOCAL_BODY_POS", 3)
+            elif key == "local_key_body_rot":
+                idx = per_body("LOCAL_BODY_ROT", 6)
+            elif key == "dif_local_key_body_pos":
+                idx = per_body("DIF_LOCAL_RIGID_BODY_POS", 3)
+            elif key == "local_ref_key_body_pos":
+                idx = per_body("LOCAL_REF_RIGID_BODY_POS", 3)
+            elif key == "future_motion_base_yaw_vel":
+                idx = [fo("FUT_BASE_ANG_VEL") + 3 * st + 2 for st in range(S)]
+            elif key == "next_step_ref_motion":                       # step-0 slices, general_tracking.py:554-564
+                idx = ([fo("FUT_ROOT_HEIGHT")] + [fo("FUT_ROLL_PITCH") + j for j in range(2)] + [fo("FUT_BASE_LIN_VEL") + j for j in range(3)]
+                       + [fo("FUT_BASE_ANG_VEL") + 2] + [fo("FUT_DOF_POS") + j for j in range(D)] + [fo("FUT_LOCAL_KEY_POS") + j for j in range(3 * Kb)])
+            else:
+                f = OBS_GATHERS_V2[key][0]
+                idx = list(range(fo(f), fo(f) + fdim[f]))
+            if (key.startswith("future_") or key == "next_step_ref_motion") and not S:
+                raise _lib.PbhcError(f"observation {key!r} needs obs.future_num_steps > 0")
+            if len(idx) != dims[key] * mult(key):
+                raise _lib.PbhcError(f"obs_dims[{key}]={dims[key]} does not match the {len(idx)} values the env produces")
+            return idx
+        if key not in feats:
             raise NotImplementedError(f"observation {key!r} has no HIP implementation")
-        f = OBS_FEATURES[key]
+        f = feats[key]
         if dims[key] > fdim[f]:
             raise _lib.PbhcError(f"obs_dims[{key}]={dims[key]} exceeds the feature size {fdim[f]}")
-        return list(range(feat_off[f], feat_off[f] + dims[key]))
+        idx = list(range(feat_off[f], feat_off[f] + dims[key]))
+        if key == "dof_vel" and mode == 1 and ob.get("masked_dof_vel", False):       # general_tracking.py:821-829
+            for j in (4, 5, 10, 11):
+                idx[j] = feat_off["ZERO"]
+        return idx
 
     # ---- output maps.  Old-history elements (scale 1, no noise) are scattered arithmetically by the kernel ("early"); the
     # maps list the remaining elements as (dst, src, scale, noise).

@@ -30,6 +30,8 @@ def get_class(path):
 
 
 class LeggedRobotMotionTracking:
+    TRACKING_MODE = 0          # selects the kernel instantiation (see PbhcEnvConfig.tracking_mode)
+
     def __init__(self, config, device):
         """config = cfg.env.config (with .robot/.obs/.rewards/.domain_rand/.terrain/.simulator aliased
         to the top-level nodes, as Hydra composes it)."""
@@ -67,14 +69,15 @@ class LeggedRobotMotionTracking:
         self.skeleton = self.simulator.skeleton
         rc.motion.step_dt = self.dt
         self._motion_lib = MotionLib.from_config(rc.motion, self.skeleton, N, dev)
-        self._motion_lib.load_motions(random_sample=not self.is_evaluating)
+        self._load_motions_initial()
         for e in rc.motion.get("extend_config", []):
             self.simulator._body_list.append(e["joint_name"])           # motion_tracking.py:226
         self.num_extend_bodies = len(rc.motion.get("extend_config", []))
         # ---- static config -> device
         top = _TopView(config)
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
-        self._c, self.layout = env_config.build(top, self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1], seed=seed)
+        self._c, self.layout = env_config.build(top, self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1], seed=seed,
+                                                mode=self.TRACKING_MODE)
         L = self.layout
         self.reward_names = L.reward_names
         self.reward_scales = L.reward_scales
@@ -96,6 +99,9 @@ class LeggedRobotMotionTracking:
         self.common_step_counter = 0
         self._resample_motion_times(torch.arange(N, device=dev))
         self.init_done = True
+
+    def _load_motions_initial(self):
+        self._motion_lib.load_motions(random_sample=not self.is_evaluating)            # motion_tracking.py:176-180
 
     # ------------------------------------------------------------------------------------
     def __del__(self):
@@ -191,6 +197,7 @@ class LeggedRobotMotionTracking:
         io.env_origins = p(self.env_origins)
         self._friction_flat = s.friction_coeffs.reshape(self.num_envs, -1).contiguous()
         io.dr_base_com, io.dr_link_mass, io.dr_friction = p(s._base_com_bias), p(s._link_mass_scale.contiguous()), p(self._friction_flat)
+        io.dr_base_mass = p(s._base_mass_scale)
         L = self.layout
         for i, g in enumerate(L.group_names[:-1]):
             io.obs[i] = p(self.obs_buf_dict[g])
@@ -235,6 +242,12 @@ class LeggedRobotMotionTracking:
     def reset_all(self):
         """base_task.py:83-93: reset every env, then one step with zero actions.  Start-up path,
         done with torch ops on the device (the per-step reset of terminated envs is in the kernel)."""
+        self._reset_all_state()
+        obs_dict, _, _, _ = self.step({"actions": torch.zeros(self.num_envs, self.dim_actions, device=self.device)})
+        return obs_dict
+
+    def _reset_all_state(self):
+        """reset_envs_idx(arange(N)) (legged_robot_base.py:491-517)."""
         N, dev = self.num_envs, self.device
         ids = torch.arange(N, device=dev)
         g = self.globals
@@ -279,14 +292,14 @@ class LeggedRobotMotionTracking:
         # _reset_dofs / _reset_root_states from the reference frame at (0+1)*dt + start
         ref = self._motion_lib.get_motion_state(self.motion_ids, (self._episode_length_buf + 1) * self.dt + self.motion_start_times, offset=self.env_origins)
         s = self.simulator
-        s.dof_pos.copy_(ref["dof_pos"]); s.dof_vel.copy_(ref["dof_vel"])
+        ref_dof = ref if self.TRACKING_MODE == 0 else self._motion_lib.get_motion_state(       # general_tracking.py:463-476: t = ep_len*dt + start
+            self.motion_ids, self._episode_length_buf * self.dt + self.motion_start_times, offset=self.env_origins)
+        s.dof_pos.copy_(ref_dof["dof_pos"]); s.dof_vel.copy_(ref_dof["dof_vel"])
         s.robot_root_states[:, 0:3] = ref["root_pos"]; s.robot_root_states[:, 3:7] = ref["root_rot"]
         s.robot_root_states[:, 7:10] = ref["root_vel"]; s.robot_root_states[:, 10:13] = ref["root_ang_vel"]
         self.extras["episode"] = {"rew_" + k: (v / self.max_episode_length_s).clone() for k, v in self.episode_sums.items()}
         self._episode_sums.zero_()
         self.extras["time_outs"] = self.time_out_buf
-        obs_dict, _, _, _ = self.step({"actions": torch.zeros(N, self.dim_actions, device=dev)})
-        return obs_dict
 
     def step(self, actor_state):
         """legged_robot_base.py:239-265 — one fused launch."""

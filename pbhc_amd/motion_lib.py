@@ -121,10 +121,12 @@ class MotionLib:
 
     # ---- slot -> clip assignment (load_motions, motion_lib_base.py:293-305) -----------------
     def load_motions(self, random_sample=True, start_idx=0):
+        # in place: the step kernel holds the pointer of this tensor
         if random_sample:
-            self.slot_clip = torch.multinomial(self._sampling_prob, num_samples=self.num_envs, replacement=True)
+            self.slot_clip.copy_(torch.multinomial(self._sampling_prob, num_samples=self.num_envs, replacement=True))
         else:
-            self.slot_clip = torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions)
+            self.slot_clip.copy_(torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions))
+        self._curr_motion_ids = self.slot_clip
         return self.slot_clip
 
     def get_motion_length(self, slot_ids=None):

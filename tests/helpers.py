@@ -62,8 +62,11 @@ PPO_V2_NARROW = {
 STUB = "pbhc_amd.simulator.replay_stub.ReplaySimStub"
 
 
-def build_hip_env(cfgname, num_envs, device="cuda:0", noise_off=True, overrides=None):
-    from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking
+def build_hip_env(cfgname, num_envs, device="cuda:0", noise_off=True, overrides=None, general=False):
+    if general:
+        from pbhc_amd.envs.general_tracking import LeggedRobotGeneralTracking as LeggedRobotMotionTracking
+    else:
+        from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking
 
     ov = {"num_envs": num_envs, "simulator._target_": STUB}
     ov.update(overrides or {})
@@ -112,6 +115,8 @@ def load_state_into_hip_env(env, st, g=None):
         s._base_com_bias.copy_(torch.from_numpy(g["base_com_bias"]).to(dev))
         s._link_mass_scale.copy_(torch.from_numpy(g["link_mass_scale"]).to(dev))
         s.friction_coeffs.copy_(torch.from_numpy(g["friction_coeffs"]).to(dev))
+        if "base_mass_scale" in g:
+            s._base_mass_scale.copy_(torch.from_numpy(g["base_mass_scale"]).to(dev))
 
 
 def synth_replay(ml, skel, N, T, start_times, ep_len, dt, origins, seed, feet, has_contact=True):

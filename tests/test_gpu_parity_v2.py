@@ -1,0 +1,58 @@
+"""GPU parity of the general-tracking (KungfuBot2, MODE 1) step: the HIP path through the C ABI against traces of the reference's
+own LeggedRobotGeneralTracking.step (tests/golden/env_v2_*.npz).  Tolerances as in test_gpu_parity.py; the angle of a near-identity
+quaternion difference, 2 acos(w), is ill-conditioned in fp32 (d angle = 2 dw / sin(angle/2)), which the angle-based rewards inherit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, build_hip_env, load_state_into_hip_env, state_dict_from_golden
+from tests.test_gpu_parity import ANGVEL, SLERP, close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CASES = [("student23", "v2_g1_23dof_student.yaml"), ("teacher29", "v2_g1_29dof_teacher.yaml")]
+
+
+@pytest.mark.parametrize("tag,cfgname", CASES)
+def test_general_tracking_step_matches_reference_trace(tag, cfgname):
+    g = dict(np.load(os.path.join(GOLDEN, f"env_v2_{tag}.npz")))
+    T, N, D = g["actions_in"].shape
+    cfg, env = build_hip_env(cfgname, N, general=True, overrides={"domain_rand.push_robots": False})
+    assert env.reward_names == list(g["reward_names"])
+    assert env.key_body_id == list(g["key_body_id"]) and env.anchor_index == int(g["anchor_index"])
+    load_state_into_hip_env(env, state_dict_from_golden(g), g)
+    dev = env.device
+    tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    env.simulator.set_replay(tg(g["replay_root"]), tg(g["replay_dof_pos"]), tg(g["replay_dof_vel"]), tg(g["replay_contact"]))
+    for k in range(T):
+        st = lambda name, dt=torch.float32: tg(g["step__state__" + name][k]).to(dt)
+        env.set_injected_draws(u_rfi=tg(g["step__u_rfi"][k]), start_time=st("motion_start_times"), kp=st("kp_scale"), kd=st("kd_scale"),
+                               rfi_lim=st("rfi_lim_scale"), rao=st("rao_scale"), delay=st("action_delay_idx", torch.long))
+        obs, rew, reset, extras = env.step({"actions": tg(g["actions_in"][k])})
+        torch.cuda.synchronize()
+        w = f"{tag} step {k}: "
+        assert torch.equal(reset.cpu(), torch.from_numpy(g["step__reset_buf_out"][k])), w + "reset_buf"
+        assert torch.equal(extras["time_outs"].cpu(), torch.from_numpy(g["step__time_outs"][k])), w + "time_outs"
+        close(extras["ref_body_pos_extend"], g["step__ref_body_pos_extend"][k], 2e-5, w + "ref_body_pos_extend")
+        close(rew, g["step__rew_buf"][k], 3e-5, w + "rew_buf", rtol=2e-4)
+        assert set(obs.keys()) == {"actor_obs", "priv_obs", "future_motion_targets", "prop_history"}
+        for ok in obs:
+            close(obs[ok], g["step__obs__" + ok][k], 3e-5, w + ok, **SLERP)
+        for name in ["torques", "last_contacts", "actions", "last_actions", "action_queue", "motion_len", "end_time_ratio_buf", "contacts_filt",
+                     "last_dof_vel", "motion_start_times"]:
+            close(getattr(env, name), g["step__state__" + name][k], 3e-5, w + "state " + name)
+        close(env.simulator.dof_pos, g["step__state__dof_pos"][k], 3e-5, w + "dof_pos")
+        close(env.simulator.dof_vel, g["step__state__dof_vel"][k], 3e-5, w + "dof_vel", rtol=1e-4)
+        close(env.simulator.robot_root_states[:, :10], g["step__state__root_states"][k][:, :10], 3e-5, w + "root_states", **SLERP)
+        close(env.simulator.robot_root_states[:, 10:], g["step__state__root_states"][k][:, 10:], 3e-5, w + "root ang vel", **ANGVEL)
+        assert torch.equal(env.episode_length_buf.cpu(), torch.from_numpy(g["step__state__episode_length_buf"][k]))
+        for name, col in env.episode_sums.items():
+            close(col, g["step__state__sum__" + name][k], 3e-5, w + "sum " + name, rtol=2e-4)
+        for name, view in env.history.items():
+            close(view, g["step__state__hist__" + name][k], 3e-5, w + "hist " + name)
+        log = env.read_log()
+        for lk in ["terminate_by_ref_pos_z", "terminate_by_ref_ori", "terminate_by_body_z", "terminate_by_time_out", "terminate_by_motion_end",
+                   "key_body_diff_norm", "local_key_body_diff_norm", "local_upper_body_diff_norm", "joint_pos_diff_norm", "action_clip_frac"]:
+            close(torch.tensor(log[lk]), g["step__log__" + lk][k], 1e-4, w + "log " + lk)
