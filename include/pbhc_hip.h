@@ -374,8 +374,10 @@ int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, co
  * mu [B,A], std [A] (the actor's `std` parameter), value [B,R]; batch tensors as the reference's storage keys
  * (actions [B,A], old_logp [B], old_mu/old_sigma [B,A], adv [B], returns/old_values [B,R]).
  * Out: grad_mu = d(actor_loss)/d(mu) [B,A], grad_value = d(critic_loss)/d(value) [B,R], grad_std [A] (surrogate part and the
- * entropy bonus), scalars[4] = {surrogate loss, value loss, entropy, mean KL}.  If adapt_lr != 0 the adaptive-KL rule
- * (mh_ppo.py:455-466) is applied to lr[0] (actor) and lr[1] (critic) on the device.
+ * entropy bonus), scalars[4] = {surrogate loss, value loss, entropy, mean KL}.  adapt_lr bit 0: apply the adaptive-KL rule
+ * (mh_ppo.py:455-466) to lr[0] (actor) and lr[1] (critic) on the device; bit 1: the KL of ppo_mimic.py:621-628
+ * (log(sigma / (old_sigma + 1e-5)) instead of log(sigma / old_sigma + 1e-5)).  `std` is the sigma vector the distribution used
+ * (mh_ppo: the parameter; ppo_mimic: clamp(std, min_sigma, max_sigma), the caller masks grad_std accordingly).
  * scratch: pbhc_ppo_loss_scratch_floats(B) floats. */
 int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
                   const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,
@@ -383,11 +385,12 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
                   float* grad_std, float* scalars, float* lr, float* scratch, void* stream);
 int pbhc_ppo_loss_scratch_floats(int B);
 
-/* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524) over ONE flat fp32 segment of n
+/* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,
+ * ppo_mimic.py:184-190,682-686) over ONE flat fp32 segment of n
  * parameters (param/grad/exp_avg/exp_avg_sq flat views; lr and step are device scalars, step is incremented).
  * scratch: 512 doubles.  norm_out (may be NULL): the pre-clip gradient norm. */
 int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
-                   float beta2, float eps, double* scratch, float* norm_out, void* stream);
+                   float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

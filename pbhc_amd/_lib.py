@@ -117,7 +117,7 @@ def _load():
     lib.pbhc_env_profile_read.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(C.c_int)]
     lib.pbhc_ppo_loss.argtypes = [vp] * 10 + [i, i, i, f, f, f, i, f, i] + [vp] * 6 + [vp]
     lib.pbhc_ppo_loss_scratch_floats.argtypes = [i]
-    lib.pbhc_adam_clip.argtypes = [vp, vp, vp, vp, i, vp, vp, f, f, f, f, vp, vp, vp]
+    lib.pbhc_adam_clip.argtypes = [vp, vp, vp, vp, i, vp, vp, f, f, f, f, f, vp, vp, vp]
     lib.pbhc_policy_sample.argtypes = [vp, vp, vp, i, i, i, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.pbhc_rollout_post.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp]
     lib.pbhc_gae.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp]

@@ -1,0 +1,166 @@
+"""Networks of the general-tracking (KungfuBot2) agent: Actor (motion ConvEncoder + history ConvEncoder | priv MLP -> MLP) and
+ActorCritic, with the reference's `state_dict()` key names so checkpoints load both ways with `strict=True`
+(reference: humanoidverse/agents/modules/agent_modules.py:11-166, encoder_modules.py:22-107, modules.py:5-66).
+
+The two Conv1d layers of an encoder see 20 (or 10) time steps and leave 3: each is evaluated as ONE GEMM over the unfolded
+windows (`[B*L, C_in*k] x [C_in*k, C_out]`, rocBLAS/hipBLASLt) in the `[B, T, C]` layout the per-step Linear already produces,
+instead of a per-row MIOpen convolution; the parameters keep nn.Conv1d's shapes and names.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions import Normal
+
+from .modules import BaseModule
+
+_CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
+
+
+class ConvEncoder(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict, time_steps):
+        super().__init__()
+        self.obs_dim_dict = obs_dim_dict
+        self.module_config_dict = module_config_dict
+        self.time_steps = time_steps
+        input_dim = 0
+        for each in module_config_dict["input_dim"]:
+            if each in obs_dim_dict:
+                input_dim += obs_dim_dict[each]
+            elif isinstance(each, (int, float)):
+                input_dim += each
+            else:
+                raise ValueError(f"_calculate_dim - Unknown input type: {each}")
+        self.input_dim = input_dim
+        self.output_dim = module_config_dict["output_dim"]
+        self.hidden_dim = module_config_dict["hidden_dim"]
+        lc = module_config_dict["layer_config"]
+        if lc["type"] != "Conv1d":
+            raise NotImplementedError(f"Unsupported layer type: {lc['type']}")
+        if time_steps not in _CONV_TABLE:
+            raise ValueError(f"Unsupported time_steps for now: {time_steps}")
+        out_channels, kernel_sizes, strides = _CONV_TABLE[time_steps]
+        self.encoder = nn.Sequential(nn.Linear(self.input_dim, self.hidden_dim), nn.ReLU())
+        act = getattr(nn, lc["activation"])()
+        layers, in_ch = [], self.hidden_dim
+        for oc, k, s in zip(out_channels, kernel_sizes, strides):
+            layers += [nn.Conv1d(in_ch, oc, k, s), act]
+            in_ch = oc
+        self.conv_module = nn.Sequential(*layers)
+        self.output_layer = nn.Linear(out_channels[-1] * 3, self.output_dim)
+        self._act = act
+        self._strides = strides
+
+    def forward(self, x):
+        B = x.shape[0] if x.dim() == 2 else x.numel() // (self.input_dim * self.time_steps)
+        x = self.encoder(x.reshape(-1, self.input_dim)).view(B, self.time_steps, self.hidden_dim)       # [B, T, H]: x.view(-1, input_dim) chunks, sic
+        for i, s in enumerate(self._strides):
+            conv = self.conv_module[2 * i]
+            k = conv.kernel_size[0]
+            w = x.unfold(1, k, s)                                          # [B, L, C, k]
+            L = w.shape[1]
+            x = self._act(F.linear(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)).view(B, L, conv.out_channels)
+        return self.output_layer(x.transpose(1, 2).reshape(B, -1))       # flatten(start_dim=1) of [B, C, 3]
+
+
+class Actor(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict, num_actions):
+        super().__init__()
+        for idx, od in enumerate(module_config_dict["output_dim"]):
+            if od == "robot_action_dim":
+                module_config_dict["output_dim"][idx] = num_actions
+        if module_config_dict.get("type", "MLP") != "MLP":
+            raise NotImplementedError
+        self.actor_module = BaseModule(obs_dim_dict, module_config_dict)
+        new_obs_dim_dict = dict(obs_dim_dict)
+        me = module_config_dict["motion_encoder"]
+        self.motion_encoder = ConvEncoder(obs_dim_dict, me, me["tsteps"])
+        he = module_config_dict.get("history_encoder", None)
+        if he is not None:
+            new_obs_dim_dict["prop_history"] //= he["tsteps"]
+            self.history_encoder = ConvEncoder(new_obs_dim_dict, he, he["tsteps"])
+        else:
+            self.history_encoder = None
+        pe = module_config_dict.get("priv_encoder", None)
+        self.priv_encoder = BaseModule(obs_dim_dict, pe) if pe is not None else None
+
+    def motion_encoding(self, motion_obs):
+        return self.motion_encoder(motion_obs)
+
+    def history_encoding(self, history_obs):
+        return self.history_encoder(history_obs)
+
+    def priv_encoding(self, priv_obs):
+        return self.priv_encoder(priv_obs)
+
+    def forward(self, obs_dict, hist_encoding: bool, obs_key="actor_obs", target_key="future_motion_targets"):
+        motion_embedding = self.motion_encoding(obs_dict[target_key])
+        latent = self.history_encoding(obs_dict["prop_history"]) if hist_encoding else self.priv_encoding(obs_dict["priv_obs"])
+        return self.actor_module(torch.cat([obs_dict[obs_key], motion_embedding, latent], dim=-1))
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, obs_dim_dict, module_config_dict, num_actions, init_noise_std):
+        super().__init__()
+        self.actor_module = Actor(obs_dim_dict, module_config_dict["actor"], num_actions)
+        cc = module_config_dict["critic"]
+        if cc.get("type", "MLP") != "MLP":
+            raise NotImplementedError
+        self.critic_module = BaseModule(obs_dim_dict, cc)
+        self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
+        a = module_config_dict["actor"]
+        self.fix_sigma = a.get("fix_sigma", False)
+        self.max_sigma = a.get("max_sigma", 1.0)
+        self.min_sigma = a.get("min_sigma", 0.1)
+        if self.fix_sigma:
+            self.std.requires_grad = False
+        self.distribution = None
+        Normal.set_default_validate_args = False
+
+    @property
+    def actor(self):
+        return self.actor_module
+
+    @property
+    def critic(self):
+        return self.critic_module
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def sigma(self):
+        return self.std.clamp(min=self.min_sigma, max=self.max_sigma)
+
+    def update_distribution(self, obs, hist_encoding, obs_key):
+        mean = self.actor(obs, hist_encoding, obs_key)
+        self.distribution = Normal(mean, (mean * 0.0 + self.std).clamp(min=self.min_sigma, max=self.max_sigma))
+
+    def act(self, obs, hist_encoding=False, obs_key="actor_obs", **kwargs):
+        self.update_distribution(obs, hist_encoding, obs_key)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, obs, hist_encoding=True, **kwargs):
+        return self.actor(obs, hist_encoding)
+
+    def evaluate(self, obs, obs_key="actor_obs", **kwargs):
+        motion_embedding = self.actor.motion_encoding(obs["future_motion_targets"])
+        return self.critic(torch.cat([obs[obs_key], obs["priv_obs"], motion_embedding], dim=-1))

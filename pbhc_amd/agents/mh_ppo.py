@@ -393,7 +393,7 @@ class MHPPO:
         for k, (o, n) in enumerate(((0, na), (na, nc))):
             _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
                                           self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
-                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, self._adam_scratch[k].data_ptr(),
+                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, 0.0, self._adam_scratch[k].data_ptr(),
                                           self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
         loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         return loss
@@ -444,7 +444,7 @@ class MHPPO:
         for k, (o, n) in enumerate(((0, na), (na, nc))):
             _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
                                           self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
-                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, self._adam_scratch[k].data_ptr(),
+                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, 0.0, self._adam_scratch[k].data_ptr(),
                                           self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
         with torch.no_grad():
             loss["Value"] += value_loss.detach(); loss["Surrogate"] += surrogate.detach(); loss["Entropy"] += entropy_loss.detach()

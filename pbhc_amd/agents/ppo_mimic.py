@@ -1,0 +1,466 @@
+"""PPO (ppo_mimic) — drop-in for the reference's KungfuBot2 general-tracking agent.
+
+Same class surface as the reference (reference: humanoidverse/agents/ppo/ppo_mimic.py:34-975 on the BaseAlgo API):
+`__init__(env, config, log_dir=None, device)`, `setup()`, `load(path)`, `save(path, infos)`, `learn()`, `inference_model`;
+the checkpoint dict (`model_state_dict`, `optimizer_state_dict` in torch.optim.AdamW's format, `iter`, `infos`) and every
+state_dict key are the reference's.  Select with `algo._target_: pbhc_amd.agents.ppo_mimic.PPO`.
+
+The teacher (RL) path of the reference is implemented: PPO on the privileged latent with the `priv_reg` term and, every
+`dagger_update_freq` iterations, the DAgger regression of the history encoder (ppo_mimic.py:270-300,596-709).  The student
+distillation path (`teacher_model_path` set) mutates the env's observation dict after construction in the reference; it is
+not part of this hot path and raises NotImplementedError.
+
+MI355X-first differences (same maths, pinned by tests/golden/ppo_v2.npz): as pbhc_amd/agents/mh_ppo.py — no host
+synchronisation inside an iteration, fused sample / bootstrap / GAE / loss / clip+AdamW kernels over flat parameter buffers,
+the motion embedding computed once per forward for actor and critic, env observations written straight into the rollout slabs,
+one flat RCCL gradient all-reduce per optimiser step when envs are sharded over ranks.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import deque
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from .. import dist as pdist
+from .agent_modules import ActorCritic
+from .mh_ppo import _make_writer
+from .modules import RolloutStorage
+
+
+class _FlatAdamWView:
+    """torch.optim.AdamW-format state_dict()/load_state_dict() over a set of parameters of the flat buffers."""
+
+    def __init__(self, algo, which):
+        self.algo, self.which = algo, which            # which: 0 = self.optimizer (all parameters), 1 = hist_encoder_optimizer
+
+    def _entries(self):
+        a = self.algo
+        names = [n for n, _ in a.alg.named_parameters()]
+        if self.which == 1:
+            names = [n for n in names if n.startswith("actor_module.history_encoder.")]
+        return names
+
+    def state_dict(self):
+        a = self.algo
+        state = {}
+        stepped = float(a._adam_step[self.which]) > 0
+        for i, n in enumerate(self._entries()):
+            is_hist = n.startswith("actor_module.history_encoder.")
+            if not stepped or (self.which == 0 and is_hist):       # never stepped: torch keeps no state for it
+                continue
+            o, k, shape = a._slice_of[n]
+            state[i] = {"step": a._adam_step[self.which].detach().clone().cpu(), "exp_avg": a._mflat[self.which][o:o + k].view(shape).clone(),
+                        "exp_avg_sq": a._vflat[self.which][o:o + k].view(shape).clone()}
+        group = {"lr": float(a._lr[0]) if self.which == 0 else float(a._lr_hist[0]), "betas": tuple(a.betas), "eps": a.adam_eps, "weight_decay": a.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self._entries())))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        a = self.algo
+        for i, n in enumerate(self._entries()):
+            if i in sd["state"]:
+                e = sd["state"][i]
+                o, k, _ = a._slice_of[n]
+                a._mflat[self.which][o:o + k].copy_(e["exp_avg"].reshape(-1).to(a.device))
+                a._vflat[self.which][o:o + k].copy_(e["exp_avg_sq"].reshape(-1).to(a.device))
+                a._adam_step[self.which] = float(e["step"])
+        if self.which == 0:
+            a._lr[:] = float(sd["param_groups"][0]["lr"])
+
+    @property
+    def param_groups(self):
+        return [{"lr": float(self.algo._lr[0])}]
+
+
+class PPO:
+    def __init__(self, env, config, log_dir=None, device="cpu"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PbhcError("pbhc_amd.agents.ppo_mimic.PPO runs on the GPU only")
+        self.env = env
+        self.config = config
+        self.log_dir = log_dir
+        self.writer = _make_writer(log_dir)
+        self.start_time = self.stop_time = 0
+        self.collection_time = self.learn_time = 0
+        self._init_config()
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.ep_infos = []
+        self.rewbuffer = deque(maxlen=100)
+        self.lenbuffer = deque(maxlen=100)
+        N = self.env.num_envs
+        self.cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
+        self.cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
+        self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        _ = self.env.reset_all()
+        self.learn = self.learn_RL
+
+    def _init_config(self):
+        c = self.config
+        self.num_envs = self.env.config.num_envs
+        self.algo_obs_dim_dict = self.env.config.robot.algo_obs_dim_dict
+        self.num_act = self.env.config.robot.actions_dim
+        self.save_interval = c.save_interval
+        self.logging_interval = c.get("logging_interval", 10)
+        self.num_steps_per_env = c.num_steps_per_env
+        self.load_optimizer = c.load_optimizer
+        self.num_learning_iterations = c.num_learning_iterations
+        self.init_at_random_ep_len = c.init_at_random_ep_len
+        self.desired_kl = c.desired_kl
+        self.schedule = c.schedule
+        self.learning_rate = c.learning_rate
+        self.clip_param = c.clip_param
+        self.num_learning_epochs = c.num_learning_epochs
+        self.num_mini_batches = c.num_mini_batches
+        self.gamma = c.gamma
+        self.lam = c.lam
+        self.value_loss_coef = c.value_loss_coef
+        self.entropy_coef = c.entropy_coef
+        self.max_grad_norm = c.max_grad_norm
+        self.use_clipped_value_loss = c.use_clipped_value_loss
+        self.num_rew_fn = self.env.num_rew_fn
+        self.priv_reg_coef_schedual = c.priv_reg_coef_schedual
+        self.counter = 0
+        self.train_distill = c.get("teacher_model_path", None) is not None
+        self.dagger_only = bool(c.get("dagger_only", False))
+        if self.train_distill or self.dagger_only:
+            raise NotImplementedError("student distillation (teacher_model_path / dagger_only) is outside the hot path; "
+                                      "set algo.config.teacher_model_path=null and dagger_only=False for the RL path")
+        if c.module_dict.get("actor", {}).get("type", "MLP") != "MLP" or c.module_dict.get("critic", {}).get("type", "MLP") != "MLP":
+            raise NotImplementedError("MoEMLP actors/critics")
+        self.dagger_update_freq = c.get("dagger_update_freq", 20)
+        self.hist_encoding = False
+
+    # ------------------------------------------------------------------------------------
+    def setup(self):
+        self._setup_models_and_optimizer()
+        self._setup_storage()
+
+    def _setup_models_and_optimizer(self):
+        c = self.config
+        if self.env.config.use_vec_reward:
+            c.module_dict.critic["output_dim"][-1] = self.num_rew_fn
+        self.alg = ActorCritic(self.algo_obs_dim_dict, c.module_dict, self.num_act, c.init_noise_std).to(self.device)
+        if self.world_size > 1:
+            for p in self.alg.parameters():
+                dist.broadcast(p.data, src=0)
+        self._flatten_parameters()
+
+    def _flatten_parameters(self):
+        """Flat fp32 buffers [main parameters | history-encoder parameters]: `self.optimizer` (AdamW over every parameter; the history
+        encoder never has a gradient in the PPO step, so torch skips it) steps the first segment, `hist_encoder_optimizer` the second."""
+        dev = self.device
+        named = list(self.alg.named_parameters())
+        main = [(n, p) for n, p in named if not n.startswith("actor_module.history_encoder.")]
+        hist = [(n, p) for n, p in named if n.startswith("actor_module.history_encoder.")]
+        self._n_main = sum(p.numel() for _, p in main)
+        self._n_hist = sum(p.numel() for _, p in hist)
+        n = self._n_main + self._n_hist
+        self._pflat = torch.zeros(n, device=dev)
+        self._gflat = torch.zeros(n, device=dev)
+        self._mflat = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]     # per optimiser (the hist segment of [0] stays unused)
+        self._vflat = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+        self._slice_of = {}
+        o = 0
+        for nme, p in main + hist:
+            k = p.numel()
+            self._pflat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self._pflat[o:o + k].view_as(p)
+            p.grad = self._gflat[o:o + k].view_as(p)
+            self._slice_of[nme] = (o, k, tuple(p.shape))
+            o += k
+        self._std_slice = self._slice_of["std"][:2]
+        self._lr = torch.full((2,), float(self.learning_rate), device=dev)          # [0] is THE learning rate (the loss kernel adapts both)
+        self._lr_hist = torch.full((1,), float(self.learning_rate), device=dev)     # hist_encoder_optimizer keeps its initial lr (ppo_mimic.py:184)
+        self._adam_step = torch.zeros(2, device=dev)
+        self._adam_scratch = torch.zeros(2, 512, dtype=torch.float64, device=dev)
+        self._grad_norms = torch.zeros(2, device=dev)
+        self._loss_scalars = torch.zeros(4, device=dev)
+        self._g_sigma = torch.zeros(self.num_act, device=dev)
+        self.betas, self.adam_eps, self.weight_decay = (0.9, 0.999), 1e-8, 0.01     # torch.optim.AdamW defaults
+        self.optimizer = _FlatAdamWView(self, 0)
+        self.hist_encoder_optimizer = _FlatAdamWView(self, 1)
+
+    def _setup_storage(self):
+        st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
+        S = len(self.env.tar_obs_steps)
+        self._obs_width = {}
+        for k, d in self.algo_obs_dim_dict.items():
+            w = d * S if k in ("future_motion_targets", "teacher_future_motion_targets") else d      # ppo_mimic.py:206-216
+            self._obs_width[k] = w
+            st.register_key(k, shape=(w,), dtype=torch.float)
+        st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
+        st.register_key("rewards", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("dones", shape=(1,), dtype=torch.bool)
+        st.register_key("values", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("returns", shape=(self.num_rew_fn,), dtype=torch.float)
+        st.register_key("advantages", shape=(1,), dtype=torch.float)
+        st.register_key("actions_log_prob", shape=(1,), dtype=torch.float)
+        st.register_key("action_mean", shape=(self.num_act,), dtype=torch.float)
+        st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
+        T, N = self.num_steps_per_env, self.env.num_envs
+        self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
+        self._last_obs = {k: torch.zeros(N, w, device=self.device) for k, w in self._obs_width.items()}
+        self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
+        if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
+            raise _lib.PbhcError("pbhc_amd PPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
+        self._mb = (T * N) // self.num_mini_batches
+        self._loss_scratch = torch.zeros(_lib.lib().pbhc_ppo_loss_scratch_floats(self._mb), device=self.device)
+        self._grad_mu = torch.zeros(self._mb, self.num_act, device=self.device)
+        self._grad_value = torch.zeros(self._mb, self.num_rew_fn, device=self.device)
+
+    def _eval_mode(self):
+        self.alg.eval()
+
+    def _train_mode(self):
+        self.alg.train()
+
+    # ---- checkpoints (ppo_mimic.py:237-265) --------------------------------------------------
+    def load(self, ckpt_path):
+        if ckpt_path is None:
+            return None
+        d = torch.load(ckpt_path, map_location=self.device, weights_only=False)   # our own / user-trusted checkpoint
+        self.alg.load_state_dict(d["model_state_dict"])
+        if self.load_optimizer:
+            self.optimizer.load_state_dict(d["optimizer_state_dict"])
+            self.learning_rate = d["optimizer_state_dict"]["param_groups"][0]["lr"]
+            self.set_learning_rate(self.learning_rate)
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def save(self, path, infos=None):
+        torch.save({"model_state_dict": self.alg.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def set_learning_rate(self, learning_rate):
+        self.learning_rate = learning_rate
+        self._lr[:] = float(learning_rate)
+
+    def update_counter(self):
+        self.counter += 1
+
+    # ---- learn loop (ppo_mimic.py:267-311) ---------------------------------------------------
+    def learn_RL(self, num_iterations=None):
+        if self.init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs_dict = self.env.reset_all()
+        self._train_mode()
+        n = self.num_learning_iterations if num_iterations is None else num_iterations
+        tot_iter = self.current_learning_iteration + n
+        for it in range(self.current_learning_iteration, tot_iter):
+            self.hist_encoding = it % self.dagger_update_freq == 0
+            self.start_time = time.time()
+            obs_dict = self._rollout_step(obs_dict)
+            loss_dict = self._training_step()
+            if self.hist_encoding:
+                loss_dict = self._training_step_dagger()
+            self.stop_time = time.time()
+            self.learn_time = self.stop_time - self.start_time
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
+                                          num_learning_iterations=n))
+            if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
+                self.current_learning_iteration = it
+                self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+            self.ep_infos.clear()
+        self.current_learning_iteration = tot_iter
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    # ---- forward pieces ---------------------------------------------------------------------
+    def _forward(self, b, hist_encoding, want_value=True):
+        """mu, value (and the motion embedding computed ONCE for both; the reference encodes it twice with the same weights)."""
+        a = self.alg.actor
+        emb = a.motion_encoding(b["future_motion_targets"])
+        latent = a.history_encoding(b["prop_history"]) if hist_encoding else a.priv_encoding(b["priv_obs"])
+        mu = a.actor_module(torch.cat([b["actor_obs"], emb, latent], dim=-1))
+        value = self.alg.critic(torch.cat([b["actor_obs"], b["priv_obs"], emb], dim=-1)) if want_value else None
+        return mu, value, latent
+
+    def _rollout_step(self, obs_dict):
+        """ppo_mimic.py:371-438.  Per control step: encoders + actor + critic forward (GEMMs), ONE sample/log-prob/buffer-write kernel,
+        the fused env step writing the next observations into the next rollout slab, ONE bootstrap/done/episode-stat kernel."""
+        st, env, lib = self.storage, self.env, _lib.lib()
+        T, N, A, R = self.num_steps_per_env, env.num_envs, self.num_act, self.num_rew_fn
+        keys = list(self._obs_width.keys())
+        K = _lib.K
+        counter = env.globals[K["PBHC_G_STEP_COUNTER"]:].data_ptr()
+        stream = _lib.current_stream()
+        with torch.inference_mode():
+            sigma = self.alg.sigma().contiguous()
+            for k in keys:
+                getattr(st, k)[0].copy_(obs_dict[k])
+            for t in range(T):
+                b = {k: getattr(st, k)[t] for k in keys}
+                mu, value, _ = self._forward(b, self.hist_encoding)
+                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
+                                                  st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
+                                                  st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
+                env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
+                nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
+                _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                 float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                 self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+            st.step = T
+            self.stop_time = time.time()
+            self.collection_time = self.stop_time - self.start_time
+            self.start_time = self.stop_time
+            self._compute_returns(self._last_obs)
+        return self._last_obs
+
+    def _compute_returns(self, last_obs_dict):
+        """ppo_mimic.py:443-491 in one HIP pass (scalar reward: R = 1, normalisation over all [T,N] entries)."""
+        st = self.storage
+        last_values = self.alg.evaluate(last_obs_dict).detach().contiguous()
+        T, N, R = self.num_steps_per_env, self.env.num_envs, self.num_rew_fn
+        adv = st.advantages
+        _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,
+                                       float(self.gamma), float(self.lam), st.returns.data_ptr(), adv.data_ptr(), self._gae_stats.data_ptr(),
+                                       _lib.current_stream()), "pbhc_gae")
+        if self.world_size > 1:
+            nb = (T * N + 255) // 256
+            mean_l, std_l = self._gae_stats[2 * nb].float(), self._gae_stats[2 * nb + 1].float()
+            adv.copy_(pdist.global_normalize_(adv * (std_l + 1e-8) + mean_l))
+        return st.returns, adv
+
+    # ---- updates (ppo_mimic.py:493-709) ------------------------------------------------------
+    UPDATE_KEYS = ["actor_obs", "priv_obs", "future_motion_targets", "prop_history", "actions", "values", "advantages", "returns", "actions_log_prob",
+                   "action_mean", "action_sigma"]
+
+    def _training_step(self, indices=None):
+        loss = {k: torch.zeros((), device=self.device) for k in ["Value", "Entropy", "Surrogate", "priv_reg_loss"]}
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=self.UPDATE_KEYS, indices=indices):
+            self._update_ppo(batch, loss)
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        self.update_counter()
+        self.learning_rate = self._lr[0:1]
+        out = {k: v / n for k, v in loss.items()}
+        out["Actor_Load_Balancing_Loss"] = torch.zeros((), device=self.device)
+        out["Critic_Load_Balancing_Loss"] = torch.zeros((), device=self.device)
+        return out
+
+    def _training_step_dagger(self, indices=None):
+        loss = {"hist_latent_loss": torch.zeros((), device=self.device)}
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=["priv_obs", "prop_history"], indices=indices):
+            self._update_dagger(batch, loss)
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        self.update_counter()
+        return {k: v / n for k, v in loss.items()}
+
+    def _adam(self, which, o, n, lr):
+        _lib.check(_lib.lib().pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[which][o:o + n].data_ptr(),
+                                             self._vflat[which][o:o + n].data_ptr(), n, lr.data_ptr(), self._adam_step[which:which + 1].data_ptr(),
+                                             float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, self.weight_decay,
+                                             self._adam_scratch[which].data_ptr(), self._grad_norms[which:which + 1].data_ptr(), _lib.current_stream()), "pbhc_adam_clip")
+
+    def _update_ppo(self, b, loss):
+        lib = _lib.lib()
+        alg = self.alg
+        mu, value, priv_latent = self._forward(b, hist_encoding=False)
+        with torch.no_grad():
+            hist_latent = alg.actor.history_encoding(b["prop_history"])
+        priv_reg = (priv_latent - hist_latent).norm(p=2, dim=1).mean()
+        sch = self.priv_reg_coef_schedual
+        stage = min(max(self.counter - sch[2], 0) / sch[3], 1)
+        coef = stage * (sch[1] - sch[0]) + sch[0]
+        B = mu.shape[0]
+        if B != self._mb:
+            raise _lib.PbhcError("minibatch size changed")
+        sigma = alg.sigma().detach().contiguous()
+        self._gflat[: self._n_main].zero_()
+        adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
+        flags = (adapt if self.world_size == 1 else 0) | 2                      # bit 1: the ppo_mimic KL form
+        st = _lib.current_stream()
+        _lib.check(lib.pbhc_ppo_loss(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), b["actions"].data_ptr(), b["actions_log_prob"].data_ptr(),
+                                     b["action_mean"].data_ptr(), b["action_sigma"].data_ptr(), b["advantages"].data_ptr(), b["returns"].data_ptr(),
+                                     b["values"].data_ptr(), B, self.num_act, self.num_rew_fn, float(self.clip_param), float(self.value_loss_coef),
+                                     float(self.entropy_coef), int(self.use_clipped_value_loss), float(self.desired_kl or 0.0), flags,
+                                     self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._g_sigma.data_ptr(), self._loss_scalars.data_ptr(),
+                                     self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
+        heads, grads = [mu, value], [self._grad_mu, self._grad_value]
+        if coef != 0.0:
+            heads.append(priv_reg * coef)
+            grads.append(torch.ones((), device=self.device))
+        torch.autograd.backward(heads, grads)
+        if alg.std.requires_grad:                                               # d sigma / d std of clamp(std, min, max)
+            so, sn = self._std_slice
+            std = alg.std.detach()
+            self._gflat[so:so + sn] = self._g_sigma * ((std >= alg.min_sigma) & (std <= alg.max_sigma))
+        if self.world_size > 1:
+            if adapt:
+                pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
+            pdist.allreduce_mean_(self._gflat[: self._n_main])
+        self._adam(0, 0, self._n_main, self._lr[0:1])
+        loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
+        loss["priv_reg_loss"] += priv_reg.detach()
+        return loss
+
+    def _update_dagger(self, b, loss):
+        a = self.alg.actor
+        with torch.no_grad():
+            priv_latent = a.priv_encoding(b["priv_obs"])
+        hist_loss = (priv_latent - a.history_encoding(b["prop_history"])).norm(p=2, dim=1).mean()
+        self._gflat[self._n_main:].zero_()
+        hist_loss.backward()
+        if self.world_size > 1:
+            pdist.allreduce_mean_(self._gflat[self._n_main:])
+        self._adam(1, self._n_main, self._n_hist, self._lr_hist)
+        loss["hist_latent_loss"] += hist_loss.detach()
+        return loss
+
+    # ---- evaluation / export surface --------------------------------------------------------
+    @property
+    def inference_model(self):
+        return {"actor": self.alg.actor}
+
+    def get_example_obs(self):
+        obs = self.env.reset_all()
+        return {k: v.clone() for k, v in obs.items()}
+
+    @torch.no_grad()
+    def evaluate_policy_steps(self, Nsteps):
+        self._eval_mode()
+        self.env.set_is_evaluating()
+        obs = self.env.reset_all()
+        for _ in range(Nsteps):
+            obs, _, _, _ = self.env.step({"actions": self.alg.act_inference(obs, hist_encoding=True)})
+        return obs
+
+    def evaluate_policy(self):
+        return self.evaluate_policy_steps(int(self.env.max_episode_length))
+
+    def _post_epoch_logging(self, log, width=80, pad=40):
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.world_size
+        it_time = log["collection_time"] + log["learn_time"]
+        self.tot_time += it_time
+        if log["it"] % self.logging_interval != 0 or self.rank != 0:
+            return
+        stats = self._ep_stats.tolist()
+        self._ep_stats.zero_()
+        fps = int(self.num_steps_per_env * self.env.num_envs * self.world_size / max(it_time, 1e-9))
+        it, w = log["it"], self.writer
+        for k, v in log["loss_dict"].items():
+            w.add_scalar("Loss/" + k, float(v), it)
+        w.add_scalar("Loss/learning_rate", float(self._lr[0]), it)
+        w.add_scalar("Policy/mean_noise_std", float(self.alg.std.mean()), it)
+        w.add_scalar("Perf/total_fps", fps, it)
+        w.add_scalar("Perf/collection_time", log["collection_time"], it)
+        w.add_scalar("Perf/learning_time", log["learn_time"], it)
+        if stats[2] > 0:
+            w.add_scalar("Train/mean_reward", stats[0] / stats[2], it)
+            w.add_scalar("Train/mean_episode_length", stats[1] / stats[2], it)
+        for k, v in (self.env.read_log() if hasattr(self.env, "read_log") else {}).items():
+            w.add_scalar("Env/" + k, float(v), it)
+        ld = ", ".join(f"{k} {float(v):.4f}" for k, v in log["loss_dict"].items() if "Load_Balancing" not in k)
+        print(f"[it {it}] fps {fps}  collect {log['collection_time']:.3f}s  learn {log['learn_time']:.3f}s  {ld}  lr {float(self._lr[0]):.2e}  "
+              f"ep_rew {stats[0] / max(stats[2], 1):.3f}  ep_len {stats[1] / max(stats[2], 1):.1f}", flush=True)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
                                                   const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ old_mu,
                                                   const float* __restrict__ old_sigma, const float* __restrict__ adv, const float* __restrict__ returns,
                                                   const float* __restrict__ old_values, int B, int A, int R, float clip, float value_coef,
-                                                  int clipped_value, float* __restrict__ grad_mu, float* __restrict__ grad_value,
+                                                  int clipped_value, int kl_v2, float* __restrict__ grad_mu, float* __restrict__ grad_value,
                                                   float* __restrict__ partial, float* __restrict__ gstd_part) {
   __shared__ float sh_s[LOSS_ROWS][4];
   __shared__ float sh_g[LOSS_ROWS][32];
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
     const float d = x - m;
     // torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(sigma) - log(sqrt(2 pi))
     lp = -(d * d) / (2.0f * var) - logf(sigma) - 0.9189385332046727f;
-    kl = logf(sigma / os + 1.0e-5f) + (os * os + (om - m) * (om - m)) / (2.0f * sigma * sigma) - 0.5f;   // mh_ppo.py:453
+    // mh_ppo.py:453 adds the 1e-5 to the ratio, ppo_mimic.py:624 to the old sigma
+    kl = (kl_v2 ? logf(sigma / (os + 1.0e-5f)) : logf(sigma / os + 1.0e-5f)) + (os * os + (om - m) * (om - m)) / (2.0f * sigma * sigma) - 0.5f;
     dmu_c = d / var;                       // d logp / d mu
     dsig_c = d * d / (var * sigma) - 1.0f / sigma;   // d logp / d sigma
   }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(const float* __restri
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
                                                       const double* __restrict__ part, int nparts, const float* __restrict__ lr, float* __restrict__ step,
-                                                      float max_norm, float b1, float b2, float eps, float* __restrict__ norm_out) {
+                                                      float max_norm, float b1, float b2, float eps, float weight_decay, float* __restrict__ norm_out) {
   __shared__ float s_clip, s_bc1, s_bc2s, s_lr;
   if (threadIdx.x == 0) {
     double t = 0.0;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
   }
   __syncthreads();
   const float clipc = s_clip, step_size = s_lr / s_bc1, bc2s = s_bc2s;
+  const float decay = 1.0f - s_lr * weight_decay;              // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
   for (size_t i = (size_t)blockIdx.x * ADAM_T + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * ADAM_T) {
     const float gi = g[i] * clipc;
     g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
     const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    p[i] = p[i] * decay - step_size * (mi / denom);
   }
 }
 __global__ void k_step_inc(float* step) { step[0] += 1.0f; }
@@ -310,8 +312,8 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
   float* partial = scratch;                       // [nb][LOSS_NP]
   float* gstd_part = scratch + (size_t)nb * LOSS_NP;   // [nb][32]
   hipLaunchKernelGGL(k_ppo_loss, dim3(nb), dim3(256), 0, st, mu, std, value, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, B, A, R,
-                     clip, value_coef, use_clipped_value_loss, grad_mu, grad_value, partial, gstd_part);
-  hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr, grad_std, scalars, lr);
+                     clip, value_coef, use_clipped_value_loss, (adapt_lr >> 1) & 1, grad_mu, grad_value, partial, gstd_part);
+  hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr & 1, grad_std, scalars, lr);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
@@ -319,7 +321,7 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
 int pbhc_ppo_loss_scratch_floats(int B) { return ((B + LOSS_ROWS - 1) / LOSS_ROWS) * (LOSS_NP + 32); }
 
 int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
-                   float beta2, float eps, double* scratch, float* norm_out, void* stream) {
+                   float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream) {
   ARG_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step && scratch && n >= 1);
   hipStream_t st = (hipStream_t)stream;
   int nb = (n + ADAM_T * 8 - 1) / (ADAM_T * 8);
@@ -327,7 +329,7 @@ int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
   hipLaunchKernelGGL(k_sqnorm_partial, dim3(nb), dim3(ADAM_T), 0, st, grad, n, scratch);
   int nb2 = (n + ADAM_T * 4 - 1) / (ADAM_T * 4);
   if (nb2 > 1024) nb2 = 1024;
-  hipLaunchKernelGGL(k_adam_clip, dim3(nb2), dim3(ADAM_T), 0, st, param, grad, exp_avg, exp_avg_sq, n, scratch, nb, lr, step, max_norm, beta1, beta2, eps, norm_out);
+  hipLaunchKernelGGL(k_adam_clip, dim3(nb2), dim3(ADAM_T), 0, st, param, grad, exp_avg, exp_avg_sq, n, scratch, nb, lr, step, max_norm, beta1, beta2, eps, weight_decay, norm_out);
   hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;

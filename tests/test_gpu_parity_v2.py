@@ -56,3 +56,82 @@ def test_general_tracking_step_matches_reference_trace(tag, cfgname):
         for lk in ["terminate_by_ref_pos_z", "terminate_by_ref_ori", "terminate_by_body_z", "terminate_by_time_out", "terminate_by_motion_end",
                    "key_body_diff_norm", "local_key_body_diff_norm", "local_upper_body_diff_norm", "joint_pos_diff_norm", "action_clip_frac"]:
             close(torch.tensor(log[lk]), g["step__log__" + lk][k], 1e-4, w + "log " + lk)
+
+
+def _v2_algo(N, overrides=None, noise_off=True):
+    from pbhc_amd.agents.ppo_mimic import PPO
+
+    ov = {"domain_rand.push_robots": False}
+    ov.update(overrides or {})
+    cfg, env = build_hip_env("v2_g1_29dof_teacher.yaml", N, general=True, overrides=ov, noise_off=noise_off)
+    algo = PPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+    algo.setup()
+    return cfg, env, algo
+
+
+def test_ppo_mimic_update_matches_reference():
+    """One _training_step + one _training_step_dagger of pbhc_amd PPO on the reference's rollout buffer, initial weights and
+    permutations reproduce the reference's updated weights, losses and learning rate (tests/golden/ppo_v2.npz)."""
+    from tests.helpers import PPO_V2_NARROW
+
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_v2.npz")).items()}
+    N = g["st__actions"].shape[1]
+    cfg, env, algo = _v2_algo(N, PPO_V2_NARROW)
+    algo.alg.load_state_dict({k[len("w0__"):]: v for k, v in g.items() if k.startswith("w0__")}, strict=True)
+    for k in algo.storage.stored_keys:
+        getattr(algo.storage, k).copy_(g["st__" + k].to(DEV))
+    algo._train_mode()
+    algo.counter = int(g["counter0"])
+    # stored rollout quantities are functions of the stored observations and the initial weights
+    with torch.no_grad():
+        b = {k: getattr(algo.storage, k).flatten(0, 1) for k in ["actor_obs", "priv_obs", "future_motion_targets", "prop_history"]}
+        mu, value, _ = algo._forward(b, hist_encoding=False)
+        close(mu, g["st__action_mean"].flatten(0, 1), 2e-5, "mu")
+        close(value, g["st__values"].flatten(0, 1), 2e-5, "value")
+        last = {k[len("last__"):]: v.to(DEV) for k, v in g.items() if k.startswith("last__")}
+        close(algo.alg.act_inference(last, hist_encoding=True), g["infer_hist"], 2e-5, "act_inference(hist)")
+        algo._compute_returns(last)
+        close(algo.storage.returns, g["st__returns"], 2e-5, "returns")
+        close(algo.storage.advantages, g["st__advantages"], 5e-5, "advantages")
+    loss = algo._training_step(indices=g["perm1"].to(DEV))
+    torch.cuda.synchronize()
+    for k in ["Value", "Surrogate", "Entropy", "priv_reg_loss"]:
+        assert abs(float(loss[k]) - float(g["loss1__" + k])) < 2e-4 * max(1.0, abs(float(g["loss1__" + k]))), (k, float(loss[k]), float(g["loss1__" + k]))
+    assert abs(float(algo._lr[0]) - float(g["lr1"])) < 1e-9
+    # AdamW moves a weight by ~lr per step whatever the gradient's size (see test_mhppo_update_matches_reference)
+    for k, v in algo.alg.state_dict().items():
+        ref = g["w1__" + k]
+        close(v, ref, 2e-4, "w1 " + k, rtol=2e-4)
+        assert float((v.cpu() - ref).norm() / ref.norm().clamp(min=1e-6)) < 1e-4, k
+    assert torch.equal(algo.alg.state_dict()["actor_module.history_encoder.encoder.0.weight"].cpu(), g["w0__actor_module.history_encoder.encoder.0.weight"])
+    loss = algo._training_step_dagger(indices=g["perm2"].to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss["hist_latent_loss"]) - float(g["loss2__hist_latent_loss"])) < 2e-4
+    for k, v in algo.alg.state_dict().items():
+        ref = g["w2__" + k]
+        close(v, ref, 2e-4, "w2 " + k, rtol=2e-4)
+        assert float((v.cpu() - ref).norm() / ref.norm().clamp(min=1e-6)) < 1e-4, k
+    assert algo.counter == int(g["counter2"])
+
+
+def test_ppo_mimic_checkpoint_roundtrip_uses_reference_keys(tmp_path):
+    g = np.load(os.path.join(GOLDEN, "ppo_v2.npz"))
+    cfg, env, algo = _v2_algo(16)
+    p = str(tmp_path / "model_0.pt")
+    algo.save(p, infos={"x": 1})
+    d = torch.load(p, map_location="cpu", weights_only=False)
+    assert set(d.keys()) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"}
+    assert list(d["model_state_dict"].keys()) == [k[len("w0__"):] for k in g.files if k.startswith("w0__")]
+    assert d["optimizer_state_dict"]["param_groups"][0]["weight_decay"] == 0.01
+    assert algo.load(p) == {"x": 1}
+    assert algo.inference_model["actor"] is algo.alg.actor
+
+
+def test_ppo_mimic_learn_runs_two_iterations():
+    cfg, env, algo = _v2_algo(256, noise_off=False)
+    algo.learn(num_iterations=2)                     # iteration 0 also runs the DAgger step (0 % dagger_update_freq == 0)
+    torch.cuda.synchronize()
+    for p in algo.alg.parameters():
+        assert torch.isfinite(p).all()
+    log = env.read_log()
+    assert np.isfinite(log["reward_mean"])
