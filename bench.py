@@ -30,6 +30,15 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.
 FP32_MFMA_PEAK_TFLOPS = 157.3
 
 WORKLOAD_CFG = "v1_g1_23dof_walk.yaml"     # BASELINE.json configs[1]: 4096 envs, G1 23-DoF, g1_walk_45cms, 1xMI355X
+# --workload: the default is the configuration the metric is quoted on; the general-tracking ones are extra measurements
+WORKLOADS = {
+    "v1_walk": dict(cfg=WORKLOAD_CFG, general=False,
+                    desc="G1 23-DoF, single reference motion g1_walk_45cms (122 frames), v1 env (LeggedRobotMotionTracking) + MHPPO"),
+    "v2_teacher29": dict(cfg="v2_g1_29dof_teacher.yaml", general=True,
+                         desc="G1 29-DoF, general tracking (LeggedRobotGeneralTracking) + ppo_mimic.PPO teacher, 20-step future targets"),
+    "v2_student23": dict(cfg="v2_g1_23dof_student.yaml", general=True,
+                         desc="G1 23-DoF, general tracking (LeggedRobotGeneralTracking) + ppo_mimic.PPO (RL path), 877-dim actor obs"),
+}
 
 
 def algorithmic_bytes_per_env_step(env):
@@ -49,6 +58,10 @@ def algorithmic_bytes_per_env_step(env):
         foot_state=5 * F, scalars=2 + 2 + 2 + 1,
     )
     motion = 2 * env._motion_lib.row
+    if getattr(env, "TRACKING_MODE", 0) == 1 and c.future_num_steps:
+        # future targets: per step two frame rows, of which dof_pos, the root body (pos z, rot, vel, ang vel), the anchor pose and the key-body positions are read
+        reads["dr_base_mass"] = 1
+        motion += 2 * c.future_num_steps * (D + 13 + (0 if c.anchor_index == 0 else 7) + 3 * c.num_key)
     return sum(reads.values()) + sum(writes.values()), motion, reads, writes
 
 
@@ -85,16 +98,55 @@ def make_replay_on_device(env, num_frames, seed):
     return root, qp, qv, cf
 
 
-def build(num_envs, device, seed):
-    from pbhc_amd.agents.mh_ppo import MHPPO
-    from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking
+def synth_library(base_clip, num_clips, seed=0):
+    """Synthetic mixed library (BASELINE.json configs[2]: the AMASS/LAFAN sets are not shipped): `num_clips` time-warped, shifted and
+    re-phased variants of the shipped clip — frames resampled at 0.6x..1.4x speed from a random start, root yawed by a constant."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    pose, trans, fps = np.asarray(base_clip["pose_aa"], np.float32), np.asarray(base_clip["root_trans_offset"], np.float32), int(base_clip["fps"])
+    F = pose.shape[0]
+    clips = [dict(pose_aa=pose, root_trans_offset=trans, fps=fps)]
+    for _ in range(num_clips - 1):
+        speed = rng.uniform(0.6, 1.4)
+        n = int(rng.integers(F // 2, F))
+        t = np.clip(rng.uniform(0, F * 0.3) + speed * np.arange(n), 0, F - 1.001)
+        i0 = t.astype(np.int64)
+        w = (t - i0).astype(np.float32)
+        p = (1 - w)[:, None, None] * pose[i0] + w[:, None, None] * pose[i0 + 1]
+        tr = (1 - w)[:, None] * trans[i0] + w[:, None] * trans[i0 + 1]
+        tr = tr - tr[:1] * np.array([1, 1, 0], np.float32) + np.array([*rng.uniform(-0.5, 0.5, 2), 0], np.float32)
+        clips.append(dict(pose_aa=p.astype(np.float32), root_trans_offset=tr.astype(np.float32), fps=fps))
+    return clips
+
+
+def build(num_envs, device, seed, workload="v1_walk", num_clips=1):
     from pbhc_amd.utils.config import load_config
 
-    cfg = load_config(os.path.join(ROOT, "tests", "golden", "configs", WORKLOAD_CFG),
-                      {"num_envs": num_envs, "simulator._target_": "pbhc_amd.simulator.replay_stub.ReplaySimStub"}, now="bench")
+    w = WORKLOADS[workload]
+    ov = {"num_envs": num_envs, "simulator._target_": "pbhc_amd.simulator.replay_stub.ReplaySimStub"}
+    if w["general"]:
+        ov.update({"algo.config.teacher_model_path": None, "algo.config.dagger_only": False})
+    cfg = load_config(os.path.join(ROOT, "tests", "golden", "configs", w["cfg"]), ov, now="bench")
     torch.manual_seed(seed)
-    env = LeggedRobotMotionTracking(cfg.env.config, device)
-    return cfg, env, MHPPO
+    if w["general"]:
+        from pbhc_amd.agents.ppo_mimic import PPO as Algo
+        from pbhc_amd.envs.general_tracking import LeggedRobotGeneralTracking as Env
+    else:
+        from pbhc_amd.agents.mh_ppo import MHPPO as Algo
+        from pbhc_amd.envs.motion_tracking import LeggedRobotMotionTracking as Env
+    if num_clips > 1:
+        from pbhc_amd import motion_lib as ML
+
+        orig = ML.load_motion_file
+        ML.load_motion_file = lambda path: [(f"synth{i}", c) for i, c in enumerate(synth_library(orig(path)[0][1], num_clips, seed=7))]
+        try:
+            env = Env(cfg.env.config, device)
+        finally:
+            ML.load_motion_file = orig
+    else:
+        env = Env(cfg.env.config, device)
+    return cfg, env, Algo
 
 
 def pmc_traffic_bytes():
@@ -137,6 +189,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="v1_walk", choices=sorted(WORKLOADS.keys()))
+    ap.add_argument("--clips", type=int, default=1, help="synthetic motion library of this many clips (general-tracking workloads)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,7 +203,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(device))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     N, K, W = a.envs, a.steps, a.warmup
-    cfg, env, MHPPO = build(N, device, seed=1234 + rank)
+    cfg, env, MHPPO = build(N, device, seed=1234 + rank, workload=a.workload, num_clips=a.clips)
     algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=device)
     algo.setup()
     T = algo.num_steps_per_env
@@ -195,25 +249,26 @@ def main():
     words, motion_words, _, _ = algorithmic_bytes_per_env_step(env)
     alg_bytes = 4.0 * (words + motion_words) * N
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    flops_per_sample = 2.0 * sum(p.numel() for n, p in list(algo.actor.named_parameters()) + list(algo.critic.named_parameters()) if n.endswith("weight"))
+    nets = list(algo.alg.named_parameters()) if hasattr(algo, "alg") else list(algo.actor.named_parameters()) + list(algo.critic.named_parameters())
+    flops_per_sample = 2.0 * sum(p.numel() for n, p in nets if n.endswith("weight") and p.dim() == 2)     # Linear layers only (conv windows not counted)
     upd_flops = 3.0 * flops_per_sample * T * N * algo.num_learning_epochs
     if rank == 0:
         out = {
             "metric": "env-steps/s (obs+reward+PPO update), 4096 G1 envs @1/2/4/8 MI355X",
             "value": N * world * T * K / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{N} envs/GPU, G1 23-DoF, single reference motion g1_walk_45cms (122 frames), v1 env (LeggedRobotMotionTracking) + MHPPO, "
-                                   f"24 steps/iter, 5 epochs x 4 minibatches; replay sim-stub tensors resident in HBM",
+            "config": {"workload": f"{N} envs/GPU, {WORKLOADS[a.workload]['desc']}" + (f", synthetic library of {a.clips} clips" if a.clips > 1 else "") +
+                                   f", {T} steps/iter, 5 epochs x 4 minibatches; replay sim-stub tensors resident in HBM",
                        "envs_per_gpu": N, "global_envs": N * world, "num_steps_per_env": T, "parallelism": f"dp{world}"},
             "rollout_ms": rollout_ms, "update_ms": update_ms,
             "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes() if N == 4096 else None, "kernel_ms": kern_ms, "launches_timed": cnt.value,
+                         "traffic": pmc_traffic_bytes() if (N == 4096 and a.workload == "v1_walk") else None, "kernel_ms": kern_ms, "launches_timed": cnt.value,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase (GEMMs via rocBLAS + gather + Adam), fp32"},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "v1_walk":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

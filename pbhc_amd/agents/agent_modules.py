@@ -15,6 +15,35 @@ from torch.distributions import Normal
 
 from .modules import BaseModule
 
+class _TallSkinnyLinear(torch.autograd.Function):
+    """y = x W^T + b for x [K, M] with K (rows x time steps, ~5e5) >> M, N (<= 360 x 60).  The weight gradient dy^T x is a reduction over K
+    with a tiny output: as one GEMM rocBLAS runs it on a handful of workgroups (measured 690 us per call at K = 491520 on MI355X); split
+    over P row chunks it is a batched GEMM that fills the chip, followed by a [P, N, M] sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        K = x.shape[0]
+        P = 1
+        while P < 512 and K % (2 * P) == 0 and K // (2 * P) >= 256:
+            P *= 2
+        dw = torch.bmm(dy.view(P, K // P, -1).transpose(1, 2), x.view(P, K // P, -1)).sum(0)
+        return dx, dw, dy.sum(0)
+
+
+def _linear(x, lin):
+    if x.requires_grad or lin.weight.requires_grad:
+        return _TallSkinnyLinear.apply(x.contiguous(), lin.weight, lin.bias)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 _CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
 
 
@@ -54,13 +83,14 @@ class ConvEncoder(nn.Module):
 
     def forward(self, x):
         B = x.shape[0] if x.dim() == 2 else x.numel() // (self.input_dim * self.time_steps)
-        x = self.encoder(x.reshape(-1, self.input_dim)).view(B, self.time_steps, self.hidden_dim)       # [B, T, H]: x.view(-1, input_dim) chunks, sic
+        x = F.relu(_linear(x.reshape(-1, self.input_dim), self.encoder[0])).view(B, self.time_steps, self.hidden_dim)   # [B, T, H]: x.view(-1, input_dim) chunks, sic
         for i, s in enumerate(self._strides):
             conv = self.conv_module[2 * i]
             k = conv.kernel_size[0]
             w = x.unfold(1, k, s)                                          # [B, L, C, k]
             L = w.shape[1]
-            x = self._act(F.linear(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)).view(B, L, conv.out_channels)
+            x = self._act(_TallSkinnyLinear.apply(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)
+                          if torch.is_grad_enabled() else F.linear(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)).view(B, L, conv.out_channels)
         return self.output_layer(x.transpose(1, 2).reshape(B, -1))       # flatten(start_dim=1) of [B, C, 3]
 
 

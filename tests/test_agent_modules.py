@@ -1,0 +1,32 @@
+"""Host-side network definitions of the general-tracking agent (torch modules, CPU here) against the oracle restatement pinned by
+the reference golden: same outputs, same gradients (the conv layers run as GEMMs over unfolded windows with a split-K weight gradient)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ppo_v2
+from pbhc_amd.agents.agent_modules import ActorCritic
+from pbhc_amd.envs.env_config import determine_obs_dim
+from tests.helpers import GOLDEN, PPO_V2_NARROW, fixture_config
+
+
+def test_actor_critic_matches_oracle_forward_and_backward():
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_v2.npz")).items()}
+    cfg = fixture_config("v2_g1_29dof_teacher.yaml", 8, PPO_V2_NARROW)
+    determine_obs_dim(cfg)
+    ac = ActorCritic(cfg.robot.algo_obs_dim_dict, cfg.algo.config.module_dict, 29, cfg.algo.config.init_noise_std)
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("w0__")}
+    assert list(ac.state_dict().keys()) == list(sd.keys())
+    ac.load_state_dict(sd, strict=True)
+    st = {k[4:]: v.flatten(0, 1) for k, v in g.items() if k.startswith("st__")}
+    mu, v, h = ac.actor(st, False), ac.evaluate(st), ac.actor.history_encoding(st["prop_history"])
+    assert torch.allclose(mu, st["action_mean"], atol=1e-5) and torch.allclose(v, st["values"], atol=1e-5)
+    (mu.square().sum() + v.square().sum() + h.square().sum()).backward()
+    orc = ppo_v2.ActorCriticOracle(sd, cfg.algo.config.module_dict, 20, 10)
+    (orc.actor_mean(st, False).square().sum() + orc.evaluate(st).square().sum() + orc.history(st["prop_history"]).square().sum()).backward()
+    for n, p in ac.named_parameters():
+        if n == "std":
+            continue
+        ref = orc.p[n].grad
+        assert (p.grad - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-7, n
