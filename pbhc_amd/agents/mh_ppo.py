@@ -143,6 +143,9 @@ class MHPPO:
 
     # ------------------------------------------------------------------------------------
     def setup(self):
+        from .gemm_tuning import enable as _enable_gemm_tuning
+
+        _enable_gemm_tuning()
         self._setup_models_and_optimizer()
         self._setup_storage()
 
