@@ -385,6 +385,13 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
                   float* grad_std, float* scalars, float* lr, float* scratch, void* stream);
 int pbhc_ppo_loss_scratch_floats(int B);
 
+/* Backward of one MLP activation fused with the bias gradient of the layer below it (what autograd runs as elu_backward /
+ * silu_backward + a column sum, agents/modules/modules.py:47-63 under torch.autograd): dz = dy * act'(saved), grad_bias = colsum(dz).
+ * act: 0 none (bias gradient of the output layer), 1 ELU from the activation output, 2 SiLU from the pre-activation, 3 ReLU from the
+ * output.  dy/saved/dz [B,n] row-major (dz may alias dy), grad_bias [n], scratch >= PBHC_ACT_MAX_BLOCKS * n floats. */
+#define PBHC_ACT_MAX_BLOCKS 512
+int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream);
+
 /* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,
  * ppo_mimic.py:184-190,682-686) over ONE flat fp32 segment of n
  * parameters (param/grad/exp_avg/exp_avg_sq flat views; lr and step are device scalars, step is incremented).

@@ -1,0 +1,98 @@
+"""Training-time forward/backward of a Linear/activation stack (`BaseModule`, reference agents/modules/modules.py:47-63) arranged for
+MI355X: the GEMMs stay library GEMMs (hipBLASLt / rocBLAS through torch), everything around them is fused or removed:
+
+* the activation backward and the bias gradient of the layer below are ONE pass (`pbhc_act_bwd_bias`) instead of an
+  `elu_backward` + a column-sum launch;
+* weight / bias gradients are written by the GEMM (`out=`) and the fused kernel straight into the parameter's `.grad` — a view of
+  the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear;
+* ELU runs in place and its derivative is taken from the output (`y > 0 ? 1 : y + 1`), so pre-activations are not kept.
+Same arithmetic as autograd's (the column sums are two-stage fp32 in a fixed order); pinned by the update-parity tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+_ACT_ID = {nn.ELU: 1, nn.SiLU: 2, nn.ReLU: 3}
+
+
+def supported(module_seq):
+    layers = list(module_seq)
+    lin = [m for m in layers if isinstance(m, nn.Linear)]
+    acts = [m for m in layers if not isinstance(m, nn.Linear)]
+    if not lin or len(layers) != 2 * len(lin) - 1 or not isinstance(layers[-1], nn.Linear):
+        return False
+    if any(type(a) not in _ACT_ID for a in acts) or len({type(a) for a in acts}) > 1:
+        return False
+    return not any(isinstance(a, nn.ELU) and a.alpha != 1.0 for a in acts)
+
+
+class _FusedMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seq, *params):
+        lin = [m for m in seq if isinstance(m, nn.Linear)]
+        act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
+        saved_in, saved_act = [], []
+        h = x if x.is_contiguous() else x.contiguous()
+        for i, l in enumerate(lin):
+            saved_in.append(h)
+            z = torch.addmm(l.bias, h, l.weight.t())
+            if i == len(lin) - 1:
+                out = z
+            elif act == 1:
+                h = F.elu_(z)
+                saved_act.append(h)                    # ELU' from the output
+            elif act == 3:
+                h = F.relu_(z)
+                saved_act.append(h)
+            else:
+                saved_act.append(z)                    # SiLU' needs the pre-activation
+                h = F.silu(z)
+        ctx.seq, ctx.act, ctx.n = seq, act, len(lin)
+        ctx.save_for_backward(*saved_in, *saved_act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib, st = _lib.lib(), _lib.current_stream()
+        lin = [m for m in ctx.seq if isinstance(m, nn.Linear)]
+        L = ctx.n
+        saved = ctx.saved_tensors
+        ins, acts = saved[:L], saved[L:]
+        d = dout.contiguous()
+        B = d.shape[0]
+        scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * max(l.out_features for l in lin), device=d.device)
+        ret_w = []
+        for i in reversed(range(L)):
+            l = lin[i]
+            n = l.out_features
+            direct = l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
+            gb = l.bias.grad if direct else torch.empty(n, device=d.device)
+            if i < L - 1:
+                _lib.check(lib.pbhc_act_bwd_bias(d.data_ptr(), acts[i].data_ptr(), B, n, ctx.act, d.data_ptr(), gb.data_ptr(), scratch.data_ptr(), st), "pbhc_act_bwd_bias")
+            else:
+                _lib.check(lib.pbhc_act_bwd_bias(d.data_ptr(), None, B, n, 0, d.data_ptr(), gb.data_ptr(), scratch.data_ptr(), st), "pbhc_act_bwd_bias")
+            if direct:
+                torch.mm(d.t(), ins[i], out=l.weight.grad)
+                ret_w.append((None, None))
+            else:
+                ret_w.append((d.t() @ ins[i], gb))
+            if i > 0 or ctx.needs_input_grad[0]:
+                d = d @ l.weight
+        dx = d if ctx.needs_input_grad[0] else None
+        flat = []
+        for gw, gbias in reversed(ret_w):
+            flat += [gw, gbias]
+        return (dx, None, *flat)
+
+
+def forward(seq, x):
+    """seq: nn.Sequential of Linear / activation; x [B, in]."""
+    params = []
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            params += [m.weight, m.bias]
+    return _FusedMLP.apply(x, seq, *params)

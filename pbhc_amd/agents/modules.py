@@ -46,8 +46,13 @@ class BaseModule(nn.Module):
                 layers.append(nn.Linear(hidden[l], hidden[l + 1]))
                 layers.append(act)
         self.module = nn.Sequential(*layers)
+        from . import fused_mlp
+
+        self._fused = fused_mlp if fused_mlp.supported(self.module) else None
 
     def forward(self, x):
+        if self._fused is not None and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (x.requires_grad or self.module[0].weight.requires_grad):
+            return self._fused.forward(self.module, x)           # training: fused activation-backward / bias-gradient path
         return self.module(x)
 
 

@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
   __shared__ float sh_s[LOSS_ROWS][4];
   __shared__ float sh_g[LOSS_ROWS][32];
   const int lane = threadIdx.x & 31, lr = threadIdx.x >> 5;
-  const int row = blockIdx.x * LOSS_ROWS + lr;
-  const bool valid = row < B;
   const float invB = 1.0f / (float)B;
+  const int ntiles = (B + LOSS_ROWS - 1) / LOSS_ROWS;
+  float acc = 0.0f;                                  // thread < 3: scalar partial; thread 32..32+A: d sigma partial (fixed tile order)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int row = tile * LOSS_ROWS + lr;
+  const bool valid = row < B;
   float lp = 0.0f, kl = 0.0f, dmu_c = 0.0f, dsig_c = 0.0f;     // per-lane pieces
   float sigma = 1.0f;
   if (valid && lane < A) {
@@ -110,14 +113,18 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
   if (threadIdx.x < 3) {
     float s = 0.0f;
     for (int r = 0; r < LOSS_ROWS; ++r) s += sh_s[r][threadIdx.x];
-    partial[(size_t)blockIdx.x * LOSS_NP + threadIdx.x] = s;
+    acc += s;
   }
   if (threadIdx.x >= 32 && threadIdx.x < 32 + A) {
     const int a = threadIdx.x - 32;
     float s = 0.0f;
     for (int r = 0; r < LOSS_ROWS; ++r) s += sh_g[r][a];
-    gstd_part[(size_t)blockIdx.x * 32 + a] = s;
+    acc += s;
   }
+  __syncthreads();
+  }
+  if (threadIdx.x < 3) partial[(size_t)blockIdx.x * LOSS_NP + threadIdx.x] = acc;
+  if (threadIdx.x >= 32 && threadIdx.x < 32 + A) gstd_part[(size_t)blockIdx.x * 32 + (threadIdx.x - 32)] = acc;
 }
 
 // Fixed-order second stage: loss scalars, d(loss)/d(std) (surrogate part + entropy bonus), and the adaptive-KL
@@ -166,6 +173,79 @@ __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ 
       }
     }
   }
+}
+
+// ---- activation backward fused with the bias gradient ------------------------------------------------
+// dz = dy * act'(saved) (written in place over dy when dz == dy) and grad_bias[c] = sum_rows dz[r][c], one pass over the [B,n] slab:
+// what eager PyTorch does as an elu_backward / silu_backward launch plus a column-sum launch per layer.
+// act: 0 none, 1 ELU(alpha 1) from the activation OUTPUT (elu' = y > 0 ? 1 : y + 1), 2 SiLU from the PRE-activation, 3 ReLU from the output.
+// Thread <-> column (coalesced rows), ACT_RPB row groups per block, fixed-order two-stage column sums.
+#define ACT_T 256
+__device__ __forceinline__ float act_grad(int act, float s) {
+  if (act == 1) return s > 0.0f ? 1.0f : s + 1.0f;
+  if (act == 2) { const float sg = 1.0f / (1.0f + expf(-s)); return sg * (1.0f + s * (1.0f - sg)); }
+  if (act == 3) return s > 0.0f ? 1.0f : 0.0f;
+  return 1.0f;
+}
+// grid (row blocks, column blocks of ACT_T): thread <-> column, `groups` row groups per block when n < ACT_T; rows unrolled by 8 so that
+// eight independent loads are in flight per thread.
+__global__ __launch_bounds__(ACT_T) void k_act_bwd_bias(const float* __restrict__ dy, const float* __restrict__ saved, int B, int n, int act,
+                                                        float* __restrict__ dz, float* __restrict__ part, int rows_per_block) {
+  __shared__ float sh[ACT_T];
+  const int cpp = n < ACT_T ? n : ACT_T;              // columns per block
+  const int groups = ACT_T / cpp;                     // row groups working in parallel (1 when n >= 256)
+  const int g = threadIdx.x / cpp, c = blockIdx.y * ACT_T + (threadIdx.x - g * cpp);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
+  const bool write = act != 0 || dz != dy;
+  float s = 0.0f;
+  if (g < groups && c < n) {
+    int r = r0 + g;
+    for (; r + 7 * groups < r1; r += 8 * groups) {
+      float v[8], sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const size_t i = (size_t)(r + u * groups) * n + c; v[u] = dy[i]; sv[u] = act ? saved[i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (act) v[u] *= act_grad(act, sv[u]);
+        if (write) dz[(size_t)(r + u * groups) * n + c] = v[u];
+        s += v[u];
+      }
+    }
+    for (; r < r1; r += groups) {
+      const size_t i = (size_t)r * n + c;
+      float v = dy[i];
+      if (act) v *= act_grad(act, saved[i]);
+      if (write) dz[i] = v;
+      s += v;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < cpp && blockIdx.y * ACT_T + threadIdx.x < n) {
+    float t = 0.0f;
+    for (int k = 0; k < groups; ++k) t += sh[k * cpp + threadIdx.x];
+    part[(size_t)blockIdx.x * n + blockIdx.y * ACT_T + threadIdx.x] = t;
+  }
+}
+// second stage: 64 columns x 4 slices per block, fixed order
+__global__ __launch_bounds__(ACT_T) void k_colsum_final(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out) {
+  __shared__ double sh[4][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + col;
+  double s = 0.0;
+  if (c < n) {
+    int b = slice;
+    for (; b + 28 < nblocks; b += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * n + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nblocks; b += 4) s += (double)part[(size_t)b * n + c];
+  }
+  sh[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && c < n) out[c] = (float)(sh[0][col] + sh[1][col] + sh[2][col] + sh[3][col]);
 }
 
 // ---- global-norm clipping + Adam over a flat parameter segment ---------------------------------
@@ -308,12 +388,29 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
   ARG_CHECK(grad_mu && grad_value && grad_std && scalars && lr && scratch);
   ARG_CHECK(B >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (B + LOSS_ROWS - 1) / LOSS_ROWS;
+  int nb = (B + LOSS_ROWS - 1) / LOSS_ROWS;
+  if (nb > 512) nb = 512;                         // grid-stride over row tiles: the 1-block second stage sums <= 512 partials per column
   float* partial = scratch;                       // [nb][LOSS_NP]
   float* gstd_part = scratch + (size_t)nb * LOSS_NP;   // [nb][32]
   hipLaunchKernelGGL(k_ppo_loss, dim3(nb), dim3(256), 0, st, mu, std, value, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, B, A, R,
                      clip, value_coef, use_clipped_value_loss, (adapt_lr >> 1) & 1, grad_mu, grad_value, partial, gstd_part);
   hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr & 1, grad_std, scalars, lr);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream) {
+  ARG_CHECK(dy && dz && grad_bias && scratch && B >= 1 && n >= 1 && act >= 0 && act <= 3 && (act == 0 || saved));
+  hipStream_t st = (hipStream_t)stream;
+  // row blocks: enough workgroups to fill 256 CUs (x column blocks when n > 256), at least 32 rows each
+  const int colblocks = (n + ACT_T - 1) / ACT_T;
+  int nb = (B + 31) / 32;
+  const int want = colblocks >= 3 ? 256 : PBHC_ACT_MAX_BLOCKS;
+  if (nb > want) nb = want;
+  const int rpb = (B + nb - 1) / nb;
+  nb = (B + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_act_bwd_bias, dim3(nb, colblocks), dim3(ACT_T), 0, st, dy, saved, B, n, act, dz, scratch, rpb);
+  hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(ACT_T), 0, st, scratch, nb, n, grad_bias);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
