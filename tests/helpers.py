@@ -119,14 +119,14 @@ def load_state_into_hip_env(env, st, g=None):
             s._base_mass_scale.copy_(torch.from_numpy(g["base_mass_scale"]).to(dev))
 
 
-def synth_replay(ml, skel, N, T, start_times, ep_len, dt, origins, seed, feet, has_contact=True):
+def synth_replay(ml, skel, N, T, start_times, ep_len, dt, origins, seed, feet, has_contact=True, ids=None):
     """Synthetic replay window on the CPU (oracle motion lib): state_k = ref((ep+k+1)dt+start) + noise."""
     from oracle import rotations as R
 
     g = torch.Generator().manual_seed(seed)
     D, B = skel["dof_axis"].shape[0], skel["num_bodies"]
     root = torch.zeros(T, N, 13); qp = torch.zeros(T, N, D); qv = torch.zeros(T, N, D); cf = torch.zeros(T, N, B, 3)
-    ids = torch.zeros(N, dtype=torch.long)
+    ids = torch.zeros(N, dtype=torch.long) if ids is None else ids
     for k in range(T):
         t = (ep_len + k + 1).float() * dt + start_times
         ref = ml.get_motion_state(ids, t, offset=origins)

@@ -135,3 +135,84 @@ def test_ppo_mimic_learn_runs_two_iterations():
         assert torch.isfinite(p).all()
     log = env.read_log()
     assert np.isfinite(log["reward_mean"])
+
+
+def test_general_tracking_multi_clip_matches_oracle():
+    """Mixed library (BASELINE configs[2]): 3 synthetic clips of different lengths, slots cycling through them, 512 envs — the HIP step
+    against the oracle on identical replay tensors, with resets (per-slot motion lengths) and futures running past clip ends."""
+    import bench
+    from oracle.env_v2 import GeneralTrackingOracle
+    from oracle.fk import sim_fk
+    from oracle.motion_lib import MotionLib as OML
+    from pbhc_amd import motion_lib as ML
+    from tests.helpers import clip_from_env_golden, fixture_config, skel_from_golden, synth_replay
+
+    N, T, M = 512, 4, 3
+    cfgname = "v2_g1_29dof_teacher.yaml"
+    g = dict(np.load(os.path.join(GOLDEN, "env_v2_teacher29.npz")))
+    clips = bench.synth_library(clip_from_env_golden(g), M, seed=3)
+    orig = ML.load_motion_file
+    ML.load_motion_file = lambda path: [(f"c{i}", c) for i, c in enumerate(clips)]
+    try:
+        cfg, env = build_hip_env(cfgname, N, general=True, overrides={"domain_rand.push_robots": False})
+    finally:
+        ML.load_motion_file = orig
+    skel = skel_from_golden("g1_29dof")
+    oml = OML(skel, clips)
+    ocfg = fixture_config(cfgname, N, {"domain_rand.push_robots": False})
+    s = env.simulator
+    dr = dict(base_com_bias=s._base_com_bias.cpu(), link_mass_scale=s._link_mass_scale.cpu(), friction_coeffs=s.friction_coeffs.cpu(), base_mass_scale=s._base_mass_scale.cpu())
+    orc = GeneralTrackingOracle(ocfg, skel, oml, N, dr)
+    orc.env_origins = env.env_origins.cpu()
+    orc.ref_init_yaw = env.ref_init_yaw
+    orc.slot_clip = env._motion_lib.slot_clip.cpu().clone()
+    assert orc.slot_clip.tolist() == [i % M for i in range(N)]
+    D = 29
+    gen = torch.Generator().manual_seed(5)
+    mlen = oml.motion_len[orc.slot_clip]
+    start = torch.rand(N, generator=gen) * mlen
+    start[:48] = mlen[:48] - 0.05                        # motion-end time-outs (all three clips)
+    ep = torch.randint(0, 50, (N,), generator=gen)
+    st = {k: v.clone() for k, v in orc.s.items()}
+    st["motion_start_times"] = start; st["episode_length_buf"] = ep; st["last_episode_length_buf"] = ep.clone(); st["motion_len"] = mlen.clone()
+    st["kp_scale"] = 0.9 + 0.2 * torch.rand(N, D, generator=gen); st["kd_scale"] = 0.9 + 0.2 * torch.rand(N, D, generator=gen)
+    st["rfi_lim_scale"] = 0.5 + torch.rand(N, D, generator=gen); st["rao_scale"] = 0.1 * (torch.rand(N, D, generator=gen) - 0.5)
+    st["action_delay_idx"] = torch.randint(0, 3, (N,), generator=gen)
+    root, qp, qv, cf = synth_replay(oml, skel, N, T + 1, start, ep, orc.dt, orc.env_origins, 6, orc.feet, ids=orc.slot_clip)
+    st["root_states"], st["dof_pos"], st["dof_vel"], st["contact_forces"] = root[0], qp[0], qv[0], cf[0]
+    flat = {k: v.numpy() for k, v in st.items()}
+    for k in orc.sums:
+        flat["sum__" + k] = np.zeros(N, np.float32)
+    for k in orc.hist:
+        flat["hist__" + k] = (0.1 * torch.randn(orc.hist[k].shape, generator=gen)).numpy()
+    for k in orc.sigma:
+        flat["sigma__" + k] = orc.sigma[k]
+    flat.update(reward_penalty_scale=1.0, average_episode_length=0.0, motion_far_threshold=1.5)
+    orc.load_state(flat)
+    load_state_into_hip_env(env, flat)
+    tg = lambda a: a.contiguous().to(DEV)
+    env.simulator.set_replay(tg(root[1:]), tg(qp[1:]), tg(qv[1:]), tg(cf[1:]))
+    nreset = 0
+    for k in range(T):
+        act = 0.5 * torch.randn(N, D, generator=gen)
+        u = torch.rand(N, D, generator=gen)
+        samp = dict(motion_start_times=torch.rand(N, generator=gen) * mlen, kp_scale=0.9 + 0.2 * torch.rand(N, D, generator=gen),
+                    kd_scale=0.9 + 0.2 * torch.rand(N, D, generator=gen), rfi_lim_scale=0.5 + torch.rand(N, D, generator=gen),
+                    rao_scale=0.1 * (torch.rand(N, D, generator=gen) - 0.5), action_delay_idx=torch.randint(0, 3, (N,), generator=gen))
+        frame = dict(root=root[k + 1], dof_pos=qp[k + 1], dof_vel=qv[k + 1], contact=cf[k + 1])
+        body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
+        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp)
+        env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
+                               rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]))
+        obs, rew, reset, extras = env.step({"actions": tg(act)})
+        torch.cuda.synchronize()
+        w = f"step {k}: "
+        assert torch.equal(reset.cpu(), o_reset), w + f"reset mismatch {int((reset.cpu() != o_reset).sum())}"
+        nreset += int(o_reset.sum())
+        close(rew, o_rew, 3e-5, w + "rew", rtol=2e-4)
+        for ok in o_obs:       # env origins reach 110 m: position differences cancel at that magnitude (fp32 spacing 8e-6)
+            close(obs[ok], o_obs[ok], 1e-4, w + ok, hard=2e-3, frac=0.002)
+        close(env.motion_len, orc.s["motion_len"], 1e-6, w + "motion_len")
+        for name, view in env.history.items():
+            close(view, orc.hist[name], 3e-5, w + "hist " + name)
+    assert nreset >= 48
