@@ -173,3 +173,41 @@ class PPOMimicUpdate:
 
     def training_step_dagger(self, storage, perm):
         return self._epochs(storage, perm, self.update_dagger)
+
+
+class DistillUpdate:
+    """Student distillation, DAgger-only (ppo_mimic.py:157-191,343-357,711-724): the student acts with its mean on the history latent,
+    the frozen teacher actor acts on the teacher observation groups, bc_loss = mean ||a_teacher - mu_student||_2, one
+    clip_grad_norm_ + AdamW over the student ACTOR's parameters (history encoder copied from the teacher and frozen)."""
+
+    def __init__(self, student: ActorCriticOracle, teacher: ActorCriticOracle, cfg):
+        self.s, self.t, self.cfg = student, teacher, cfg
+        for k, v in student.p.items():
+            if k.startswith("actor_module.history_encoder."):
+                v.requires_grad_(False)
+        self.actor_params = [v for k, v in student.p.items() if k.startswith("actor_module.")]
+        self.opt = torch.optim.AdamW(self.actor_params, lr=cfg.learning_rate)
+
+    def teacher_actions(self, b):
+        tb = dict(b, actor_obs=b["teacher_actor_obs"], future_motion_targets=b["teacher_future_motion_targets"])
+        with torch.no_grad():
+            return self.t.actor_mean(tb, hist_encoding=True)
+
+    def update(self, b):
+        mu = self.s.actor_mean(b, hist_encoding=True)
+        bc = (b["teacher_actions"] - mu).norm(p=2, dim=1).mean()
+        self.opt.zero_grad()
+        bc.backward()
+        torch.nn.utils.clip_grad_norm_(self.actor_params, self.cfg.max_grad_norm)
+        self.opt.step()
+        return dict(bc_loss=bc.item())
+
+    def training_step(self, storage, perm):
+        c = self.cfg
+        flat = {k: v.flatten(0, 1)[perm].contiguous() for k, v in storage.items()}
+        mb = perm.numel() // c.num_mini_batches
+        tot = 0.0
+        for _ in range(c.num_learning_epochs):
+            for i in range(c.num_mini_batches):
+                tot += self.update({k: v[i * mb:(i + 1) * mb] for k, v in flat.items()})["bc_loss"]
+        return dict(bc_loss=tot / (c.num_learning_epochs * c.num_mini_batches))

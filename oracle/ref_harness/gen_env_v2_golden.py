@@ -177,7 +177,13 @@ def dump_fixture_config(variant, name, extra=None):
     from pbhc_amd.motion_lib import load_motion_file, save_motion_npz
     from pbhc_amd.skeleton import Skeleton
 
-    c = unresolved_tree(variant)
+    dump_fixture_tree(unresolved_tree(variant), name, extra)
+
+
+def dump_fixture_tree(c, name, extra=None):
+    from pbhc_amd.motion_lib import load_motion_file, save_motion_npz
+    from pbhc_amd.skeleton import Skeleton
+
     for k, v in dict(COMMON, **(extra or {})).items():
         if k != "simulator._target_":
             set_by_path(c, k, v)

@@ -15,3 +15,13 @@ class OmegaConf:
     @staticmethod
     def save(cfg, path):
         return None
+
+
+def _load(path):
+    # config container only: the repo's own YAML loader (resolved tree with attribute access)
+    from pbhc_amd.utils.config import load_config
+    return load_config(str(path), now="golden")
+
+
+OmegaConf.load = staticmethod(_load)
+OmegaConf.resolve = staticmethod(lambda cfg: None)

@@ -49,3 +49,27 @@ def test_ppo_mimic_maths_match_reference():
     for k, v in ac.p.items():
         assert torch.allclose(v.detach(), g["w2__" + k], atol=2e-5, rtol=1e-4), k
     assert up.counter == int(g["counter2"])
+
+
+def test_distillation_maths_match_reference():
+    """Student distillation (DAgger-only) of the reference ppo_mimic.PPO: teacher actions from the teacher observation groups,
+    student mean on the history latent, bc loss, AdamW over the actor (tests/golden/ppo_distill.npz)."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_distill.npz")).items() if v.dtype.kind in "fiub"}
+    scfg = fixture_config("v2_g1_23dof_student.yaml", 8, PPO_V2_NARROW)
+    tcfg = fixture_config("v2_g1_23dof_teacher.yaml", 8, PPO_V2_NARROW)
+    S, H = scfg.obs.future_num_steps, scfg.obs.history_length
+    student = ppo_v2.ActorCriticOracle({k[len("w0__"):]: v for k, v in g.items() if k.startswith("w0__")}, scfg.algo.config.module_dict, S, H)
+    teacher = ppo_v2.ActorCriticOracle({k[len("teacher__"):]: v for k, v in g.items() if k.startswith("teacher__")}, tcfg.algo.config.module_dict, S, H)
+    st = {k[len("st__"):]: v for k, v in g.items() if k.startswith("st__")}
+    up = ppo_v2.DistillUpdate(student, teacher, scfg.algo.config)
+    fl = {k: v.flatten(0, 1) for k, v in st.items()}
+    assert torch.allclose(up.teacher_actions(fl), fl["teacher_actions"], atol=1e-5)
+    with torch.no_grad():
+        assert torch.allclose(student.actor_mean(fl, hist_encoding=True), fl["actions"], atol=1e-5)       # dagger_only rollouts act with the mean
+    for k, v in student.p.items():          # the student's history encoder is the teacher's
+        if k.startswith("actor_module.history_encoder."):
+            assert torch.equal(v.detach(), g["teacher__" + k])
+    loss = up.training_step(st, g["perm"])
+    assert abs(loss["bc_loss"] - float(g["loss__bc_loss"])) < 1e-4
+    for k, v in student.p.items():
+        assert torch.allclose(v.detach(), g["w1__" + k], atol=2e-5, rtol=1e-4), k
