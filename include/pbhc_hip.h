@@ -33,7 +33,7 @@ extern "C" {
 #define PBHC_MAX_FEET 2
 #define PBHC_MAX_TERMS 32    /* reward terms (vector-reward heads - 1) */
 #define PBHC_MAX_IDX 36
-#define PBHC_MAX_GROUPS 6    /* observation groups + the history write-back map */
+#define PBHC_MAX_GROUPS 8    /* observation groups + the history write-back map */
 #define PBHC_MAX_QUEUE 8     /* control-delay queue depth */
 #define PBHC_NUM_SIGMA 20
 #define PBHC_NUM_GLOBALS 128

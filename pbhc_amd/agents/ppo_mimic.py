@@ -5,10 +5,11 @@ Same class surface as the reference (reference: humanoidverse/agents/ppo/ppo_mim
 the checkpoint dict (`model_state_dict`, `optimizer_state_dict` in torch.optim.AdamW's format, `iter`, `infos`) and every
 state_dict key are the reference's.  Select with `algo._target_: pbhc_amd.agents.ppo_mimic.PPO`.
 
-The teacher (RL) path of the reference is implemented: PPO on the privileged latent with the `priv_reg` term and, every
-`dagger_update_freq` iterations, the DAgger regression of the history encoder (ppo_mimic.py:270-300,596-709).  The student
-distillation path (`teacher_model_path` set) mutates the env's observation dict after construction in the reference; it is
-not part of this hot path and raises NotImplementedError.
+Both branches of the reference are implemented: the teacher (RL) path — PPO on the privileged latent with the `priv_reg` term
+and, every `dagger_update_freq` iterations, the DAgger regression of the history encoder (ppo_mimic.py:270-300,596-709) — and the
+student distillation path (`teacher_model_path` set, `dagger_only: True`; ppo_mimic.py:121-191,313-357,533-549,711-724): the frozen
+teacher actor acts on the teacher's observation groups, which are added to the env after construction as the reference does, and
+the student actor is regressed onto it (DAgger-only behaviour cloning; PPO-with-distillation raises in the reference too).
 
 MI355X-first differences (same maths, pinned by tests/golden/ppo_v2.npz): as pbhc_amd/agents/mh_ppo.py — no host
 synchronisation inside an iteration, fused sample / bootstrap / GAE / loss / clip+AdamW kernels over flat parameter buffers,
@@ -26,7 +27,7 @@ import torch.distributed as dist
 
 from .. import _lib
 from .. import dist as pdist
-from .agent_modules import ActorCritic
+from .agent_modules import Actor, ActorCritic
 from .mh_ppo import _make_writer
 from .modules import RolloutStorage
 
@@ -42,6 +43,8 @@ class _FlatAdamWView:
         names = [n for n, _ in a.alg.named_parameters()]
         if self.which == 1:
             names = [n for n in names if n.startswith("actor_module.history_encoder.")]
+        elif a.dagger_only:                                  # optim.AdamW(self.alg.actor.parameters()) (ppo_mimic.py:186-187)
+            names = [n for n in names if n.startswith("actor_module.")]
         return names
 
     def state_dict(self):
@@ -49,8 +52,7 @@ class _FlatAdamWView:
         state = {}
         stepped = float(a._adam_step[self.which]) > 0
         for i, n in enumerate(self._entries()):
-            is_hist = n.startswith("actor_module.history_encoder.")
-            if not stepped or (self.which == 0 and is_hist):       # never stepped: torch keeps no state for it
+            if not stepped or (self.which == 0 and not a._is_main(n)):       # never stepped: torch keeps no state for it
                 continue
             o, k, shape = a._slice_of[n]
             state[i] = {"step": a._adam_step[self.which].detach().clone().cpu(), "exp_avg": a._mflat[self.which][o:o + k].view(shape).clone(),
@@ -102,7 +104,7 @@ class PPO:
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world_size > 1 else 0
         _ = self.env.reset_all()
-        self.learn = self.learn_RL
+        self.learn = self.learn_RL if not self.train_distill else self.learn_distill
 
     def _init_config(self):
         c = self.config
@@ -132,13 +134,39 @@ class PPO:
         self.counter = 0
         self.train_distill = c.get("teacher_model_path", None) is not None
         self.dagger_only = bool(c.get("dagger_only", False))
-        if self.train_distill or self.dagger_only:
-            raise NotImplementedError("student distillation (teacher_model_path / dagger_only) is outside the hot path; "
-                                      "set algo.config.teacher_model_path=null and dagger_only=False for the RL path")
+        if self.dagger_only != self.train_distill:
+            # the reference: distillation without dagger_only raises NotImplementedError in _update_distill (ppo_mimic.py:724);
+            # dagger_only without a teacher stores no values/log-probs and fails in _update_ppo
+            raise NotImplementedError("ppo_mimic supports dagger_only=False without a teacher (RL) or dagger_only=True with teacher_model_path (distillation)")
+        if self.train_distill:
+            self._preprocess_teacher_config()
         if c.module_dict.get("actor", {}).get("type", "MLP") != "MLP" or c.module_dict.get("critic", {}).get("type", "MLP") != "MLP":
             raise NotImplementedError("MoEMLP actors/critics")
         self.dagger_update_freq = c.get("dagger_update_freq", 20)
         self.hist_encoding = False
+
+    def _preprocess_teacher_config(self):
+        """ppo_mimic.py:121-145: the teacher's actor / future-target observation groups are added to the env under `teacher_*` names and
+        the teacher's module config is rewritten to read them."""
+        from pathlib import Path
+
+        from ..envs import env_config
+        from ..utils.config import load_config
+
+        tc = load_config(str(Path(self.config.teacher_model_path).parent / "config.yaml"))
+        groups, _, _ = env_config.determine_obs_dim(tc)
+        od = self.env.config.obs.obs_dict
+        od["teacher_actor_obs"] = list(tc.obs.obs_dict["actor_obs"])
+        od["teacher_future_motion_targets"] = list(tc.obs.obs_dict["future_motion_targets"])
+        self.env.rebuild_observations()
+        self.algo_obs_dim_dict = self.env.config.robot.algo_obs_dim_dict
+        assert self.algo_obs_dim_dict["teacher_actor_obs"] == groups["actor_obs"] and self.algo_obs_dim_dict["teacher_future_motion_targets"] == groups["future_motion_targets"]
+        md = tc.algo.config.module_dict
+        swap = lambda dims: ["teacher_actor_obs" if x == "actor_obs" else x for x in dims]
+        md.actor.input_dim = swap(list(md.actor.input_dim))
+        md.critic.input_dim = swap(list(md.critic.input_dim))
+        md.actor.motion_encoder.input_dim = ["teacher_future_motion_targets"]
+        self.config.teacher_module_dict = md
 
     # ------------------------------------------------------------------------------------
     def setup(self):
@@ -152,7 +180,18 @@ class PPO:
         c = self.config
         if self.env.config.use_vec_reward:
             c.module_dict.critic["output_dim"][-1] = self.num_rew_fn
+        if self.train_distill:
+            self.teacher_actor = Actor(self.algo_obs_dim_dict, c.teacher_module_dict.actor, self.num_act).to(self.device)
+            sd = torch.load(c.teacher_model_path, map_location=self.device, weights_only=True)
+            self.teacher_actor.load_state_dict({k[len("actor_module."):]: v for k, v in sd["model_state_dict"].items() if k.startswith("actor_module.")}, strict=True)
+            for p in self.teacher_actor.parameters():
+                p.requires_grad = False
+            self.teacher_actor.eval()
         self.alg = ActorCritic(self.algo_obs_dim_dict, c.module_dict, self.num_act, c.init_noise_std).to(self.device)
+        if self.train_distill:
+            self.alg.actor.history_encoder.load_state_dict(self.teacher_actor.history_encoder.state_dict())
+            for p in self.alg.actor.history_encoder.parameters():
+                p.requires_grad_(False)
         if self.world_size > 1:
             for p in self.alg.parameters():
                 dist.broadcast(p.data, src=0)
@@ -163,8 +202,12 @@ class PPO:
         encoder never has a gradient in the PPO step, so torch skips it) steps the first segment, `hist_encoder_optimizer` the second."""
         dev = self.device
         named = list(self.alg.named_parameters())
-        main = [(n, p) for n, p in named if not n.startswith("actor_module.history_encoder.")]
-        hist = [(n, p) for n, p in named if n.startswith("actor_module.history_encoder.")]
+        if self.dagger_only:       # distillation: only the actor MLP and the motion encoder ever have a gradient (ppo_mimic.py:711-721)
+            self._is_main = lambda n: n.startswith("actor_module.actor_module.") or n.startswith("actor_module.motion_encoder.")
+        else:
+            self._is_main = lambda n: not n.startswith("actor_module.history_encoder.")
+        main = [(n, p) for n, p in named if self._is_main(n)]
+        hist = [(n, p) for n, p in named if not self._is_main(n)]
         self._n_main = sum(p.numel() for _, p in main)
         self._n_hist = sum(p.numel() for _, p in hist)
         n = self._n_main + self._n_hist
@@ -182,6 +225,7 @@ class PPO:
             self._slice_of[nme] = (o, k, tuple(p.shape))
             o += k
         self._std_slice = self._slice_of["std"][:2]
+        self._main_has_std = self._is_main("std")
         self._lr = torch.full((2,), float(self.learning_rate), device=dev)          # [0] is THE learning rate (the loss kernel adapts both)
         self._lr_hist = torch.full((1,), float(self.learning_rate), device=dev)     # hist_encoder_optimizer keeps its initial lr (ppo_mimic.py:184)
         self._adam_step = torch.zeros(2, device=dev)
@@ -210,6 +254,8 @@ class PPO:
         st.register_key("actions_log_prob", shape=(1,), dtype=torch.float)
         st.register_key("action_mean", shape=(self.num_act,), dtype=torch.float)
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
+        if self.train_distill:
+            st.register_key("teacher_actions", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
         self._last_obs = {k: torch.zeros(N, w, device=self.device) for k, w in self._obs_width.items()}
@@ -277,6 +323,81 @@ class PPO:
         self.current_learning_iteration = tot_iter
         if self.log_dir is not None and self.rank == 0:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    # ---- distillation (ppo_mimic.py:313-357,533-549,711-724) ----------------------------------
+    def learn_distill(self, num_iterations=None):
+        if self.init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs_dict = self.env.reset_all()
+        self._train_mode()
+        n = self.num_learning_iterations if num_iterations is None else num_iterations
+        tot_iter = self.current_learning_iteration + n
+        for it in range(self.current_learning_iteration, tot_iter):
+            self.hist_encoding = True
+            self.start_time = time.time()
+            obs_dict = self._rollout_step_distill(obs_dict)
+            loss_dict = self._training_step_distill()
+            self.stop_time = time.time()
+            self.learn_time = self.stop_time - self.start_time
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
+                                          num_learning_iterations=n))
+            if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
+                self.current_learning_iteration = it
+                self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+            self.ep_infos.clear()
+        self.current_learning_iteration = tot_iter
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def teacher_actor_act_step(self, obs_dict, hist_encoding=True):
+        return self.teacher_actor(obs_dict, hist_encoding, obs_key="teacher_actor_obs", target_key="teacher_future_motion_targets")
+
+    def _rollout_step_distill(self, obs_dict):
+        """DAgger-only rollout: the student acts with its mean on the history latent, the teacher's actions are recorded."""
+        st, env, lib = self.storage, self.env, _lib.lib()
+        T, N, R = self.num_steps_per_env, env.num_envs, self.num_rew_fn
+        keys = list(self._obs_width.keys())
+        stream = _lib.current_stream()
+        with torch.inference_mode():
+            for k in keys:
+                getattr(st, k)[0].copy_(obs_dict[k])
+            for t in range(T):
+                b = {k: getattr(st, k)[t] for k in keys}
+                st.teacher_actions[t].copy_(self.teacher_actor_act_step(b, hist_encoding=True))
+                st.actions[t].copy_(self.alg.act_inference(b, hist_encoding=True))
+                env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
+                nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
+                _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                 0.0, st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                 self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+            st.step = T
+            self.stop_time = time.time()
+            self.collection_time = self.stop_time - self.start_time
+            self.start_time = self.stop_time
+        return self._last_obs
+
+    def _training_step_distill(self, indices=None):
+        loss = {"bc_loss": torch.zeros((), device=self.device)}
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs,
+                                                       keys=["actor_obs", "future_motion_targets", "prop_history", "teacher_actions"], indices=indices):
+            self._update_distill(batch, loss)
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        out = {k: v / n for k, v in loss.items()}
+        for k in ["Value", "Entropy", "Surrogate", "Actor_Load_Balancing_Loss", "Critic_Load_Balancing_Loss"]:
+            out[k] = torch.zeros((), device=self.device)
+        return out
+
+    def _update_distill(self, b, loss):
+        mu = self.alg.act_inference(b, hist_encoding=True)
+        bc = (b["teacher_actions"] - mu).norm(p=2, dim=1).mean()
+        self._gflat[: self._n_main].zero_()
+        bc.backward()
+        if self.world_size > 1:
+            pdist.allreduce_mean_(self._gflat[: self._n_main])
+        self._adam(0, 0, self._n_main, self._lr[0:1])
+        loss["bc_loss"] += bc.detach()
+        return loss
 
     # ---- forward pieces ---------------------------------------------------------------------
     def _forward(self, b, hist_encoding, want_value=True):

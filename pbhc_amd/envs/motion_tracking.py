@@ -74,10 +74,9 @@ class LeggedRobotMotionTracking:
             self.simulator._body_list.append(e["joint_name"])           # motion_tracking.py:226
         self.num_extend_bodies = len(rc.motion.get("extend_config", []))
         # ---- static config -> device
-        top = _TopView(config)
-        seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
-        self._c, self.layout = env_config.build(top, self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1], seed=seed,
-                                                mode=self.TRACKING_MODE)
+        self._seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        self._c, self.layout = env_config.build(_TopView(config), self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1],
+                                                seed=self._seed, mode=self.TRACKING_MODE)
         L = self.layout
         self.reward_names = L.reward_names
         self.reward_scales = L.reward_scales
@@ -93,6 +92,7 @@ class LeggedRobotMotionTracking:
         self._env = C.c_void_p()
         _lib.check(self._lib.pbhc_env_create(C.byref(self._c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(self._env)), "pbhc_env_create")
         self._init_buffers()
+        self._init_obs_buffers()
         self._build_io()
         self.log_dict = {}
         self.extras = {}
@@ -150,13 +150,33 @@ class LeggedRobotMotionTracking:
         self.time_out_buf = torch.zeros(N, dtype=torch.bool, device=dev)
         self.motion_ids = torch.arange(N, device=dev)
         self.rew_buf = f(N, L.num_rew_fn) if self.config.use_vec_reward else f(N)
-        self._own_obs = {g: f(N, L.group_dims[g]) for g in L.group_names[:-1]}
-        self.obs_buf_dict = dict(self._own_obs)
         Bx = self.skeleton.num_bodies_ext
         self.ref_body_pos_extend, self.ref_body_rot_extend = f(N, Bx, 3), f(N, Bx, 4)
         self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(D)], device=dev).repeat(N, 1)
         self.p_gains = torch.tensor([self._c.p_gains[i] for i in range(D)], device=dev)
         self.d_gains = torch.tensor([self._c.d_gains[i] for i in range(D)], device=dev)
+
+    def _init_obs_buffers(self):
+        L = self.layout
+        self._own_obs = {g: torch.zeros(self.num_envs, L.group_dims[g], dtype=torch.float32, device=self.device) for g in L.group_names[:-1]}
+        self.obs_buf_dict = dict(self._own_obs)
+
+    def rebuild_observations(self):
+        """Re-derive the observation maps after `config.obs.obs_dict` changed (the reference re-reads the dict every step, so
+        ppo_mimic's distillation adds the teacher's observation groups after the env exists, ppo_mimic.py:131-134).  State is kept;
+        the set of history keys must not change."""
+        old = self.layout
+        c, L = env_config.build(_TopView(self.config), self.skeleton, self._motion_lib, self.num_envs, self.device, self.simulator._link_mass_scale.shape[1],
+                                seed=self._seed, mode=self.TRACKING_MODE)
+        if (L.hist_keys, L.hist_len, L.hist_dim) != (old.hist_keys, old.hist_len, old.hist_dim) or L.sum_names != old.sum_names:
+            raise _lib.PbhcError("rebuild_observations: history keys / reward terms changed")
+        c.ref_init_yaw = self.ref_init_yaw
+        env = C.c_void_p()
+        _lib.check(self._lib.pbhc_env_create(C.byref(c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(env)), "pbhc_env_create")
+        self._lib.pbhc_env_destroy(self._env)
+        self._env, self._c, self.layout = env, c, L
+        self._init_obs_buffers()
+        self._build_io()
 
     @property
     def history(self):

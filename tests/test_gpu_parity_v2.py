@@ -216,3 +216,54 @@ def test_general_tracking_multi_clip_matches_oracle():
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
     assert nreset >= 48
+
+
+def test_ppo_mimic_distillation_matches_reference(tmp_path):
+    """Student distillation (teacher_model_path + dagger_only): the teacher observation groups are added to the existing env, the teacher
+    actor is loaded from a checkpoint + config.yaml, and one _training_step_distill on the reference's rollout buffer / permutation
+    reproduces the reference's student weights and bc loss (tests/golden/ppo_distill.npz)."""
+    from pbhc_amd.agents.ppo_mimic import PPO
+    from pbhc_amd.utils.config import load_unresolved, save_unresolved, set_by_path
+    from tests.helpers import PPO_V2_NARROW
+
+    raw = np.load(os.path.join(GOLDEN, "ppo_distill.npz"))
+    g = {k: torch.from_numpy(raw[k]) for k in raw.files if raw[k].dtype.kind in "fiub"}
+    # the teacher's checkpoint + composed config next to it, as the reference expects them (ppo_mimic.py:127-128,165)
+    tdir = tmp_path / "teacher"
+    tdir.mkdir()
+    tc = load_unresolved(os.path.join(GOLDEN, "configs", "v2_g1_23dof_teacher.yaml"))
+    for k, v in PPO_V2_NARROW.items():
+        set_by_path(tc, k, v)
+    for k in ("motion_file",):
+        tc["robot"]["motion"][k] = os.path.join(os.path.dirname(GOLDEN), "..", tc["robot"]["motion"][k])
+    save_unresolved(tc, str(tdir / "config.yaml"))
+    torch.save({"model_state_dict": {k[len("teacher__"):]: v for k, v in g.items() if k.startswith("teacher__")}, "iter": 0, "infos": None}, str(tdir / "model_0.pt"))
+    N = g["st__actions"].shape[1]
+    ov = dict(PPO_V2_NARROW)
+    ov.update({"domain_rand.push_robots": False, "algo.config.teacher_model_path": str(tdir / "model_0.pt"), "algo.config.dagger_only": True})
+    cfg, env = build_hip_env("v2_g1_23dof_student.yaml", N, general=True, overrides=ov)
+    algo = PPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+    algo.setup()
+    assert list(env.obs_buf_dict.keys()) == [str(k) for k in raw["obs_keys"]]
+    assert [f"{k}={v}" for k, v in algo.algo_obs_dim_dict.items()] == [str(x) for x in raw["algo_obs_dims"]]
+    algo.alg.load_state_dict({k[len("w0__"):]: v for k, v in g.items() if k.startswith("w0__")}, strict=True)
+    for k in algo.storage.stored_keys:
+        getattr(algo.storage, k).copy_(g["st__" + k].to(DEV))
+    algo._train_mode()
+    with torch.no_grad():
+        b = {k: getattr(algo.storage, k).flatten(0, 1) for k in algo._obs_width}
+        close(algo.teacher_actor_act_step(b), g["st__teacher_actions"].flatten(0, 1), 2e-5, "teacher actions")
+        close(algo.alg.act_inference(b, hist_encoding=True), g["st__actions"].flatten(0, 1), 2e-5, "student mean")
+    loss = algo._training_step_distill(indices=g["perm"].to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss["bc_loss"]) - float(g["loss__bc_loss"])) < 2e-4
+    for k, v in algo.alg.state_dict().items():
+        ref = g["w1__" + k]
+        close(v, ref, 2e-4, "w1 " + k, rtol=2e-4)
+    # the env still steps with the two extra groups, and a short distillation run stays finite
+    algo.learn(num_iterations=1)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in algo.alg.parameters())
+    assert env.obs_buf_dict["teacher_future_motion_targets"].shape == (N, 57 * 20)
+    d = algo.optimizer.state_dict()
+    assert len(d["param_groups"][0]["params"]) == len(list(algo.alg.actor.parameters()))
