@@ -166,12 +166,13 @@ typedef struct PbhcOutMap {
   const int32_t* src;        /* device [dim] index into the feature row */
   const float* scale;        /* device [dim] */
   const float* noise;        /* device [dim] noise scale (0 = none) */
+  /* compact form (PbhcEnvConfig.map_image): word offset and size of this group's block
+   * [seg_scale 16 floats][seg_noise 16 floats][nn][nn noisy entries: j | word[j] << 16][u16 word[j] x dim], word[j] = src[j] | seg[j] << 12 */
+  int32_t lds_off;
+  int32_t map_words;
 } PbhcOutMap;
+#define PBHC_MAX_SEGS 16
 
-/* ---- early history scatter.  Old history (HistoryHandler buffers, history_handler.py:10-48) feeds the outputs unchanged
- * (scale 1, no noise): element i of the packed history row goes to position p_g(i) of output group g — the history_* slices
- * of the observation groups and, shifted by one step, the history write-back.  hist_pack[i*words + w] packs, `bits` bits per
- * group, the values p_g(i)+1 (0 = group g does not carry element i), group g in word g / (32/bits), field g % (32/bits). --- */
 /* ---- static configuration of the env (tracking_mode 0: LeggedRobotMotionTracking, 1: LeggedRobotGeneralTracking) -----
  * Filled by the host from the reference's YAML config tree (same keys); copied to the device by
  * pbhc_env_create. */
@@ -235,9 +236,11 @@ typedef struct PbhcEnvConfig {
   int32_t hist_dim;                          /* floats of history state per env */
   int32_t num_groups;
   PbhcOutMap groups[PBHC_MAX_GROUPS];
-  int32_t hist_pack_bits;                    /* 0: no early history scatter (everything goes through the maps); else 10 or 16 */
-  int32_t hist_pack_words;
-  const int32_t* hist_pack;                  /* device [hist_dim * hist_pack_words] */
+  /* compact observation maps, staged in LDS once per workgroup when they fit without costing occupancy (requires identity dst,
+   * feat_dim <= 4096 and at most PBHC_MAX_SEGS distinct (scale, noise) pairs per group): the concatenated group blocks */
+  int32_t map_lds_words;                     /* 0: none */
+  int32_t pad3_;
+  const uint32_t* map_image;                 /* device [map_lds_words] */
   int32_t has_contact_mask;
   float ref_init_yaw;
   int32_t dr_link_mass_dim;
@@ -280,7 +283,8 @@ typedef struct PbhcStepIO {
   const float* frame_contact;     /* [T,N,B,3] net contact forces                              */
   int32_t* frame_cursor;          /* device int32[1]                                           */
   int32_t num_frames;             /* T                                                         */
-  int32_t pad0_;
+  int32_t frame_index;            /* >= 0: the host names the frame (saves the kernel a dependent load; the device cursor is still
+                                     advanced); < 0: read the device cursor (hipGraph replay)  */
   /* optional injected random draws (NULL -> in-kernel Philox) */
   const float* u_rfi;             /* [N,D] uniforms of the torque RFI noise                    */
   const float* ovr_start_time;    /* [N]   values consumed by resetting envs                   */
@@ -311,6 +315,11 @@ typedef struct PbhcStepIO {
   float* ref_body_pos_extend;     /* [N,Bx,3] may be NULL */
   float* ref_body_rot_extend;     /* [N,Bx,4] may be NULL */
   float* episode_rew_out;         /* [N,num_sum_cols] episode_sums / max_episode_length_s of envs reset this step (else unchanged), may be NULL */
+  /* row pitches in floats (0 = dense).  Rows padded to a multiple of 32 floats start on 128-B lines: no cache line is shared by two envs,
+   * so no line is written twice by different workgroups. */
+  int32_t obs_pitch[PBHC_MAX_GROUPS];
+  int32_t hist_pitch;
+  int32_t pad1_;
 } PbhcStepIO;
 
 typedef struct PbhcEnv PbhcEnv;   /* opaque */

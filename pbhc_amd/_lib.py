@@ -151,6 +151,19 @@ def current_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def require_gpu_rows(t, name, dtype=None, shape=None):
+    """as require_gpu_tensor, but rows may be padded: [N, C] with stride (pitch >= C, 1)"""
+    import torch
+
+    if not (torch.is_tensor(t) and t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        raise PbhcError(f"{name}: expected a CUDA(HIP) [N, C] tensor with unit inner stride")
+    if dtype is not None and t.dtype != dtype:
+        raise PbhcError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise PbhcError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
 def require_gpu_tensor(t, name, dtype=None, shape=None):
     """host-side shape/dtype/device check before a raw pointer crosses the ABI"""
     import torch

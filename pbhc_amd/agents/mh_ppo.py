@@ -204,7 +204,7 @@ class MHPPO:
             self.actor.actor_module._fused = None
             self.critic.critic_module._fused = None
         for k, d in self.algo_obs_dim_dict.items():
-            st.register_key(k, shape=(d,), dtype=torch.float)
+            st.register_key(k, shape=(d,), dtype=torch.float, pad_rows=True)
             if self._need_next:
                 st.register_key("next_" + k, shape=(d,), dtype=torch.float)
         st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
@@ -218,7 +218,7 @@ class MHPPO:
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, d, device=self.device) for k, d in self.algo_obs_dim_dict.items()}
+        self._last_obs = {k: torch.zeros(N, (d + 31) // 32 * 32, device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
         self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd MHPPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")

@@ -131,10 +131,14 @@ class RolloutStorage(nn.Module):
         self.step = 0
         self.stored_keys = []
 
-    def register_key(self, key, shape=(), dtype=torch.float):
+    def register_key(self, key, shape=(), dtype=torch.float, pad_rows=False):
+        """pad_rows: the [N, C] slab of each step is a view of [N, ceil32(C)] rows, so that the env kernel writes whole 128-B lines."""
         assert not hasattr(self, key), key
         assert isinstance(shape, (list, tuple)), "shape must be a list or tuple"
-        buf = torch.zeros((self.num_transitions_per_env, self.num_envs) + tuple(shape), dtype=dtype, device=self.device)
+        if pad_rows and len(shape) == 1:
+            buf = torch.zeros((self.num_transitions_per_env, self.num_envs, (shape[0] + 31) // 32 * 32), dtype=dtype, device=self.device)[..., :shape[0]]
+        else:
+            buf = torch.zeros((self.num_transitions_per_env, self.num_envs) + tuple(shape), dtype=dtype, device=self.device)
         self.register_buffer(key, buf, persistent=False)
         self.stored_keys.append(key)
 

@@ -244,7 +244,7 @@ class PPO:
         for k, d in self.algo_obs_dim_dict.items():
             w = d * S if k in ("future_motion_targets", "teacher_future_motion_targets") else d      # ppo_mimic.py:206-216
             self._obs_width[k] = w
-            st.register_key(k, shape=(w,), dtype=torch.float)
+            st.register_key(k, shape=(w,), dtype=torch.float, pad_rows=True)
         st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
         st.register_key("rewards", shape=(self.num_rew_fn,), dtype=torch.float)
         st.register_key("dones", shape=(1,), dtype=torch.bool)
@@ -258,7 +258,7 @@ class PPO:
             st.register_key("teacher_actions", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, w, device=self.device) for k, w in self._obs_width.items()}
+        self._last_obs = {k: torch.zeros(N, (w + 31) // 32 * 32, device=self.device)[:, :w] for k, w in self._obs_width.items()}
         self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd PPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")

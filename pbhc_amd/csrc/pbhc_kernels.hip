@@ -75,20 +75,25 @@ enum {
 };
 static_assert(R_NUM <= 80, "RED region");
 
-// per-env LDS layout (floats); body arrays sized for PBHC_MAX_BODIES = 36
+// per-env LDS layout (floats); the body arrays are sized for the robot at hand (Bx rounded up to 4)
 struct Lds {
   enum {
     ACT = 0, ACTD = 32, TAU = 64, Q = 96, QD = 128, RDOF = 160, RDOFV = 192,          // 7 x 32
     ROOT = 224,                                                                      // 16
     MISC = 240,                                                                      // 48: scalars
     CF = 288,                                                                        // 108 contact forces
-    BP = 396, BQ = 504, BV = 648, BW = 756,                                          // body pos3/quat4/vel3/ang3 x36
-    RP = 864, RQ = 972, RV = 1116, RW = 1224,                                        // reference, same shapes
-    RED = 1332,                                                                      // 80
-    FUT = 1412,                                                                      // general tracking: 10 x PBHC_MAX_FUTURE per-step scratch
-    FEAT_V1 = 1412, FEAT_V2 = 1412 + 10 * PBHC_MAX_FUTURE
+    BP = 396,                                                                        // body pos3/quat4/vel3/ang3 x Bxp, then the reference's, same shapes
+    RED_WORDS = 80, FUT_WORDS = 10 * PBHC_MAX_FUTURE                                 // reductions; general tracking: per-step future scratch
   };
-  static __host__ __device__ constexpr int feat(int mode) { return mode ? FEAT_V2 : FEAT_V1; }
+  int bq, bv, bw, rp, rq, rv, rw, red, fut, feat;
+  __host__ __device__ explicit Lds(int Bx, int mode) {
+    const int p = (Bx + 3) & ~3;
+    bq = BP + 3 * p; bv = bq + 4 * p; bw = bv + 3 * p;
+    rp = bw + 3 * p; rq = rp + 3 * p; rv = rq + 4 * p; rw = rv + 3 * p;
+    red = rw + 3 * p;
+    fut = red + RED_WORDS;
+    feat = fut + (mode ? FUT_WORDS : 0);
+  }
 };
 // MISC slots
 enum {
@@ -131,32 +136,19 @@ __device__ __forceinline__ void copy_g2l(float* dst, const float* __restrict__ s
   }
 }
 
-// Old-history element of one env -> every output row that carries it unchanged (see hist_pack in pbhc_hip.h): observation
-// groups (clipped) and the one-step-shifted history write-back.  The reset path rewrites those positions with zeros.
-__device__ __forceinline__ void hist_scatter(const PbhcEnvConfig& c, const PbhcStepIO& io, int env, const int* words, float v) {
-  const int bits = c.hist_pack_bits, per = 32 / bits;
-  const unsigned mask = (1u << bits) - 1u;
-  for (int g = 0; g < c.num_groups; ++g) {
-    const unsigned f = ((unsigned)words[g / per] >> (bits * (g % per))) & mask;
-    if (f) {
-      float x = v;
-      if (c.groups[g].clip) x = clampf(x, -c.clip_observations, c.clip_observations);
-      io.obs[g][(size_t)env * c.groups[g].pitch + (f - 1)] = x;
-    }
-  }
-}
-
 // ---- skeleton constants staged once per workgroup in LDS (shared by its envs) -------------------
 // per body b: off[3] lq_xyzw[4] axis[3] chain_len chain[PBHC_MAX_DEPTH]
 #define SKC_W (11 + PBHC_MAX_DEPTH)
 #define SKC_WORDS (PBHC_MAX_BODIES * SKC_W)
-__device__ __forceinline__ float skel_word(const PbhcSkeleton& sk, int i) {
+__host__ __device__ __forceinline__ float skel_word(const PbhcSkeleton& sk, int i) {
   int b = i / SKC_W, w = i - b * SKC_W;
   if (w < 3) return sk.offset[b][w];
   if (w < 7) return sk.local_rot_wxyz[b][(w - 3 + 1) & 3];                 // wxyz -> xyzw
   if (w < 10) return (b >= 1 && b < sk.num_bodies) ? sk.dof_axis[b - 1][w - 7] : 0.0f;
-  if (w == 10) return __int_as_float(sk.chain_len[b]);
-  return __int_as_float(sk.chain[b][w - 11]);
+  int iv = (w == 10) ? sk.chain_len[b] : sk.chain[b][w - 11];
+  float fv;
+  memcpy(&fv, &iv, sizeof(fv));
+  return fv;
 }
 __device__ __forceinline__ void stage_skeleton(const PbhcSkeleton& sk, float* skc) {
   const int n = sk.num_bodies_ext * SKC_W;
@@ -167,6 +159,19 @@ __device__ __forceinline__ void stage_skeleton(const PbhcSkeleton& sk, float* sk
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x; if (i < n) skc[i] = v[u]; }
   }
+}
+// the same in two halves for the step kernel (128 threads, <= 8 words each): loads first, LDS stores after the other prologue loads are issued
+#define SKC_REGS ((SKC_WORDS + PBHC_G * PBHC_EPB - 1) / (PBHC_G * PBHC_EPB))
+// `img`: the SKC image built on the host at pbhc_env_create (plain coalesced loads; building it word by word from the struct in the kernel
+// cost one dependent memory round trip per register)
+__device__ __forceinline__ void stage_skeleton_load(const float* __restrict__ img, int n, float* v) {
+#pragma unroll
+  for (int u = 0; u < SKC_REGS; ++u) { const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB); v[u] = i < n ? img[i] : 0.0f; }
+}
+__device__ __forceinline__ void stage_skeleton_store(const PbhcSkeleton& sk, float* skc, const float* v) {
+  const int n = sk.num_bodies_ext * SKC_W;
+#pragma unroll
+  for (int u = 0; u < SKC_REGS; ++u) { const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB); if (i < n) skc[i] = v[u]; }
 }
 
 // ---- rigid-body pose + twist of every body (what Isaac Gym's rigid-body state tensor held in the
@@ -262,7 +267,7 @@ extern __shared__ float smem[];
 template <int MODE>
 __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
-                                                              int lds_stride) {
+                                                              int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
   // whose scalars fold into the instruction stream; pointers, seed, env count and reference yaw always come from `rt`.
   const PbhcEnvConfig& rt = *cfgp;
@@ -279,17 +284,32 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float* S = smem + (size_t)le * lds_stride;
   float *act = S + Lds::ACT, *actd = S + Lds::ACTD, *tau = S + Lds::TAU, *q = S + Lds::Q, *qd = S + Lds::QD;
   float *rdof = S + Lds::RDOF, *rdofv = S + Lds::RDOFV, *root = S + Lds::ROOT, *misc = S + Lds::MISC, *cf = S + Lds::CF;
-  float *bp = S + Lds::BP, *bq = S + Lds::BQ, *bv = S + Lds::BV, *bw = S + Lds::BW;
-  float *rp = S + Lds::RP, *rq = S + Lds::RQ, *rv = S + Lds::RV, *rw = S + Lds::RW;
-  float *red = S + Lds::RED, *feat = S + Lds::feat(MODE);
-  const size_t fk = (size_t)(io.frame_cursor[0] % io.num_frames) * (size_t)N;   // replay frame of this step (device-side cursor)
+  const Lds lo(Bx, MODE);
+  float *bp = S + Lds::BP, *bq = S + lo.bq, *bv = S + lo.bv, *bw = S + lo.bw;
+  float *rp = S + lo.rp, *rq = S + lo.rq, *rv = S + lo.rv, *rw = S + lo.rw;
+  float *red = S + lo.red, *feat = S + lo.feat;
+  // replay frame of this step: named by the host, or read from the device-side cursor
+  const size_t fk = (size_t)(io.frame_index >= 0 ? io.frame_index : io.frame_cursor[0] % io.num_frames) * (size_t)N;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
   float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
+  uint32_t* mapl = (uint32_t*)(blockpart + PBHC_EPB * PBHC_NP);   // [map_lds_words] compact observation maps, shared by the workgroup
   const float dt = c.dt;
   const size_t eD = (size_t)env * D;
   STAMP(0);
-  stage_skeleton(sk, skc);
+  float skreg[SKC_REGS];
+  stage_skeleton_load(skc_img, Bx * SKC_W, skreg);
+  // compact observation maps: loads ISSUED here (registers), written to LDS at the end of the prologue (consumed in phase I)
+#define PBHC_MAPREG (MODE ? 16 : 8)
+  uint32_t mreg[PBHC_MAPREG];
+  const int map_words = c.map_lds_words;
+  if (map_words > 0) {
+#pragma unroll
+    for (int u = 0; u < PBHC_MAPREG; ++u) {
+      const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB);
+      mreg[u] = i < map_words ? map_img[i] : 0u;
+    }
+  }
 
   // ---------------- prologue + phase A: every global load that does not depend on this step's compute is ISSUED here,
   // in the order it is needed (frame q / q-dot / root first: the FK chain waits only for them; the history, the per-dof
@@ -314,66 +334,63 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   float clipcnt = 0.0f;
   const int hoff = c.feat_off[PBHC_F_HISTORY];
   const int Q = c.queue_len;
+  // Branch-free load section: every index is clamped into range instead of predicating the load, so that the whole section is one
+  // basic block and the loads issue back to back (a predicated load costs a branch, a zero-initialised phi and, in practice, an early
+  // s_waitcnt when the allocator recycles the register of a load still in flight).  Out-of-range lanes read a neighbour's value and
+  // never use it; a tail workgroup's missing envs read env N-1.
+  const int envc = valid ? env : N - 1;
+  const size_t eDc = (size_t)envc * D;
+  const int d = lane;                         // D <= 32: one dof per lane
+  const int dc = min(lane, D - 1);
+  float sumrow = 0.0f;                        // episode_sums[env][lane]; a term's own column is fetched with a shuffle in phase F
+  // (1) what the FK chain needs
+  const float fq = io.frame_dof_pos[fk * D + eDc + dc], fqd = io.frame_dof_vel[fk * D + eDc + dc];
+  const float froot = io.frame_root[(fk + envc) * 13 + min(lane, 12)];
+  // (2) env scalars -> reference-frame address
+  ep1 = io.episode_length_buf[envc] + 1;
+  start = io.motion_start_times[envc];
+  mlen_env = io.motion_len[envc];
+  mid = (int)io.motion_ids[envc];
+  origin = ld3(io.env_origins + (size_t)envc * 3);
+  // (3) everything else of this step, into registers
+  float hreg[PBHC_HREG];
+  {
+    const float* __restrict__ hsrc = io.hist + (size_t)envc * (io.hist_pitch ? io.hist_pitch : c.hist_dim);
+    const int hlast = c.hist_dim - 1;
+#pragma unroll
+    for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = hsrc[min(lane + u * PBHC_G, hlast)];
+  }
+  float creg[4];
+  {
+    const float* __restrict__ csrc = io.frame_contact + (fk + envc) * (size_t)(B * 3);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) creg[u] = csrc[min(lane + u * PBHC_G, B * 3 - 1)];
+  }
+  float qold[PBHC_MAX_QUEUE];
+  float* qu = io.action_queue + (size_t)envc * Q * D + dc;
+#pragma unroll
+  for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = qu[(size_t)min(k, Q - 1) * D];
+  const float a_in = io.actions_in[eDc + dc];
+  const float qp = io.dof_state[(eDc + dc) * 2], qv = io.dof_state[(eDc + dc) * 2 + 1];
+  const float kp = io.kp_scale[eDc + dc], kd = io.kd_scale[eDc + dc], rfs = io.rfi_lim_scale[eDc + dc], ras = io.rao_scale[eDc + dc];
+  const float u_inj = (io.u_rfi ? io.u_rfi : io.actions_in)[eDc + dc];
+  pf_last_act = io.last_actions[eDc + dc]; pf_last_qd = io.last_dof_vel[eDc + dc];
+  const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
+  const float bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
+  const int nlm = max(c.dr_link_mass_dim, 1);
+  const float lmreg = (c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com)[(size_t)envc * nlm + min(lane, nlm - 1)];
+  const float combias = io.dr_base_com[(size_t)envc * 3 + min(lane, 2)];
+  const float fric = io.dr_friction[envc];
+  const float fat = io.feet_air_time[(size_t)envc * NF + min(lane, NF - 1)], lastc = io.last_contacts[(size_t)envc * NF + min(lane, NF - 1)];
+  {
+    const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
+    pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_];
+    sumrow = io.episode_sums[(size_t)envc * c.num_sum_cols + min(lane, c.num_sum_cols - 1)];
+    pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
+  }
+  float u_rfi = 0.5f;
+  if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
   if (valid) {
-    const int d = lane;                       // D <= 32: one dof per lane
-    // (1) what the FK chain needs
-    float fq = 0, fqd = 0, froot = 0;
-    if (d < D) { fq = io.frame_dof_pos[fk * D + eD + d]; fqd = io.frame_dof_vel[fk * D + eD + d]; }
-    if (lane < 13) froot = io.frame_root[(fk + env) * 13 + lane];
-    // (2) env scalars -> reference-frame address
-    ep1 = io.episode_length_buf[env] + 1;
-    start = io.motion_start_times[env];
-    mlen_env = io.motion_len[env];
-    mid = (int)io.motion_ids[env];
-    origin = ld3(io.env_origins + (size_t)env * 3);
-    // (3) everything else of this step, into registers
-    float hreg[PBHC_HREG];
-    int hpk[PBHC_HREG][2];
-    {
-      const float* __restrict__ hsrc = io.hist + (size_t)env * c.hist_dim;
-#pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) {
-        const int i = lane + u * PBHC_G;
-        const bool ok = i < c.hist_dim;
-        hreg[u] = ok ? hsrc[i] : 0.0f;
-        hpk[u][0] = (ok && c.hist_pack_bits) ? rt.hist_pack[(size_t)i * c.hist_pack_words] : 0;
-        hpk[u][1] = (ok && c.hist_pack_bits && c.hist_pack_words > 1) ? rt.hist_pack[(size_t)i * c.hist_pack_words + 1] : 0;
-      }
-    }
-    float creg[4];
-    {
-      const float* __restrict__ csrc = io.frame_contact + (fk + env) * (size_t)(B * 3);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = lane + u * PBHC_G; creg[u] = i < B * 3 ? csrc[i] : 0.0f; }
-    }
-    float a_in = 0, qp = 0, qv = 0, kp = 0, kd = 0, rfs = 0, ras = 0, u_rfi = 0.5f, qold[PBHC_MAX_QUEUE];
-    int didx = 0;
-    float* qu = io.action_queue + (size_t)env * Q * D + d;
-#pragma unroll
-    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = 0.0f;
-    if (d < D) {
-      a_in = io.actions_in[eD + d];
-#pragma unroll
-      for (int k = 0; k < PBHC_MAX_QUEUE; ++k) if (c.randomize_ctrl_delay && k < Q) qold[k] = qu[(size_t)k * D];
-      qp = io.dof_state[(eD + d) * 2]; qv = io.dof_state[(eD + d) * 2 + 1];
-      kp = io.kp_scale[eD + d]; kd = io.kd_scale[eD + d]; rfs = io.rfi_lim_scale[eD + d]; ras = io.rao_scale[eD + d];
-      if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? io.u_rfi[eD + d] : rng_uniform(rt.seed, env, step_ctr, 1, d);
-      pf_last_act = io.last_actions[eD + d]; pf_last_qd = io.last_dof_vel[eD + d];
-    }
-    didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[env] : 0;
-    float lmreg = 0, combias = 0, fric = 0, fat = 0, lastc = 0, bmass = 1.0f;
-    if (MODE && lane == 0 && io.dr_base_mass) bmass = io.dr_base_mass[env];
-    if (lane < c.dr_link_mass_dim) lmreg = io.dr_link_mass[(size_t)env * c.dr_link_mass_dim + lane];
-    if (lane < 3) combias = io.dr_base_com[(size_t)env * 3 + lane];
-    if (lane == 0) fric = io.dr_friction[env];
-    if (lane < NF) { fat = io.feet_air_time[(size_t)env * NF + lane]; lastc = io.last_contacts[(size_t)env * NF + lane]; }
-    if (lane < c.num_terms) {
-      pf_tid = c.term_id[lane]; pf_tscale = c.term_scale[lane]; pf_tpen = c.term_penalty[lane]; pf_tcol = c.term_sum_col[lane];
-      pf_sum = io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol];
-    }
-    if (lane < PBHC_NUM_SIGMA) pf_sigma = (float)glob[PBHC_G_SIGMA + lane];
-    if (c.has_termination && lane == c.num_terms - 1) pf_termsum = io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col];
-
     // ---- consume (1): frame state -> LDS for the FK chain
     if (d < D) { q[d] = fq; qd[d] = fqd; }
     if (lane < 13) root[lane] = froot;
@@ -390,25 +407,21 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
     }
     const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
-    if (lane < Bx) {
-      rp0 = ld3(r0 + o_pos + 3 * lane); rp1 = ld3(r1 + o_pos + 3 * lane);
-      rq0 = ld4(r0 + o_rot + 4 * lane); rq1 = ld4(r1 + o_rot + 4 * lane);
-      rv0 = ld3(r0 + o_vel + 3 * lane); rv1 = ld3(r1 + o_vel + 3 * lane);
-      rw0 = ld3(r0 + o_ang + 3 * lane); rw1 = ld3(r1 + o_ang + 3 * lane);
+    {
+      const int lb = min(lane, Bx - 1), lc = min(lane, 1);
+      rp0 = ld3(r0 + o_pos + 3 * lb); rp1 = ld3(r1 + o_pos + 3 * lb);
+      rq0 = ld4(r0 + o_rot + 4 * lb); rq1 = ld4(r1 + o_rot + 4 * lb);
+      rv0 = ld3(r0 + o_vel + 3 * lb); rv1 = ld3(r1 + o_vel + 3 * lb);
+      rw0 = ld3(r0 + o_ang + 3 * lb); rw1 = ld3(r1 + o_ang + 3 * lb);
+      rd0 = r0[dc]; rd1 = r1[dc]; rdv0 = r0[D + dc]; rdv1 = r1[D + dc];
+      rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
-    if (lane < D) { rd0 = r0[lane]; rd1 = r1[lane]; rdv0 = r0[D + lane]; rdv1 = r1[D + lane]; }
-    if (lane < 2) { rc0 = r0[2 * D + lane]; rc1 = r1[2 * D + lane]; }
 
     // ---- consume (3): LDS staging + torques
 #pragma unroll
     for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
     if (c.hist_dim > PBHC_HREG * PBHC_G)
-      copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * c.hist_dim + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
-    // old history goes to its outputs NOW (stores are fire-and-forget; a reset later rewrites these positions with zeros)
-    if (c.hist_pack_bits) {
-#pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) hist_scatter(c, io, env, hpk[u], hreg[u]); }
-    }
+      copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
     if (d < D) {
@@ -444,6 +457,15 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
   }
   clipcnt = group_sum(clipcnt);
+  stage_skeleton_store(sk, skc, skreg);
+  if (map_words > 0) {
+#pragma unroll
+    for (int u = 0; u < PBHC_MAPREG; ++u) {
+      const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB);
+      if (i < map_words) mapl[i] = mreg[u];
+    }
+    for (int i = threadIdx.x + PBHC_MAPREG * (PBHC_G * PBHC_EPB); i < map_words; i += PBHC_G * PBHC_EPB) mapl[i] = map_img[i];
+  }
   LDS_BARRIER();
 
   STAMP(1);
@@ -721,6 +743,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
 #pragma unroll
   for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
   float rew_total = 0.0f;
+  pf_sum = __shfl(sumrow, pf_tcol, PBHC_G);
+  pf_termsum = __shfl(sumrow, c.termination_sum_col, PBHC_G);
   if (valid) {
     const float pen_scale = pf_pen_scale;
     float myrew = 0.0f;
@@ -796,7 +820,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       }
       myrew = raw * pf_tscale;
       if (pf_tpen) myrew = myrew * pen_scale;
-      io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol] = pf_sum + myrew;
+      io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol] = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
     }
     if (c.use_vec_reward) {
       if (lane < c.num_rew_cols) {
@@ -842,7 +866,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.
   if (MODE && c.future_num_steps > 0) {
     const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
-    float* fut = S + Lds::FUT;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
+    float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
     const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
     int row0 = 0, nf_c = tbl.single_num_frames;
     float len_c = tbl.single_len, dt_c = tbl.single_dt;
@@ -935,10 +959,6 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     }
     for (int i = lane; i < c.hist_dim; i += PBHC_G) {
       feat[hoff + i] *= 0.0f;
-      if (c.hist_pack_bits) {
-        int w[2] = {rt.hist_pack[(size_t)i * c.hist_pack_words], c.hist_pack_words > 1 ? rt.hist_pack[(size_t)i * c.hist_pack_words + 1] : 0};
-        hist_scatter(c, io, env, w, 0.0f);
-      }
     }
     float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
     for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
@@ -1013,13 +1033,56 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
   if (valid) {
     const float noise_cur = pf_noise_cur;
+    if (c.map_lds_words > 0) {
+      // compact maps from LDS.  Block of a group: [seg_scale 16][seg_noise 16][nn][noisy entries nn x (j | word << 16)][u16 word per element],
+      // word = 12-bit feature index | 4-bit (scale, noise) segment.  Pass 1 writes every element without noise, 8 per lane in flight;
+      // pass 2 revisits only the noisy elements (a few dozen per group), four per lane per Philox4x32 call.
+      for (int g = 0; g < c.num_groups; ++g) {
+        const int dim = c.groups[g].dim, clip = c.groups[g].clip;
+        const uint32_t* mg = mapl + c.groups[g].lds_off;
+        const float* segs = (const float*)mg;
+        const int nn = (int)mg[32];
+        const uint32_t* noisy = mg + 33;
+        const uint16_t* m16 = (const uint16_t*)(noisy + nn);
+        float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
+        for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
+          uint32_t w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int j = j0 + u * PBHC_G; w[u] = j < dim ? m16[j] : 0u; }
+          float x[8], sc[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { x[u] = feat[w[u] & 0xFFFu]; sc[u] = segs[w[u] >> 12]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * PBHC_G;
+            float v = x[u] * sc[u];
+            if (clip) v = clampf(v, -c.clip_observations, c.clip_observations);
+            if (j < dim) out[j] = v;
+          }
+        }
+        for (int k0 = 4 * lane; k0 < nn; k0 += 4 * PBHC_G) {
+          uint32_t r[4];
+          philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16 + g, (uint32_t)(k0 >> 2), r);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < nn) {
+              const uint32_t e = noisy[k0 + u];
+              const uint32_t w = e >> 16;
+              const int seg = w >> 12;
+              float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
+              if (clip) v = clampf(v, -c.clip_observations, c.clip_observations);
+              out[e & 0xFFFFu] = v;
+            }
+        }
+      }
+    } else
     for (int g = 0; g < c.num_groups; ++g) {
       const int dim = c.groups[g].dim, clip = c.groups[g].clip;
       const int* __restrict__ mdst = rt.groups[g].dst;
       const int* __restrict__ msrc = rt.groups[g].src;
       const float* __restrict__ mscale = rt.groups[g].scale;
       const float* __restrict__ mnoise = rt.groups[g].noise;
-      float* __restrict__ out = io.obs[g] + (size_t)env * c.groups[g].pitch;
+      float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
       for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
         int si[8], di[8]; float sc[8], ns[8];
 #pragma unroll
@@ -1401,6 +1464,7 @@ struct PbhcEnv {
   PbhcMotionTable tbl;
   double* d_glob;
   float* d_partials;
+  float* d_skc;
   int nblocks;
   int lds_stride;
   size_t lds_bytes;
@@ -1509,15 +1573,36 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
     for (int k = 0; k < cfg->num_key; ++k) ARG_CHECK(cfg->key[k] >= 0 && cfg->key[k] < Bx);
     for (int k = 0; k < cfg->future_num_steps; ++k) ARG_CHECK(cfg->future_steps[k] >= 0);
   }
-  e->lds_stride = Lds::feat(cfg->tracking_mode) + ((cfg->feat_dim + 3) & ~3);
-  e->lds_bytes = ((size_t)PBHC_EPB * e->lds_stride + SKC_WORDS + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+  e->lds_stride = Lds(Bx, cfg->tracking_mode).feat + ((cfg->feat_dim + 3) & ~3);
+  ARG_CHECK(cfg->map_lds_words >= 0);
+  if (cfg->map_lds_words > 0) {
+    int need = 0;
+    for (int g = 0; g < cfg->num_groups; ++g) {
+      ARG_CHECK(cfg->groups[g].dst == nullptr && cfg->groups[g].lds_off == need && cfg->groups[g].map_words >= 33 + ((cfg->groups[g].dim + 1) >> 1));
+      need += cfg->groups[g].map_words;
+    }
+    ARG_CHECK(need == cfg->map_lds_words && cfg->feat_dim <= 4096 && cfg->map_image != nullptr);
+  }
+  {
+    // the compact maps must not cost a resident workgroup per CU (160 KB LDS): otherwise the per-element maps stay in global memory
+    const size_t base = ((size_t)PBHC_EPB * e->lds_stride + SKC_WORDS + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+    const size_t with = base + (size_t)cfg->map_lds_words * sizeof(float);
+    if (cfg->map_lds_words > 0 && (160 * 1024) / with < (160 * 1024) / base) e->cfg.map_lds_words = 0;
+    e->lds_bytes = e->cfg.map_lds_words > 0 ? with : base;
+  }
   e->step_ctr = 0;
   e->profile = 0;
   e->prof_count = 0;
   if (e->lds_bytes > 160 * 1024) { delete e; snprintf(g_err, sizeof(g_err), "feature row too large for LDS"); return PBHC_EINVAL; }
   if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
-  HIP_CHECK(hipMemcpy(e->d_cfg, cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
+  if (hipMalloc(&e->d_skc, SKC_WORDS * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); (void)hipFree(e->d_partials); delete e; return PBHC_ENOMEM; }
+  {
+    float img[SKC_WORDS];
+    for (int i = 0; i < SKC_WORDS; ++i) img[i] = i < Bx * SKC_W ? skel_word(cfg->skel, i) : 0.0f;
+    HIP_CHECK(hipMemcpy(e->d_skc, img, sizeof(img), hipMemcpyHostToDevice));
+  }
+  HIP_CHECK(hipMemcpy(e->d_cfg, &e->cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
   if (e->lds_bytes > 64 * 1024)
     HIP_CHECK(hipFuncSetAttribute(cfg->tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   *out = e;
@@ -1530,6 +1615,7 @@ void pbhc_env_destroy(PbhcEnv* e) {
     for (int i = 0; i < PBHC_PROFILE_RING; ++i) { (void)hipEventDestroy(e->ev0[i]); (void)hipEventDestroy(e->ev1[i]); }
   (void)hipFree(e->d_cfg);
   (void)hipFree(e->d_partials);
+  (void)hipFree(e->d_skc);
   delete e;
 }
 
@@ -1569,14 +1655,15 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(io->motion_start_times && io->motion_len && io->end_time_ratio_buf && io->episode_sums && io->hist);
   ARG_CHECK(io->episode_length_buf && io->last_episode_length_buf && io->reset_buf && io->action_delay_idx && io->motion_ids && io->time_out_buf);
   ARG_CHECK(io->env_origins && io->dr_base_com && io->dr_link_mass && io->dr_friction && io->rew_buf);
-  for (int g = 0; g < e->cfg.num_groups; ++g) ARG_CHECK(io->obs[g] != nullptr);
+  for (int g = 0; g < e->cfg.num_groups; ++g) ARG_CHECK(io->obs[g] != nullptr && (io->obs_pitch[g] == 0 || io->obs_pitch[g] >= e->cfg.groups[g].pitch));
+  ARG_CHECK(io->hist_pitch == 0 || io->hist_pitch >= e->cfg.hist_dim);
   hipStream_t st = (hipStream_t)stream;
   const int slot = e->prof_count % PBHC_PROFILE_RING;
   if (e->profile) HIP_CHECK(hipEventRecord(e->ev0[slot], st));
   if (e->cfg.tracking_mode)
-    hipLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride);
+    hipLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride, e->d_skc, e->cfg.map_image);
   else
-    hipLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride);
+    hipLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride, e->d_skc, e->cfg.map_image);
   if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
   hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames);
   e->step_ctr++;

@@ -86,7 +86,9 @@ def determine_obs_dim(cfg):
     return groups, dims, aux
 
 
-EARLY_HIST_SCATTER = False
+import os as _os
+
+PACKED_MAPS = _os.environ.get("PBHC_PACKED_MAPS", "1") != "0"     # compact 16-bit observation maps staged in LDS (PbhcEnvConfig.map_image); 0: diagnosis only
 
 
 class EnvLayout:
@@ -413,16 +415,11 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
                 idx[j] = feat_off["ZERO"]
         return idx
 
-    # ---- output maps.  Old-history elements (scale 1, no noise) are scattered arithmetically by the kernel ("early"); the
-    # maps list the remaining elements as (dst, src, scale, noise).
+    # ---- output maps: every output element as (dst, src, scale, noise)
     group_names = list(ob.obs_dict.keys())
     G = len(group_names) + 1                                   # + history write-back
     if G > K["PBHC_MAX_GROUPS"]:
         raise _lib.PbhcError("too many observation groups")
-    # The arithmetic early scatter of old history is implemented and parity-green but measured SLOWER on MI355X round 1
-    # (68 us vs 55 us per step at 4096 envs: phase A grows by more than the obs phase shrinks), so it stays off.
-    early_ok = EARLY_HIST_SCATTER and c.hist_dim <= 384 and max(list(groups.values()) + [c.hist_dim]) < 65535
-    hk_struct = {hk: dict(start=hist_off[hk], dim=dims[hk], len=hist_len[hk], base=[0] * K["PBHC_MAX_GROUPS"], n=[0] * K["PBHC_MAX_GROUPS"]) for hk in hist_keys}
     maps = []           # (name, dst, src, scale, noise, clip, pitch)
     for gi, g in enumerate(group_names):
         keys = ob.obs_dict[g]
@@ -436,12 +433,8 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
                 a = ob.obs_auxiliary[k]
                 for hk in sorted(a.keys()):
                     n = int(a[hk]) * dims[hk]
-                    if early_ok and scale == 1.0 and noise == 0.0 and hk_struct[hk]["n"][gi] == 0:
-                        hk_struct[hk]["base"][gi] = pos
-                        hk_struct[hk]["n"][gi] = int(a[hk])
-                    else:
-                        base = feat_off["HISTORY"] + hist_off[hk]
-                        dst.extend(range(pos, pos + n)); src.extend(range(base, base + n)); sc.extend([scale] * n); ns.extend([noise] * n)
+                    base = feat_off["HISTORY"] + hist_off[hk]
+                    dst.extend(range(pos, pos + n)); src.extend(range(base, base + n)); sc.extend([scale] * n); ns.extend([noise] * n)
                     pos += n
             else:
                 idx = key_sources(k)
@@ -451,24 +444,30 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         maps.append((g, dst, src, sc, ns, 1, groups[g]))
     # history write-back: new[k][0] = parse(current k), new[k][t] = old[k][t-1]  (history_handler.py:40-44)
     dst, src, sc, ns = [], [], [], []
-    hi = G - 1
     for hk in hist_keys:
         cur = key_sources(hk)
         o0 = hist_off[hk]
         dst.extend(range(o0, o0 + len(cur))); src.extend(cur); sc.extend([float(ob.obs_scales[hk])] * len(cur)); ns.extend([float(ob.noise_scales[hk])] * len(cur))
         n_old = (hist_len[hk] - 1) * dims[hk]
-        if early_ok:
-            hk_struct[hk]["base"][hi] = o0 + dims[hk]
-            hk_struct[hk]["n"][hi] = hist_len[hk] - 1
-        else:
-            base = feat_off["HISTORY"] + o0
-            dst.extend(range(o0 + dims[hk], o0 + dims[hk] + n_old)); src.extend(range(base, base + n_old)); sc.extend([1.0] * n_old); ns.extend([0.0] * n_old)
+        base = feat_off["HISTORY"] + o0
+        dst.extend(range(o0 + dims[hk], o0 + dims[hk] + n_old)); src.extend(range(base, base + n_old)); sc.extend([1.0] * n_old); ns.extend([0.0] * n_old)
     if not src:
         dst, src, sc, ns = [0], [feat_off["ZERO"]], [1.0], [0.0]
     maps.append(("__history__", dst, src, sc, ns, 0, c.hist_dim))
     c.num_groups = len(maps)
     L.group_names = [m[0] for m in maps]
     L.map_tensors = []
+    # compact form (16 bits per element, staged in LDS by the kernel): possible when every group writes its row in order and has
+    # at most PBHC_MAX_SEGS distinct (scale, noise) pairs
+    seg_tables = []
+    compact = PACKED_MAPS and off <= 4096
+    for (g, dst, src, sc, ns, clip, pitch) in maps:
+        pairs = sorted(set(zip(sc, ns)))
+        seg_tables.append(pairs)
+        if dst != list(range(len(dst))) or len(pairs) > K["PBHC_MAX_SEGS"]:
+            compact = False
+    lds_off = 0
+    image = []
     for i, (g, dst, src, sc, ns, clip, pitch) in enumerate(maps):
         if not src:                                            # a group made only of old history
             dst, src, sc, ns = [0], [feat_off["ZERO"]], [1.0], [0.0]
@@ -486,22 +485,27 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         c.groups[i].src = ts.data_ptr()
         c.groups[i].scale = tsc.data_ptr()
         c.groups[i].noise = tn.data_ptr()
-    c.hist_pack_bits = 0
-    if early_ok:
-        bits = 10 if max(list(groups.values()) + [c.hist_dim]) < 1023 else 16
-        per = 32 // bits
-        words = (G + per - 1) // per
-        pack = np.zeros((c.hist_dim, words), dtype=np.int64)
-        for hk in hist_keys:
-            e = hk_struct[hk]
-            for gi in range(G):
-                for t in range(e["n"][gi]):
-                    for d in range(e["dim"]):
-                        i = e["start"] + t * e["dim"] + d
-                        pack[i, gi // per] |= (e["base"][gi] + t * e["dim"] + d + 1) << (bits * (gi % per))
-        L.hist_pack = torch.from_numpy((pack & 0xFFFFFFFF).astype(np.uint32).view(np.int32).copy()).to(device)
-        c.hist_pack_bits, c.hist_pack_words = bits, words
-        c.hist_pack = L.hist_pack.data_ptr()
+        if compact:
+            pairs = seg_tables[i]
+            seg_of = {p: k for k, p in enumerate(pairs)}
+            pk = np.array([s_ | (seg_of[(a_, b_)] << 12) for s_, a_, b_ in zip(src, sc, ns)] + [0] * (len(src) % 2), dtype=np.uint16)
+            tabs = np.zeros(32, dtype=np.float32)
+            for k, (a_, b_) in enumerate(pairs):
+                tabs[k], tabs[16 + k] = a_, b_
+            noisy = np.array([j | (int(pk[j]) << 16) for j in range(len(src)) if ns[j] != 0.0], dtype=np.uint32)
+            if len(src) >= 65536:
+                raise _lib.PbhcError("observation group too wide for the compact maps")
+            blk = np.concatenate([tabs.view(np.uint32), np.array([len(noisy)], dtype=np.uint32), noisy, pk.view(np.uint32)])
+            image.append(blk)
+            c.groups[i].dst = None                                  # identity
+            c.groups[i].lds_off = lds_off
+            c.groups[i].map_words = len(blk)
+            lds_off += len(blk)
+    c.map_lds_words = lds_off if compact else 0
+    if compact:
+        L.map_image = torch.from_numpy(np.concatenate(image).view(np.int32).copy()).to(device)
+        assert L.map_image.numel() == lds_off
+        c.map_image = L.map_image.data_ptr()
     c.clip_observations = float(ec.normalization.clip_observations)
     c.has_contact_mask = int(bool(motion_lib.has_contact_mask))
     if "teleop_contact_mask" in L.reward_names and not motion_lib.has_contact_mask:

@@ -143,7 +143,7 @@ class LeggedRobotMotionTracking:
         self._episode_sums = f(N, len(L.sum_names))
         self.episode_sums = {name: self._episode_sums[:, i] for i, name in enumerate(L.sum_names)}
         self._episode_rew_out = f(N, len(L.sum_names))
-        self._hist = f(N, L.hist_dim)
+        self._hist = _padded_rows(N, L.hist_dim, dev)            # rows start on 128-B lines
         self._episode_length_buf = torch.zeros(N, dtype=torch.long, device=dev)
         self.last_episode_length_buf = torch.zeros(N, dtype=torch.long, device=dev)
         self.reset_buf = torch.ones(N, dtype=torch.long, device=dev)
@@ -158,7 +158,7 @@ class LeggedRobotMotionTracking:
 
     def _init_obs_buffers(self):
         L = self.layout
-        self._own_obs = {g: torch.zeros(self.num_envs, L.group_dims[g], dtype=torch.float32, device=self.device) for g in L.group_names[:-1]}
+        self._own_obs = {g: _padded_rows(self.num_envs, L.group_dims[g], self.device) for g in L.group_names[:-1]}
         self.obs_buf_dict = dict(self._own_obs)
 
     def rebuild_observations(self):
@@ -221,7 +221,9 @@ class LeggedRobotMotionTracking:
         L = self.layout
         for i, g in enumerate(L.group_names[:-1]):
             io.obs[i] = p(self.obs_buf_dict[g])
+            io.obs_pitch[i] = self.obs_buf_dict[g].stride(0)
         io.obs[len(L.group_names) - 1] = p(self._hist)
+        io.obs_pitch[len(L.group_names) - 1] = io.hist_pitch = self._hist.stride(0)
         io.rew_buf = p(self.rew_buf)
         io.ref_body_pos_extend, io.ref_body_rot_extend = p(self.ref_body_pos_extend), p(self.ref_body_rot_extend)
         io.episode_rew_out = p(self._episode_rew_out)
@@ -234,9 +236,10 @@ class LeggedRobotMotionTracking:
         the next step) instead of the env-owned ones; `None` restores the env-owned buffers."""
         L = self.layout
         for i, g in enumerate(L.group_names[:-1]):
-            t = self._own_obs[g] if tensors is None else _lib.require_gpu_tensor(tensors[g], g, torch.float32, (self.num_envs, L.group_dims[g]))
+            t = self._own_obs[g] if tensors is None else _lib.require_gpu_rows(tensors[g], g, torch.float32, (self.num_envs, L.group_dims[g]))
             self.obs_buf_dict[g] = t
             self._io.obs[i] = t.data_ptr()
+            self._io.obs_pitch[i] = t.stride(0)
 
     # ---- test / replay hooks: inject the random draws instead of the in-kernel Philox ---------
     def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None):
@@ -339,6 +342,7 @@ class LeggedRobotMotionTracking:
             io.frame_dof_vel, io.frame_contact = r["dof_vel"].data_ptr(), r["contact"].data_ptr()
             io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
             self._replay_version = s.replay_version
+        io.frame_index = s.take_host_frame()
         _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
         self.common_step_counter += 1
         self.extras["time_outs"] = self.time_out_buf
@@ -367,6 +371,11 @@ class LeggedRobotMotionTracking:
             out["error_ema_" + k] = g[K["PBHC_G_EMA"] + i]
         self.log_dict.update({k: torch.tensor(float(v)) for k, v in out.items()})
         return out
+
+
+def _padded_rows(n, dim, device, dtype=torch.float32):
+    """[n, dim] view of an [n, ceil32(dim)] buffer: every row starts on a 128-byte line."""
+    return torch.zeros(n, (dim + 31) // 32 * 32, dtype=dtype, device=device)[:, :dim]
 
 
 class _TopView:

@@ -38,6 +38,7 @@ class ReplaySimStub:
         self.replay = None
         self.replay_version = 0
         self.frame_cursor = torch.zeros(1, dtype=torch.int32, device=self.device)     # device-side cursor, advanced by the step kernel
+        self._host_frame = 0                                                           # its host mirror (-1: unknown, the kernel reads the device cursor)
 
     # ---- bring-up ------------------------------------------------------------------------
     def set_headless(self, headless):
@@ -134,6 +135,7 @@ class ReplaySimStub:
         self.replay_len = T
         self._frame = start_frame
         self.frame_cursor.fill_(start_frame % T)
+        self._host_frame = start_frame % T
         self.replay_version += 1
 
     def ensure_replay(self):
@@ -143,13 +145,22 @@ class ReplaySimStub:
                                dof_vel=self.dof_vel.clone()[None].contiguous(), contact=self.contact_forces.clone()[None])
             self.replay_len = 1
             self.frame_cursor.zero_()
+            self._host_frame = 0
             self.replay_version += 1
+
+    def take_host_frame(self):
+        """Frame index of the fused step about to be launched, by value (the step kernel advances the device cursor itself)."""
+        k = self._host_frame
+        if k >= 0:
+            self._host_frame = (k + 1) % self.replay_len
+        return k
 
     def next_frame_index(self):
         """Host-side stepping (reference-style `simulate` loop only): frame index, cursor advanced on both sides."""
         self.ensure_replay()
         k = int(self.frame_cursor.item())
         self.frame_cursor.copy_((self.frame_cursor + 1) % self.replay_len)
+        self._host_frame = (k + 1) % self.replay_len
         return k
 
     def refresh_sim_tensors(self):

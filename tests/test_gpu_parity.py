@@ -368,3 +368,40 @@ def test_policy_sample_and_rollout_post():
     close(cur_l, torch.where(d, torch.zeros_like(nl), nl), 0, "cur_episode_length")
     ref = torch.stack([nr[d].double().sum(), nl[d].double().sum(), d.double().sum()])
     assert torch.allclose(stats, ref, rtol=1e-6)
+
+
+def test_observation_noise_is_bounded_uniform_and_only_where_configured():
+    """Noise-on vs noise-off step from the same state (reference: helpers.parse_observation, (x + (2U-1) * noise) * scale, helpers.py:128-152):
+    elements of noise-free keys are identical, noisy elements differ by at most noise*scale, and over 4096 envs the differences have
+    the mean ~0 and the variance (noise*scale)^2 / 3 of a uniform on [-1, 1] — separately in every group that carries the key."""
+    N = 4096
+    outs = []
+    for noise_off in (True, False):
+        torch.manual_seed(11)
+        cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", N, noise_off=noise_off)
+        torch.manual_seed(12)
+        env.reset_all()
+        obs, _, _, _ = env.step({"actions": torch.zeros(N, env.num_dof, device=DEV)})
+        torch.cuda.synchronize()
+        outs.append(({k: v.clone() for k, v in obs.items()}, {k: v.clone() for k, v in env.history.items()}, cfg, env.layout))
+    (clean, hclean, _, _), (noisy, hnoisy, cfg, L) = outs
+    ob = cfg.obs
+    for g, keys in ob.obs_dict.items():
+        pos = 0
+        for key in sorted(keys):
+            d = L.obs_dims[key] if key in L.obs_dims else sum(L.obs_dims[k] * n for k, n in ob.obs_auxiliary[key].items())
+            diff = (noisy[g][:, pos:pos + d] - clean[g][:, pos:pos + d]).cpu()
+            amp = float(ob.noise_scales[key]) * float(ob.obs_scales[key])
+            if amp == 0.0 or key in ob.obs_auxiliary:
+                if key not in ob.obs_auxiliary:
+                    assert float(diff.abs().max()) == 0.0, (g, key)
+            else:
+                assert float(diff.abs().max()) <= amp * (1 + 1e-5) + 1e-6, (g, key, float(diff.abs().max()), amp)
+                assert abs(float(diff.mean())) < 0.05 * amp and abs(float(diff.var()) / (amp * amp / 3.0) - 1.0) < 0.1, (g, key, float(diff.mean()), float(diff.var()), amp)
+            pos += d
+    k = "dof_pos"                                                # the newest history entry carries its own independent draw
+    dh = (hnoisy[k][:, 0] - hclean[k][:, 0]).cpu()
+    amp = float(ob.noise_scales[k]) * float(ob.obs_scales[k])
+    assert 0 < float(dh.abs().max()) <= amp * (1 + 1e-5)
+    da = (noisy["actor_obs"] - clean["actor_obs"]).cpu()
+    assert float((dh[:, 0] - da[:, 0]).abs().max()) > 0        # different draws than the actor group's
