@@ -168,8 +168,8 @@ __device__ __forceinline__ void stage_skeleton_load(const float* __restrict__ im
 #pragma unroll
   for (int u = 0; u < SKC_REGS; ++u) { const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB); v[u] = i < n ? img[i] : 0.0f; }
 }
-__device__ __forceinline__ void stage_skeleton_store(const PbhcSkeleton& sk, float* skc, const float* v) {
-  const int n = sk.num_bodies_ext * SKC_W;
+__device__ __forceinline__ void stage_skeleton_store(int num_bodies_ext, float* skc, const float* v) {
+  const int n = num_bodies_ext * SKC_W;
 #pragma unroll
   for (int u = 0; u < SKC_REGS; ++u) { const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB); if (i < n) skc[i] = v[u]; }
 }
@@ -270,13 +270,17 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
                                                               int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
   // whose scalars fold into the instruction stream; pointers, seed, env count and reference yaw always come from `rt`.
-  const PbhcEnvConfig& rt = *cfgp;
+  // The config is read through the CONSTANT address space: the kernel never writes it, and saying so lets the compiler keep its
+  // scalars in SGPRs across the kernel's global stores (through a plain global pointer every `c.x` after a store is reloaded and
+  // waited for with s_waitcnt lgkmcnt(0), which also drains the LDS queue: ~8 reloads per batch of 8 stores in the observation phase).
+  typedef const PbhcEnvConfig __attribute__((address_space(4))) ConstCfg;
+  ConstCfg& rt = *(ConstCfg*)cfgp;
 #ifdef PBHC_STATIC_CFG
   const PbhcEnvConfig& c = kStaticCfg;
 #else
-  const PbhcEnvConfig& c = rt;
+  ConstCfg& c = rt;
 #endif
-  const PbhcSkeleton& sk = c.skel;
+  const auto& sk = c.skel;
   const int N = rt.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
   const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G;
   const int env = blockIdx.x * PBHC_EPB + le;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
   }
   clipcnt = group_sum(clipcnt);
-  stage_skeleton_store(sk, skc, skreg);
+  stage_skeleton_store(Bx, skc, skreg);
   if (map_words > 0) {
 #pragma unroll
     for (int u = 0; u < PBHC_MAPREG; ++u) {
@@ -1033,11 +1037,13 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
   if (valid) {
     const float noise_cur = pf_noise_cur;
-    if (c.map_lds_words > 0) {
+    const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals: after a global store the
+    const int ngroups = c.num_groups;              // compiler otherwise reloads `c.x` (possible aliasing) and waits on lgkmcnt(0)
+    if (map_words > 0) {
       // compact maps from LDS.  Block of a group: [seg_scale 16][seg_noise 16][nn][noisy entries nn x (j | word << 16)][u16 word per element],
       // word = 12-bit feature index | 4-bit (scale, noise) segment.  Pass 1 writes every element without noise, 8 per lane in flight;
       // pass 2 revisits only the noisy elements (a few dozen per group), four per lane per Philox4x32 call.
-      for (int g = 0; g < c.num_groups; ++g) {
+      for (int g = 0; g < ngroups; ++g) {
         const int dim = c.groups[g].dim, clip = c.groups[g].clip;
         const uint32_t* mg = mapl + c.groups[g].lds_off;
         const float* segs = (const float*)mg;
@@ -1056,7 +1062,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
           for (int u = 0; u < 8; ++u) {
             const int j = j0 + u * PBHC_G;
             float v = x[u] * sc[u];
-            if (clip) v = clampf(v, -c.clip_observations, c.clip_observations);
+            if (clip) v = clampf(v, -clipobs, clipobs);
             if (j < dim) out[j] = v;
           }
         }
@@ -1070,7 +1076,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
               const uint32_t w = e >> 16;
               const int seg = w >> 12;
               float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
-              if (clip) v = clampf(v, -c.clip_observations, c.clip_observations);
+              if (clip) v = clampf(v, -clipobs, clipobs);
               out[e & 0xFFFFu] = v;
             }
         }
