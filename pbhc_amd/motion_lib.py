@@ -94,7 +94,11 @@ class MotionLib:
         self._motion_dt = torch.tensor(dts, dtype=torch.float32, device=self.device)
         self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=self.device)
         self._num_unique_motions = len(clips)
+        # sampling hooks of the reference (setup_constants, motion_lib_base.py:109-118): per-unique-clip tensors a curriculum may write
         self._sampling_prob = torch.ones(len(clips), device=self.device) / len(clips)
+        self._termination_history = torch.zeros(len(clips), device=self.device)
+        self._success_rate = torch.zeros(len(clips), device=self.device)
+        self._sampling_history = torch.zeros(len(clips), device=self.device)
         self.slot_clip = torch.zeros(num_envs, dtype=torch.long, device=self.device)
         self.table = _lib.PbhcMotionTable()
         self.table.frames = self.frames.data_ptr()
@@ -120,10 +124,15 @@ class MotionLib:
         return cls(skeleton, clips, num_envs, device)
 
     # ---- slot -> clip assignment (load_motions, motion_lib_base.py:293-305) -----------------
-    def load_motions(self, random_sample=True, start_idx=0):
+    def load_motions(self, random_sample=True, start_idx=0, max_len=-1, target_heading=None, sampling_prob=None):
+        """Slot -> clip assignment only: the per-clip FK tables were built once at construction (the reference re-runs FK for every
+        slot here).  `max_len` random crops and `target_heading` re-basing would need per-slot tables and are not supported."""
+        if max_len != -1 or target_heading is not None:
+            raise NotImplementedError("load_motions(max_len / target_heading)")
         # in place: the step kernel holds the pointer of this tensor
         if random_sample:
-            self.slot_clip.copy_(torch.multinomial(self._sampling_prob, num_samples=self.num_envs, replacement=True))
+            prob = self._sampling_prob if sampling_prob is None else sampling_prob
+            self.slot_clip.copy_(torch.multinomial(prob, num_samples=self.num_envs, replacement=True))
         else:
             self.slot_clip.copy_(torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions))
         self._curr_motion_ids = self.slot_clip
