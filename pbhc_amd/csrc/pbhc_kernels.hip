@@ -1180,8 +1180,17 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
   const int k = threadIdx.x & 63, chunk = threadIdx.x >> 6;
   // column sums of the workgroup partials in a FIXED order (chunk-strided, then chunk order): deterministic
   double s = 0.0;
-  if (k < PBHC_NP)
-    for (int b = chunk; b < nblocks; b += PBHC_FIN_CHUNKS) s += (double)partials[(size_t)b * PBHC_NP + k];
+  if (k < PBHC_NP) {
+    int b = chunk;
+    for (; b + 7 * PBHC_FIN_CHUNKS < nblocks; b += 8 * PBHC_FIN_CHUNKS) {       // 8 independent loads in flight, summed in the same fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * PBHC_FIN_CHUNKS) * PBHC_NP + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nblocks; b += PBHC_FIN_CHUNKS) s += (double)partials[(size_t)b * PBHC_NP + k];
+  }
   acc[chunk][k] = s;
   __syncthreads();
   if (threadIdx.x < PBHC_NP) {
