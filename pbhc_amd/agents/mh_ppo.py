@@ -48,6 +48,44 @@ def _make_writer(log_dir):
         return _NullWriter()
 
 
+def policy_forward_graphs(self, eager, key=0):
+    """The rollout is launch-bound on the host (≈18 launches per control step): the policy forward of step t — 14 of them, reading the
+    fixed rollout slab t and the in-place-updated flat weights — is captured once as a hipGraph per step index and replayed with one
+    launch.  The first rollout runs eagerly (GEMM selection happens there); PBHC_FWD_GRAPHS=0 keeps everything eager.
+    `key`: one set of graphs per forward variant (ppo_mimic: history / privileged latent)."""
+    if os.environ.get("PBHC_FWD_GRAPHS", "1") == "0":
+        return eager
+    seen = self.__dict__.setdefault("_fwd_seen", set())
+    if key not in seen:                        # first rollout of this variant: eager (online GEMM selection must not run inside a capture)
+        seen.add(key)
+        return eager
+    cache = self.__dict__.setdefault("_fwd_graph_cache", {})
+    if key not in cache:
+        T = self.num_steps_per_env
+        graphs, outs = [], []
+        pool = None
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t in range(T):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=side):
+                    out = eager(t)
+                pool = g.pool() if pool is None else pool
+                graphs.append(g); outs.append(out)
+        torch.cuda.current_stream().wait_stream(side)
+        cache[key] = (graphs, outs)
+    graphs, outs = cache[key]
+
+    def replay(t):
+        graphs[t].replay()
+        return outs[t]
+
+    return replay
+
+
+
 class _FlatAdamView:
     """torch.optim.Adam-format state_dict()/load_state_dict() over one network's slice of the flat Adam buffers, so
     checkpoints keep the reference's `*_optimizer_state_dict` entries (mh_ppo.py:195-204)."""
@@ -220,6 +258,7 @@ class MHPPO:
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
         self._last_obs = {k: torch.zeros(N, (d + 31) // 32 * 32, device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
         self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
+        self._branch_stream = torch.cuda.Stream(device=self.device)
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd MHPPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
         mb = (T * N) // self.num_mini_batches
@@ -311,9 +350,21 @@ class MHPPO:
         with torch.inference_mode():
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
-            for t in range(T):
+            def fwd_eager(t):
+                # actor and critic are independent chains of small (4096-row) GEMMs: two branches (parallel nodes once captured)
+                cur = torch.cuda.current_stream()
+                br = self._branch_stream
+                br.wait_stream(cur)
+                with torch.cuda.stream(br):
+                    value = self.critic.critic_module(getattr(st, "critic_obs")[t])
                 mu = self.actor.actor_module(getattr(st, "actor_obs")[t])
-                value = self.critic.critic_module(getattr(st, "critic_obs")[t])
+                cur.wait_stream(br)
+                value.record_stream(cur)
+                return mu, value
+
+            fwd = policy_forward_graphs(self, fwd_eager)
+            for t in range(T):
+                mu, value = fwd(t)
                 _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
                                                   st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")

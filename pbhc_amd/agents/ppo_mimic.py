@@ -28,7 +28,7 @@ import torch.distributed as dist
 from .. import _lib
 from .. import dist as pdist
 from .agent_modules import Actor, ActorCritic
-from .mh_ppo import _make_writer
+from .mh_ppo import _make_writer, policy_forward_graphs
 from .modules import RolloutStorage
 
 
@@ -422,9 +422,10 @@ class PPO:
             sigma = self.alg.sigma().contiguous()
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
+            mode = bool(self.hist_encoding)                    # the captured forward depends on the latent source
+            fwd = policy_forward_graphs(self, lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2], key=mode)
             for t in range(T):
-                b = {k: getattr(st, k)[t] for k in keys}
-                mu, value, _ = self._forward(b, self.hist_encoding)
+                mu, value = fwd(t)
                 _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
                                                   st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
