@@ -405,3 +405,60 @@ def test_observation_noise_is_bounded_uniform_and_only_where_configured():
     assert 0 < float(dh.abs().max()) <= amp * (1 + 1e-5)
     da = (noisy["actor_obs"] - clean["actor_obs"]).cpu()
     assert float((dh[:, 0] - da[:, 0]).abs().max()) > 0        # different draws than the actor group's
+
+
+def test_act_bwd_bias_matches_torch():
+    """pbhc_act_bwd_bias: dz = dy * act'(saved) and grad_bias = colsum(dz) against torch autograd for ELU / SiLU / ReLU / none, at the
+    shapes the update uses (24576 rows; 768-, 128- and 23-wide layers)."""
+    import torch.nn.functional as F
+
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for B, n in ((24576, 768), (24576, 128), (24576, 23), (100, 300)):
+        scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * n, device=DEV)
+        for act, fn in ((1, F.elu), (2, F.silu), (3, F.relu), (0, None)):
+            z = torch.randn(B, n, device=DEV, generator=g, requires_grad=True)
+            dy = torch.randn(B, n, device=DEV, generator=g)
+            if fn is None:
+                ref_dz, saved = dy, None
+            else:
+                y = fn(z)
+                (ref_dz,) = torch.autograd.grad(y, z, dy)
+                saved = z.detach() if act == 2 else y.detach()
+            dz = dy.clone()
+            gb = torch.zeros(n, device=DEV)
+            _lib.check(lib.pbhc_act_bwd_bias(dz.data_ptr(), None if saved is None else saved.data_ptr(), B, n, act, dz.data_ptr(), gb.data_ptr(),
+                                             scratch.data_ptr(), _lib.current_stream()))
+            torch.cuda.synchronize()
+            close(dz, ref_dz, 1e-6, f"dz act={act} {B}x{n}", rtol=1e-5)
+            close(gb, ref_dz.double().sum(0).float(), 2e-3 if B > 1000 else 1e-4, f"grad_bias act={act} {B}x{n}", rtol=1e-5)
+
+
+def test_adam_clip_matches_torch_adam_and_adamw():
+    """pbhc_adam_clip over a flat segment == clip_grad_norm_ + torch.optim.Adam / AdamW (decoupled weight decay) for 5 steps."""
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    n = 300_000
+    for wd, opt_cls in ((0.0, torch.optim.Adam), (0.01, torch.optim.AdamW)):
+        g = torch.Generator(device=DEV).manual_seed(1)
+        p0 = torch.randn(n, device=DEV, generator=g)
+        ref = torch.nn.Parameter(p0.clone())
+        opt = opt_cls([ref], lr=1e-3, **({"weight_decay": wd} if wd else {}))
+        p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        lr, step = torch.tensor([1e-3], device=DEV), torch.zeros(1, device=DEV)
+        scratch, norm = torch.zeros(512, dtype=torch.float64, device=DEV), torch.zeros(1, device=DEV)
+        for it in range(5):
+            grad = torch.randn(n, device=DEV, generator=g) * (0.01 if it % 2 else 1.0)        # with and without clipping
+            ref.grad = grad.clone()
+            tn = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+            opt.step()
+            gbuf = grad.clone()
+            _lib.check(lib.pbhc_adam_clip(p.data_ptr(), gbuf.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr.data_ptr(), step.data_ptr(), 1.0, 0.9, 0.999, 1e-8,
+                                          wd, scratch.data_ptr(), norm.data_ptr(), _lib.current_stream()))
+            torch.cuda.synchronize()
+            assert abs(float(norm) - float(tn)) < 1e-4 * float(tn)
+            close(p, ref.detach(), 2e-6, f"{opt_cls.__name__} step {it}", rtol=2e-6)
+        assert float(step) == 5.0
