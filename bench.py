@@ -197,10 +197,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # rehearsal hooks (one-GPU box): PBHC_BENCH_DEVICE pins every rank to one device, PBHC_BENCH_BACKEND=gloo replaces RCCL
+    dev_index = int(os.environ.get("PBHC_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("PBHC_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        dist.init_process_group(backend=backend, **({"device_id": torch.device(device)} if backend == "nccl" else {}))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     N, K, W = a.envs, a.steps, a.warmup
     cfg, env, MHPPO = build(N, device, seed=1234 + rank, workload=a.workload, num_clips=a.clips)

@@ -441,12 +441,19 @@ class MHPPO:
                                      float(self.entropy_coef), int(self.use_clipped_value_loss), float(self.desired_kl or 0.0), on_device_lr,
                                      self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._gflat[so:so + sn].data_ptr(), self._loss_scalars.data_ptr(),
                                      self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
-        torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+        na, nc = self._n_actor, self._n_critic
         if self.world_size > 1:
+            # the actor's gradient segment is all-reduced while the critic's backward runs; the tiny KL exchange rides in between
+            torch.autograd.backward([mu], [self._grad_mu])
+            h_a = dist.all_reduce(self._gflat[:na], async_op=True)
+            torch.autograd.backward([value], [self._grad_value])
+            h_c = dist.all_reduce(self._gflat[na:na + nc], async_op=True)
             if adapt:
                 pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
-            self._allreduce_grads()
-        na, nc = self._n_actor, self._n_critic
+            h_a.wait(); h_c.wait()
+            self._gflat.div_(self.world_size)
+        else:
+            torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
         for k, (o, n) in enumerate(((0, na), (na, nc))):
             _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
                                           self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
