@@ -239,8 +239,8 @@ class MHPPO:
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
         self._need_next = bool(self.cfg_l2c2 is not None and self.cfg_l2c2.enable)
         if self._need_next:                      # the L2C2 terms run each network twice per graph: plain autograd accumulation
-            self.actor.actor_module._fused = None
-            self.critic.critic_module._fused = None
+            self.actor.actor_module._fused = False
+            self.critic.critic_module._fused = False
         for k, d in self.algo_obs_dim_dict.items():
             st.register_key(k, shape=(d,), dtype=torch.float, pad_rows=True)
             if self._need_next:

@@ -48,11 +48,13 @@ class BaseModule(nn.Module):
         self.module = nn.Sequential(*layers)
         from . import fused_mlp
 
-        self._fused = fused_mlp if fused_mlp.supported(self.module) else None
+        self._fused = bool(fused_mlp.supported(self.module))       # a flag, not the module object: the reference's exporters deepcopy the actor
 
     def forward(self, x):
-        if self._fused is not None and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (x.requires_grad or self.module[0].weight.requires_grad):
-            return self._fused.forward(self.module, x)           # training: fused activation-backward / bias-gradient path
+        if self._fused and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (x.requires_grad or self.module[0].weight.requires_grad):
+            from . import fused_mlp
+
+            return fused_mlp.forward(self.module, x)             # training: fused activation-backward / bias-gradient path
         return self.module(x)
 
 

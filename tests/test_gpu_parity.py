@@ -314,6 +314,17 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert d["critic_model_state_dict"]["critic_module.module.6.weight"].shape[0] == env.num_rew_fn
     assert isinstance(d["actor_optimizer_state_dict"]["param_groups"][0]["lr"], float)
     assert algo.load(p) == {"x": 1}
+    # what the reference's exporters do with `inference_model` (utils/inference_helpers.py:13-52): deepcopy the actor to the CPU, call
+    # act_inference on an example observation (torch.onnx.export itself needs the `onnx` package, absent here) — and TorchScript tracing
+    import copy
+
+    actor_cpu = copy.deepcopy(algo.inference_model["actor"]).to("cpu")
+    ex = algo.get_example_obs()["actor_obs"][:4].cpu()
+    with torch.no_grad():
+        ref_out = algo.inference_model["actor"].act_inference(ex.to(DEV)).cpu()
+        assert torch.allclose(actor_cpu.act_inference(ex), ref_out, atol=1e-5)
+        traced = torch.jit.trace(actor_cpu.actor_module, ex)
+        assert torch.allclose(traced(ex), ref_out, atol=1e-5)
 
 
 def test_learn_runs_two_iterations():
