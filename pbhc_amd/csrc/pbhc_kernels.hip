@@ -1051,6 +1051,32 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         const uint32_t* noisy = mg + 33;
         const uint16_t* m16 = (const uint16_t*)(noisy + nn);
         float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
+        const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
+        if (((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) == 0)) {
+          // rows start 8-byte aligned: a lane takes PAIRS of elements — one 32-bit LDS word holds both map entries, one 8-byte store both values
+          const uint32_t* m32 = (const uint32_t*)m16;
+          const int npair = (dim + 1) >> 1;
+          for (int p0 = lane; p0 < npair; p0 += 8 * PBHC_G) {
+            uint32_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int p = p0 + u * PBHC_G; w[u] = p < npair ? m32[p] : 0u; }
+            float xa[8], xb[8], sa[8], sb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const uint32_t lo = w[u] & 0xFFFFu, hi = w[u] >> 16;
+              xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
+              xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int j = 2 * (p0 + u * PBHC_G);
+              float va = xa[u] * sa[u], vb = xb[u] * sb[u];
+              if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
+              if (j + 1 < dim) *reinterpret_cast<float2*>(out + j) = make_float2(va, vb);
+              else if (j < dim) out[j] = va;
+            }
+          }
+        } else
         for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
           uint32_t w[8];
 #pragma unroll
@@ -1066,6 +1092,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
             if (j < dim) out[j] = v;
           }
         }
+        STAMP(12 + 2 * g);
         for (int k0 = 4 * lane; k0 < nn; k0 += 4 * PBHC_G) {
           uint32_t r[4];
           philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16 + g, (uint32_t)(k0 >> 2), r);
@@ -1080,6 +1107,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
               out[e & 0xFFFFu] = v;
             }
         }
+        STAMP(13 + 2 * g);
       }
     } else
     for (int g = 0; g < c.num_groups; ++g) {

@@ -34,3 +34,8 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
         d = st[i + 1] - st[i]
         print(f"  {n:16s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
     print(f"  total {tot} cycles")
+    if st[12]:
+        prev = st[8]
+        for g in range(3):
+            print(f"  obs group {g}: pass1 {st[12 + 2 * g] - prev} cyc, noisy pass {st[13 + 2 * g] - st[12 + 2 * g]} cyc")
+            prev = st[13 + 2 * g]
