@@ -214,6 +214,7 @@ typedef struct PbhcEnvConfig {
   float term_scale[PBHC_MAX_TERMS];          /* reward_scales[name] * dt */
   int32_t term_penalty[PBHC_MAX_TERMS];      /* in reward_penalty_reward_names and curriculum on */
   int32_t term_sum_col[PBHC_MAX_TERMS];      /* column in episode_sums */
+  int32_t term_src[PBHC_MAX_TERMS];          /* filled by pbhc_env_create (kernel-internal slot of the term's raw value, or -1) */
   int32_t has_termination, termination_sum_col, only_positive_rewards, num_sum_cols;
   float termination_scale;
   float body_pos_lower_weight, body_pos_upper_weight, desired_feet_air_time, max_contact_force;

@@ -65,10 +65,15 @@ static_assert(P_NUM <= PBHC_NP, "partials");
 
 // reduction slots per env (LDS)
 enum {
-  R_UP = 0, R_LO, R_VR, R_FEET, R_ROT, R_VEL, R_ANG, R_MAXNORM, R_UPN, R_LON, R_VRN,
-  R_MAXJP, R_JP2, R_JV2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
-  // general tracking: key-body / anchor / root errors, local-frame log norms, body_z flag
-  R_KEY, R_KEYN, R_LKEY, R_LKEYN, R_LKROT, R_KVEL, R_KANG, R_APOS, R_AROT, R_RVEL, R_RPOSE, R_LUPN, R_LLON, R_LVRN, R_BODYZ,
+  R_ERR0 = 0,                              // [PBHC_NUM_SIGMA] the tracking errors, in sigma order (what exp(-err/sigma) and the sigma EMA read)
+  R_MAXJP = R_ERR0 + PBHC_S_MAX_JOINT_POS, R_UP = R_ERR0 + PBHC_S_UPPER_BODY_POS, R_LO = R_ERR0 + PBHC_S_LOWER_BODY_POS,
+  R_VR = R_ERR0 + PBHC_S_VR_3POINT_POS, R_FEET = R_ERR0 + PBHC_S_FEET_POS, R_ROT = R_ERR0 + PBHC_S_BODY_ROT, R_VEL = R_ERR0 + PBHC_S_BODY_VEL,
+  R_ANG = R_ERR0 + PBHC_S_BODY_ANG_VEL, R_JPM = R_ERR0 + PBHC_S_JOINT_POS, R_JVM = R_ERR0 + PBHC_S_JOINT_VEL,
+  R_KEY = R_ERR0 + PBHC_S_KEY_BODY_POS, R_APOS = R_ERR0 + PBHC_S_ANCHOR_BODY_POS, R_AROT = R_ERR0 + PBHC_S_ANCHOR_BODY_ROT,
+  R_LKEY = R_ERR0 + PBHC_S_LOCAL_KEY_BODY_POS, R_LKROT = R_ERR0 + PBHC_S_LOCAL_KEY_BODY_ROT, R_KVEL = R_ERR0 + PBHC_S_KEY_BODY_VEL,
+  R_KANG = R_ERR0 + PBHC_S_KEY_BODY_ANG_VEL, R_RVEL = R_ERR0 + PBHC_S_ROOT_VEL, R_RPOSE = R_ERR0 + PBHC_S_ROOT_POSE,
+  R_MAXNORM = R_ERR0 + PBHC_NUM_SIGMA, R_UPN, R_LON, R_VRN, R_JP2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
+  R_KEYN, R_LKEYN, R_LUPN, R_LLON, R_LVRN, R_BODYZ,                 // general tracking: log norms, body_z flag
   R_EXP0,                                  // [PBHC_NUM_SIGMA] exp(-err_k / sigma_k)
   R_FOOT0 = R_EXP0 + PBHC_NUM_SIGMA,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2)
   R_NUM = R_FOOT0 + 10
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
   float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
   float pf_last_act = 0, pf_last_qd = 0, pf_sum = 0, pf_tscale = 0, pf_sigma = 1.0f, pf_termsum = 0;
-  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0;
+  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0, pf_tsrc = -1;
   const float pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE], pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
   const float pf_soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], pf_soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], pf_soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
   const float pf_noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   const float fat = io.feet_air_time[(size_t)envc * NF + min(lane, NF - 1)], lastc = io.last_contacts[(size_t)envc * NF + min(lane, NF - 1)];
   {
     const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
-    pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_];
+    pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_]; pf_tsrc = c.term_src[tl_];
     sumrow = io.episode_sums[(size_t)envc * c.num_sum_cols + min(lane, c.num_sum_cols - 1)];
     pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
   }
@@ -494,14 +499,13 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
       if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
       st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
-    } else if (lane == 1) {
-      st3(feat + c.feat_off[PBHC_F_BASE_LIN_VEL], quat_rotate_inverse(rq4, ld3(root + 7)));
-    } else if (lane == 2) {
-      st3(feat + c.feat_off[PBHC_F_BASE_ANG_VEL], quat_rotate_inverse(rq4, ld3(root + 10)));
-    } else if (lane == 3) {
-      f3 g = quat_rotate_inverse(rq4, mk3(0.0f, 0.0f, -1.0f));
-      st3(feat + c.feat_off[PBHC_F_PROJECTED_GRAVITY], g);
-      misc[M_GX] = g.x; misc[M_GY] = g.y; misc[M_GZ] = g.z;
+    } else if (lane <= 3) {
+      // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
+      const f3 vin = lane == 1 ? ld3(root + 7) : (lane == 2 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
+      const f3 vo = quat_rotate_inverse(rq4, vin);
+      const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+      st3(feat + off, vo);
+      if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
     } else if (lane >= 4 && lane < 4 + NF) {
       int f = lane - 4;
       float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
@@ -679,7 +683,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
     red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
     red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
-    red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JV2] = s_jv2; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
+    red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
+    if (!MODE) for (int k = PBHC_S_KEY_BODY_POS; k < PBHC_NUM_SIGMA; ++k) red[R_ERR0 + k] = 0.0f;
     red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = clipcnt;
     // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
     float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
@@ -706,30 +711,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // (a) lane k < 10: e_k = exp(-err_k / sigma_k); lanes 10.. : per-foot norms.  (b) lane i <-> term i: cheap selects.
   if (valid) {
     if (lane < PBHC_NUM_SIGMA) {
-      float e;
-      switch (lane) {
-        case PBHC_S_MAX_JOINT_POS: e = red[R_MAXJP]; break;
-        case PBHC_S_UPPER_BODY_POS: e = red[R_UP]; break;
-        case PBHC_S_LOWER_BODY_POS: e = red[R_LO]; break;
-        case PBHC_S_VR_3POINT_POS: e = red[R_VR]; break;
-        case PBHC_S_FEET_POS: e = red[R_FEET]; break;
-        case PBHC_S_BODY_ROT: e = red[R_ROT]; break;
-        case PBHC_S_BODY_VEL: e = red[R_VEL]; break;
-        case PBHC_S_BODY_ANG_VEL: e = red[R_ANG]; break;
-        case PBHC_S_JOINT_POS: e = red[R_JP2] / (float)D; break;
-        case PBHC_S_JOINT_VEL: e = red[R_JV2] / (float)D; break;
-        case PBHC_S_KEY_BODY_POS: e = red[R_KEY]; break;
-        case PBHC_S_ANCHOR_BODY_POS: e = red[R_APOS]; break;
-        case PBHC_S_ANCHOR_BODY_ROT: e = red[R_AROT]; break;
-        case PBHC_S_LOCAL_KEY_BODY_POS: e = red[R_LKEY]; break;
-        case PBHC_S_LOCAL_KEY_BODY_ROT: e = red[R_LKROT]; break;
-        case PBHC_S_KEY_BODY_VEL: e = red[R_KVEL]; break;
-        case PBHC_S_KEY_BODY_ANG_VEL: e = red[R_KANG]; break;
-        case PBHC_S_ROOT_VEL: e = red[R_RVEL]; break;
-        case PBHC_S_ROOT_POSE: e = red[R_RPOSE]; break;
-        default: e = 0.0f; break;
-      }
-      if (!MODE && lane >= PBHC_S_KEY_BODY_POS) e = 0.0f;
+      const float e = red[R_ERR0 + lane];
       red[R_EXP0 + lane] = expf(-e / pf_sigma);
     } else if (lane < PBHC_NUM_SIGMA + NF) {
       const int f = lane - PBHC_NUM_SIGMA;
@@ -757,25 +739,21 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       const int id = pf_tid;
       const float* ex = red + R_EXP0;
       const float* ft = red + R_FOOT0;
-      switch (id) {
+      // Most terms are one value of the reduction row: `term_src` (filled by pbhc_env_create, see term_source()) is its LDS slot.
+      // Only the terms that combine several values keep a case.
+      if (pf_tsrc >= 0) raw = red[pf_tsrc];
+      else switch (id) {
         case PBHC_R_TELEOP_CONTACT_MASK: {
           float e = 0.0f;
           for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
           raw = 1.0f - e / (float)NF;
         } break;
-        case PBHC_R_TELEOP_MAX_JOINT_POSITION: raw = ex[PBHC_S_MAX_JOINT_POS]; break;
+        case PBHC_R_TELEOP_CONTACT_MASK_V2: {
+          float e = 0.0f;
+          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
+          raw = 0.5f - e / (float)NF;
+        } break;
         case PBHC_R_TELEOP_BODY_POSITION_EXTEND: raw = ex[PBHC_S_LOWER_BODY_POS] * c.body_pos_lower_weight + ex[PBHC_S_UPPER_BODY_POS] * c.body_pos_upper_weight; break;
-        case PBHC_R_TELEOP_VR_3POINT: raw = ex[PBHC_S_VR_3POINT_POS]; break;
-        case PBHC_R_TELEOP_BODY_POSITION_FEET: raw = ex[PBHC_S_FEET_POS]; break;
-        case PBHC_R_TELEOP_BODY_ROTATION_EXTEND: raw = ex[PBHC_S_BODY_ROT]; break;
-        case PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND: raw = ex[PBHC_S_BODY_ANG_VEL]; break;
-        case PBHC_R_TELEOP_BODY_VELOCITY_EXTEND: raw = ex[PBHC_S_BODY_VEL]; break;
-        case PBHC_R_TELEOP_JOINT_POSITION: raw = ex[PBHC_S_JOINT_POS]; break;
-        case PBHC_R_TELEOP_JOINT_VELOCITY: raw = ex[PBHC_S_JOINT_VEL]; break;
-        case PBHC_R_PENALTY_TORQUES: raw = red[R_TAU2]; break;
-        case PBHC_R_PENALTY_DOF_VEL: raw = red[R_QD2]; break;
-        case PBHC_R_PENALTY_DOF_ACC: raw = red[R_QACC2]; break;
-        case PBHC_R_PENALTY_ACTION_RATE: raw = red[R_ARATE]; break;
         case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
         case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
           for (int f = 0; f < NF; ++f) {
@@ -801,25 +779,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
         case PBHC_R_FOOT_SLIP_PENALTY:
           for (int f = 0; f < NF; ++f) raw += (ft[4 * f] > 1.0f ? 1.0f : 0.0f) * ft[8 + f];
           break;
-        case PBHC_R_LIMITS_DOF_POS: raw = red[R_LIMPOS]; break;
-        case PBHC_R_LIMITS_DOF_VEL: raw = red[R_LIMVEL]; break;
-        case PBHC_R_LIMITS_TORQUE: raw = red[R_LIMTAU]; break;
-        case PBHC_R_COLLISION: raw = red[R_COLL]; break;
         case PBHC_R_ALIVE: raw = 1.0f; break;
-        case PBHC_R_TELEOP_CONTACT_MASK_V2: {
-          float e = 0.0f;
-          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
-          raw = 0.5f - e / (float)NF;
-        } break;
-        case PBHC_R_TELEOP_KEY_BODY_POSITION: raw = ex[PBHC_S_KEY_BODY_POS]; break;
-        case PBHC_R_TELEOP_ANCHOR_BODY_POSITION: raw = ex[PBHC_S_ANCHOR_BODY_POS]; break;
-        case PBHC_R_TELEOP_ANCHOR_BODY_ROTATION: raw = ex[PBHC_S_ANCHOR_BODY_ROT]; break;
-        case PBHC_R_LOCAL_KEY_BODY_POSITION: raw = ex[PBHC_S_LOCAL_KEY_BODY_POS]; break;
-        case PBHC_R_LOCAL_KEY_BODY_ROTATION: raw = ex[PBHC_S_LOCAL_KEY_BODY_ROT]; break;
-        case PBHC_R_KEY_BODY_VELOCITY: raw = ex[PBHC_S_KEY_BODY_VEL]; break;
-        case PBHC_R_KEY_BODY_ANG_VELOCITY: raw = ex[PBHC_S_KEY_BODY_ANG_VEL]; break;
-        case PBHC_R_TELEOP_ROOT_VEL: raw = ex[PBHC_S_ROOT_VEL]; break;
-        case PBHC_R_TELEOP_ROOT_POSE: raw = ex[PBHC_S_ROOT_POSE]; break;
         default: raw = 0.0f;
       }
       myrew = raw * pf_tscale;
@@ -852,15 +812,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
       }
       rew_total = v;
     }
-    err[PBHC_S_MAX_JOINT_POS] = red[R_MAXJP]; err[PBHC_S_UPPER_BODY_POS] = red[R_UP]; err[PBHC_S_LOWER_BODY_POS] = red[R_LO];
-    err[PBHC_S_VR_3POINT_POS] = red[R_VR]; err[PBHC_S_FEET_POS] = red[R_FEET]; err[PBHC_S_BODY_ROT] = red[R_ROT];
-    err[PBHC_S_BODY_VEL] = red[R_VEL]; err[PBHC_S_BODY_ANG_VEL] = red[R_ANG]; err[PBHC_S_JOINT_POS] = red[R_JP2] / (float)D;
-    err[PBHC_S_JOINT_VEL] = red[R_JV2] / (float)D;
-    if (MODE) {
-      err[PBHC_S_KEY_BODY_POS] = red[R_KEY]; err[PBHC_S_ANCHOR_BODY_POS] = red[R_APOS]; err[PBHC_S_ANCHOR_BODY_ROT] = red[R_AROT];
-      err[PBHC_S_LOCAL_KEY_BODY_POS] = red[R_LKEY]; err[PBHC_S_LOCAL_KEY_BODY_ROT] = red[R_LKROT]; err[PBHC_S_KEY_BODY_VEL] = red[R_KVEL];
-      err[PBHC_S_KEY_BODY_ANG_VEL] = red[R_KANG]; err[PBHC_S_ROOT_VEL] = red[R_RVEL]; err[PBHC_S_ROOT_POSE] = red[R_RPOSE];
-    }
+#pragma unroll
+    for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = red[R_ERR0 + k];
   }
   LDS_BARRIER();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
 
@@ -1060,6 +1013,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
             uint32_t w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int p = p0 + u * PBHC_G; w[u] = p < npair ? m32[p] : 0u; }
+#ifdef PBHC_STAMPS
+            if (g == 1 && p0 == lane) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(20); }
+#endif
             float xa[8], xb[8], sa[8], sb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1067,6 +1023,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
               xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
               xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
             }
+#ifdef PBHC_STAMPS
+            if (g == 1 && p0 == lane) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(21); }
+#endif
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int j = 2 * (p0 + u * PBHC_G);
@@ -1075,6 +1034,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
               if (j + 1 < dim) *reinterpret_cast<float2*>(out + j) = make_float2(va, vb);
               else if (j < dim) out[j] = va;
             }
+#ifdef PBHC_STAMPS
+            if (g == 1 && p0 == lane) STAMP(22);
+#endif
           }
         } else
         for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
@@ -1501,6 +1463,38 @@ __global__ void k_adv_norm(float* __restrict__ adv, size_t TN, const double* __r
 // =================================================================================================
 //  C ABI
 // =================================================================================================
+// LDS slot of the reduction row that IS the raw value of a reward term, or -1 for the terms computed by a case of the kernel's switch
+static int term_source(int id) {
+  switch (id) {
+    case PBHC_R_TELEOP_MAX_JOINT_POSITION: return R_EXP0 + PBHC_S_MAX_JOINT_POS;
+    case PBHC_R_TELEOP_VR_3POINT: return R_EXP0 + PBHC_S_VR_3POINT_POS;
+    case PBHC_R_TELEOP_BODY_POSITION_FEET: return R_EXP0 + PBHC_S_FEET_POS;
+    case PBHC_R_TELEOP_BODY_ROTATION_EXTEND: return R_EXP0 + PBHC_S_BODY_ROT;
+    case PBHC_R_TELEOP_BODY_ANG_VELOCITY_EXTEND: return R_EXP0 + PBHC_S_BODY_ANG_VEL;
+    case PBHC_R_TELEOP_BODY_VELOCITY_EXTEND: return R_EXP0 + PBHC_S_BODY_VEL;
+    case PBHC_R_TELEOP_JOINT_POSITION: return R_EXP0 + PBHC_S_JOINT_POS;
+    case PBHC_R_TELEOP_JOINT_VELOCITY: return R_EXP0 + PBHC_S_JOINT_VEL;
+    case PBHC_R_PENALTY_TORQUES: return R_TAU2;
+    case PBHC_R_PENALTY_DOF_VEL: return R_QD2;
+    case PBHC_R_PENALTY_DOF_ACC: return R_QACC2;
+    case PBHC_R_PENALTY_ACTION_RATE: return R_ARATE;
+    case PBHC_R_LIMITS_DOF_POS: return R_LIMPOS;
+    case PBHC_R_LIMITS_DOF_VEL: return R_LIMVEL;
+    case PBHC_R_LIMITS_TORQUE: return R_LIMTAU;
+    case PBHC_R_COLLISION: return R_COLL;
+    case PBHC_R_TELEOP_KEY_BODY_POSITION: return R_EXP0 + PBHC_S_KEY_BODY_POS;
+    case PBHC_R_TELEOP_ANCHOR_BODY_POSITION: return R_EXP0 + PBHC_S_ANCHOR_BODY_POS;
+    case PBHC_R_TELEOP_ANCHOR_BODY_ROTATION: return R_EXP0 + PBHC_S_ANCHOR_BODY_ROT;
+    case PBHC_R_LOCAL_KEY_BODY_POSITION: return R_EXP0 + PBHC_S_LOCAL_KEY_BODY_POS;
+    case PBHC_R_LOCAL_KEY_BODY_ROTATION: return R_EXP0 + PBHC_S_LOCAL_KEY_BODY_ROT;
+    case PBHC_R_KEY_BODY_VELOCITY: return R_EXP0 + PBHC_S_KEY_BODY_VEL;
+    case PBHC_R_KEY_BODY_ANG_VELOCITY: return R_EXP0 + PBHC_S_KEY_BODY_ANG_VEL;
+    case PBHC_R_TELEOP_ROOT_VEL: return R_EXP0 + PBHC_S_ROOT_VEL;
+    case PBHC_R_TELEOP_ROOT_POSE: return R_EXP0 + PBHC_S_ROOT_POSE;
+    default: return -1;
+  }
+}
+
 struct PbhcEnv {
   PbhcEnvConfig cfg;
   PbhcEnvConfig* d_cfg;
@@ -1606,6 +1600,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   PbhcEnv* e = new (std::nothrow) PbhcEnv();
   if (!e) return PBHC_ENOMEM;
   e->cfg = *cfg;
+  for (int i = 0; i < PBHC_MAX_TERMS; ++i) e->cfg.term_src[i] = i < cfg->num_terms ? term_source(cfg->term_id[i]) : -1;
   e->tbl = *tbl;
   e->d_glob = globals;
   e->nblocks = (cfg->num_envs + PBHC_EPB - 1) / PBHC_EPB;

@@ -39,3 +39,5 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
         for g in range(3):
             print(f"  obs group {g}: pass1 {st[12 + 2 * g] - prev} cyc, noisy pass {st[13 + 2 * g] - st[12 + 2 * g]} cyc")
             prev = st[13 + 2 * g]
+        if st[20]:
+            print(f"  group 1 first batch: map reads {st[20] - st[13]} cyc, feature+segment reads {st[21] - st[20]} cyc, scale/clip/stores {st[22] - st[21]} cyc")
