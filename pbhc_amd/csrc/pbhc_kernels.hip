@@ -21,7 +21,9 @@ using namespace pbhc;
 #include PBHC_STATIC_CFG
 #endif
 
+#ifndef PBHC_G
 #define PBHC_G 32     // lanes per env
+#endif
 #define PBHC_EPB 4    // envs per workgroup
 #define PBHC_NP 64    // partial sums per workgroup
 
@@ -116,12 +118,12 @@ enum {
 
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+  for (int m = PBHC_G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, PBHC_G);
   return v;
 }
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 32));
+  for (int m = PBHC_G / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, PBHC_G));
   return v;
 }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -270,7 +272,10 @@ extern __shared__ float smem[];
 
 // MODE 0: LeggedRobotMotionTracking (motion_tracking.py), MODE 1: LeggedRobotGeneralTracking (general_tracking.py)
 template <int MODE>
-__global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
+#ifndef PBHC_MIN_WAVES
+#define PBHC_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
   // state and the reference rows stay in flight behind the chain).  _pre_physics_step (motion_tracking.py:749-768) and the
   // torques from the pre-step state (legged_robot_base.py:795-838) are computed when their operands land.
   // All lanes of an env compute the reference-frame address redundantly (no LDS round trip).
-#define PBHC_HREG 12                                    // history words per lane held in registers (hist_dim <= 384)
+#define PBHC_HREG (384 / PBHC_G)                        // history words per lane held in registers (hist_dim <= 384)
   long long ep1 = 0;
   float start = 0.0f, mlen_env = 0.0f, tref = 0.0f, blend = 0.0f;
   int mid = 0;
@@ -369,11 +374,11 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
 #pragma unroll
     for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = hsrc[min(lane + u * PBHC_G, hlast)];
   }
-  float creg[4];
+  float creg[128 / PBHC_G];
   {
     const float* __restrict__ csrc = io.frame_contact + (fk + envc) * (size_t)(B * 3);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) creg[u] = csrc[min(lane + u * PBHC_G, B * 3 - 1)];
+    for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = csrc[min(lane + u * PBHC_G, B * 3 - 1)];
   }
   float qold[PBHC_MAX_QUEUE];
   float* qu = io.action_queue + (size_t)envc * Q * D + dc;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_env_step(const PbhcEnvConf
     if (c.hist_dim > PBHC_HREG * PBHC_G)
       copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
+    for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
     if (d < D) {
       const float tl = c.torque_limits[d];
       const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
