@@ -33,17 +33,9 @@ class LeggedRobotGeneralTracking(LeggedRobotMotionTracking):
         self.curr_motion_ids = self._motion_lib.slot_clip
         self.num_motions = self._motion_lib._num_unique_motions
         self.motion_start_idx = 0
-        if config.resample_motion_when_training:
-            self.resample_time_interval = np.ceil(config.resample_time_interval_s / self.dt)
 
     def _load_motions_initial(self):
         self._motion_lib.load_motions(random_sample=False)                 # general_tracking.py:57-61: init not random sample
-
-    # ---- slot -> clip resampling (general_tracking.py:216-222,291-297) ------------------------
-    def resample_motion(self):
-        self._motion_lib.load_motions(random_sample=True)
-        self.curr_motion_ids = self._motion_lib.slot_clip
-        self.reset_all_no_step()
 
     def next_task(self):
         self.motion_start_idx += self.num_envs
@@ -52,19 +44,6 @@ class LeggedRobotGeneralTracking(LeggedRobotMotionTracking):
         self._motion_lib.load_motions(random_sample=False, start_idx=self.motion_start_idx)
         self.curr_motion_ids = self._motion_lib.slot_clip
         self.reset_all()
-
-    def reset_all_no_step(self):
-        """reset_envs_idx(all) without the zero-action step of reset_all (what resample_motion calls)."""
-        self._reset_all_state()
-
-    def step(self, actor_state):
-        out = super().step(actor_state)
-        # _update_tasks_callback (general_tracking.py:216-222).  In the reference this runs inside the step, before termination and
-        # reward of that step; here it runs after the fused launch, i.e. one control step later on the resampled slots — once every
-        # resample_time_interval (50 000 steps with the shipped config).
-        if self.config.resample_motion_when_training and not self.is_evaluating and self.common_step_counter % self.resample_time_interval == 0:
-            self.resample_motion()
-        return out
 
     def read_log(self):
         out = super().read_log()

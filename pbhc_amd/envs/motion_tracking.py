@@ -98,6 +98,8 @@ class LeggedRobotMotionTracking:
         self.extras = {}
         self.common_step_counter = 0
         self._resample_motion_times(torch.arange(N, device=dev))
+        if config.get("resample_motion_when_training", False):
+            self.resample_time_interval = np.ceil(config.resample_time_interval_s / self.dt)
         self.init_done = True
 
     def _load_motions_initial(self):
@@ -262,6 +264,12 @@ class LeggedRobotMotionTracking:
         else:
             self.motion_start_times[env_ids] = self._motion_lib.sample_time(self.motion_ids[env_ids])
 
+    def resample_motion(self):
+        """motion_tracking.py:385-389 / general_tracking.py:291-297"""
+        self._motion_lib.load_motions(random_sample=True)
+        self.curr_motion_ids = self._motion_lib.slot_clip
+        self._reset_all_state()
+
     def reset_all(self):
         """base_task.py:83-93: reset every env, then one step with zero actions.  Start-up path,
         done with torch ops on the device (the per-step reset of terminated envs is in the kernel)."""
@@ -345,6 +353,11 @@ class LeggedRobotMotionTracking:
         io.frame_index = s.take_host_frame()
         _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
         self.common_step_counter += 1
+        # _update_tasks_callback (motion_tracking.py:320-325, general_tracking.py:216-222): periodic slot -> clip resampling + reset of every
+        # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
+        # it takes effect one control step later — once every resample_time_interval (50 000 - 100 000 steps in the shipped configs).
+        if self.config.get("resample_motion_when_training", False) and self.common_step_counter % self.resample_time_interval == 0:
+            self.resample_motion()
         self.extras["time_outs"] = self.time_out_buf
         self.extras["ref_body_pos_extend"] = self.ref_body_pos_extend
         self.extras["ref_body_rot_extend"] = self.ref_body_rot_extend

@@ -267,3 +267,38 @@ def test_ppo_mimic_distillation_matches_reference(tmp_path):
     assert env.obs_buf_dict["teacher_future_motion_targets"].shape == (N, 57 * 20)
     d = algo.optimizer.state_dict()
     assert len(d["param_groups"][0]["params"]) == len(list(algo.alg.actor.parameters()))
+
+
+def test_periodic_motion_resampling_resets_every_env():
+    """resample_motion_when_training (general_tracking.py:216-222,291-297): every resample_time_interval steps the slot -> clip map is
+    redrawn from the sampling probabilities and every env is reset onto its new clip."""
+    import bench
+    from pbhc_amd import motion_lib as ML
+    from tests.helpers import clip_from_env_golden
+
+    g = dict(np.load(os.path.join(GOLDEN, "env_v2_teacher29.npz")))
+    clips = bench.synth_library(clip_from_env_golden(g), 3, seed=3)
+    orig = ML.load_motion_file
+    ML.load_motion_file = lambda path: [(f"c{i}", c) for i, c in enumerate(clips)]
+    try:
+        cfg, env = build_hip_env("v2_g1_29dof_teacher.yaml", 64, general=True,
+                                 overrides={"domain_rand.push_robots": False, "env.config.resample_time_interval_s": 0.02 * 3})
+    finally:
+        ML.load_motion_file = orig
+    assert env.resample_time_interval == 3
+    env.reset_all()                                         # one step
+    torch.manual_seed(0)
+    act = torch.zeros(64, env.num_dof, device=DEV)
+    env.step({"actions": act})                              # step 2
+    before = env._motion_lib.slot_clip.clone()
+    assert before.tolist() == [i % 3 for i in range(64)]
+    env._motion_lib._sampling_prob.copy_(torch.tensor([0.0, 0.0, 1.0], device=DEV))       # the sampling hook: only clip 2 from now on
+    env.step({"actions": act})                              # step 3 -> resample
+    torch.cuda.synchronize()
+    assert env._motion_lib.slot_clip.tolist() == [2] * 64
+    assert int(env.episode_length_buf.abs().sum()) == 0
+    assert torch.allclose(env.motion_len, env._motion_lib._motion_lengths[2].expand(64))
+    assert bool((env.motion_start_times <= env.motion_len).all())
+    obs, _, reset, _ = env.step({"actions": act})
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in obs.values())
