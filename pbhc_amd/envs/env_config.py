@@ -161,6 +161,8 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
             raise NotImplementedError(f"domain_rand.{unsupported}")
     if dr.get("randomize_default_dof_pos", False):
         raise NotImplementedError("domain_rand.randomize_default_dof_pos")
+    if dr.get("reinit_epis_rand", -1) > 0:
+        raise NotImplementedError("domain_rand.reinit_epis_rand (re-randomisation of the episodic DR at exponential intervals, legged_robot_base.py:390-395)")
     # ---- body index sets
     names = skel.body_names
     ext = skel.body_names_ext
