@@ -151,6 +151,12 @@ def current_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def padded_width(dim):
+    """Row pitch (floats) of the [N, dim] tensors the env kernel writes: a multiple of 32 floats (rows start on 128-byte lines) with at
+    least two floats of padding (lanes past the end of a row store there instead of being predicated off)."""
+    return (dim + 2 + 31) // 32 * 32
+
+
 def require_gpu_rows(t, name, dtype=None, shape=None):
     """as require_gpu_tensor, but rows may be padded: [N, C] with stride (pitch >= C, 1)"""
     import torch

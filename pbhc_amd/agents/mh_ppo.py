@@ -256,7 +256,7 @@ class MHPPO:
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, (d + 31) // 32 * 32, device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
+        self._last_obs = {k: torch.zeros(N, _lib.padded_width(d), device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
         self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
         self._branch_stream = torch.cuda.Stream(device=self.device)
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):

@@ -11,6 +11,8 @@ import math
 
 import torch
 import torch.nn as nn
+
+from .. import _lib
 from torch.distributions import Normal
 
 
@@ -138,7 +140,7 @@ class RolloutStorage(nn.Module):
         assert not hasattr(self, key), key
         assert isinstance(shape, (list, tuple)), "shape must be a list or tuple"
         if pad_rows and len(shape) == 1:
-            buf = torch.zeros((self.num_transitions_per_env, self.num_envs, (shape[0] + 31) // 32 * 32), dtype=dtype, device=self.device)[..., :shape[0]]
+            buf = torch.zeros((self.num_transitions_per_env, self.num_envs, _lib.padded_width(shape[0])), dtype=dtype, device=self.device)[..., :shape[0]]
         else:
             buf = torch.zeros((self.num_transitions_per_env, self.num_envs) + tuple(shape), dtype=dtype, device=self.device)
         self.register_buffer(key, buf, persistent=False)

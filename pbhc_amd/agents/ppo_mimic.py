@@ -258,7 +258,7 @@ class PPO:
             st.register_key("teacher_actions", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, (w + 31) // 32 * 32, device=self.device)[:, :w] for k, w in self._obs_width.items()}
+        self._last_obs = {k: torch.zeros(N, _lib.padded_width(w), device=self.device)[:, :w] for k, w in self._obs_width.items()}
         self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd PPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")

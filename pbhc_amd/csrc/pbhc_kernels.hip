@@ -1014,10 +1014,13 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
           // rows start 8-byte aligned: a lane takes PAIRS of elements — one 32-bit LDS word holds both map entries, one 8-byte store both values
           const uint32_t* m32 = (const uint32_t*)m16;
           const int npair = (dim + 1) >> 1;
+          // rows padded by at least two floats (ours are): lanes past the end store into the padding instead of being predicated off,
+          // and read a clamped map word — the batch is branch-free
+          const bool pad_ok = pitch_g >= dim + 2 + (dim & 1);
           for (int p0 = lane; p0 < npair; p0 += 8 * PBHC_G) {
             uint32_t w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int p = p0 + u * PBHC_G; w[u] = p < npair ? m32[p] : 0u; }
+            for (int u = 0; u < 8; ++u) w[u] = m32[min(p0 + u * PBHC_G, npair - 1)];
 #ifdef PBHC_STAMPS
             if (g == 1 && p0 == lane) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(20); }
 #endif
@@ -1036,7 +1039,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
               const int j = 2 * (p0 + u * PBHC_G);
               float va = xa[u] * sa[u], vb = xb[u] * sb[u];
               if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
-              if (j + 1 < dim) *reinterpret_cast<float2*>(out + j) = make_float2(va, vb);
+              if (pad_ok) {
+                const int jj = (j + 1 < dim) ? j : ((j < dim) ? j : pitch_g - 2);      // a trailing odd element writes its pair's second half into the padding
+                *reinterpret_cast<float2*>(out + jj) = make_float2(va, vb);
+              } else if (j + 1 < dim) *reinterpret_cast<float2*>(out + j) = make_float2(va, vb);
               else if (j < dim) out[j] = va;
             }
 #ifdef PBHC_STAMPS

@@ -183,11 +183,13 @@ __device__ __forceinline__ f4 matrix_to_quat_xyzw(const m33& M) {
   return mk4(c[1] / den, c[2] / den, c[3] / den, c[0] / den);
 }
 
-// ---- Philox4x32-10 counter RNG (own; the reference draws from torch's global generator, so
-// noise-on runs are compared statistically, never bitwise) ---------------------------------------
+// ---- Philox4x32-7 counter RNG (own; the reference draws from torch's global generator, so noise-on runs are compared
+// statistically, never bitwise).  7 rounds is the smallest Crush-resistant member of the family (Salmon et al., "Parallel random
+// numbers: as easy as 1, 2, 3", SC'11, Table 2); the step kernel is instruction-bound and runs the generator at four call sites. ----
+#define PBHC_PHILOX_ROUNDS 7
 __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < PBHC_PHILOX_ROUNDS; ++i) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

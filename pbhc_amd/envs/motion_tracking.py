@@ -388,7 +388,7 @@ class LeggedRobotMotionTracking:
 
 def _padded_rows(n, dim, device, dtype=torch.float32):
     """[n, dim] view of an [n, ceil32(dim)] buffer: every row starts on a 128-byte line."""
-    return torch.zeros(n, (dim + 31) // 32 * 32, dtype=dtype, device=device)[:, :dim]
+    return torch.zeros(n, _lib.padded_width(dim), dtype=dtype, device=device)[:, :dim]
 
 
 class _TopView:
