@@ -80,9 +80,13 @@ class ConvEncoder(nn.Module):
         self.output_layer = nn.Linear(out_channels[-1] * 3, self.output_dim)
         self._act = act
         self._strides = strides
+        self.unfold_gemm = None        # None: unfolded-window GEMMs on the GPU, nn.Conv1d on the CPU (what the deploy exporters trace)
 
     def forward(self, x):
         B = x.shape[0] if x.dim() == 2 else x.numel() // (self.input_dim * self.time_steps)
+        if not (x.is_cuda if self.unfold_gemm is None else self.unfold_gemm):
+            h = self.encoder(x.reshape(-1, self.input_dim)).view(B, self.time_steps, self.hidden_dim).permute(0, 2, 1)
+            return self.output_layer(self.conv_module(h).flatten(start_dim=1))
         x = F.relu(_linear(x.reshape(-1, self.input_dim), self.encoder[0])).view(B, self.time_steps, self.hidden_dim)   # [B, T, H]: x.view(-1, input_dim) chunks, sic
         for i, s in enumerate(self._strides):
             conv = self.conv_module[2 * i]

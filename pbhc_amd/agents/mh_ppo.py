@@ -70,7 +70,8 @@ def policy_forward_graphs(self, eager, key=0):
         with torch.cuda.stream(side):
             for t in range(T):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=side):
+                # thread_local: the RCCL watchdog thread polls its events while we capture; only this thread's calls are policed
+                with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
                     out = eager(t)
                 pool = g.pool() if pool is None else pool
                 graphs.append(g); outs.append(out)

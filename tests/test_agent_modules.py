@@ -19,6 +19,7 @@ def test_actor_critic_matches_oracle_forward_and_backward():
     sd = {k[4:]: v for k, v in g.items() if k.startswith("w0__")}
     assert list(ac.state_dict().keys()) == list(sd.keys())
     ac.load_state_dict(sd, strict=True)
+    ac.actor.motion_encoder.unfold_gemm = ac.actor.history_encoder.unfold_gemm = True        # the GPU formulation, run here on the CPU
     st = {k[4:]: v.flatten(0, 1) for k, v in g.items() if k.startswith("st__")}
     mu, v, h = ac.actor(st, False), ac.evaluate(st), ac.actor.history_encoding(st["prop_history"])
     assert torch.allclose(mu, st["action_mean"], atol=1e-5) and torch.allclose(v, st["values"], atol=1e-5)

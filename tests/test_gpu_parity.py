@@ -325,6 +325,11 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
         assert torch.allclose(actor_cpu.act_inference(ex), ref_out, atol=1e-5)
         traced = torch.jit.trace(actor_cpu.actor_module, ex)
         assert torch.allclose(traced(ex), ref_out, atol=1e-5)
+    # ... and the exporter itself: the file evaluates (numpy ONNX reader) to the GPU actor's action on the example observation
+    from pbhc_amd.utils import inference_helpers as ih
+
+    file = ih.export_policy_as_onnx(algo.inference_model, str(tmp_path), "model_0.onnx", algo.get_example_obs())
+    assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
 def test_learn_runs_two_iterations():

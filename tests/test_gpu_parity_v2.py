@@ -125,6 +125,17 @@ def test_ppo_mimic_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert d["optimizer_state_dict"]["param_groups"][0]["weight_decay"] == 0.01
     assert algo.load(p) == {"x": 1}
     assert algo.inference_model["actor"] is algo.alg.actor
+    # deploy export of the encoder policy (inference_helpers.py:95-138): three named inputs, graph == the GPU actor (unfolded-window GEMMs)
+    from pbhc_amd.utils import inference_helpers as ih
+    from pbhc_amd.utils import onnx_lite
+
+    ex = algo.get_example_obs()
+    file = ih.export_policy_and_encoder_as_onnx(algo.inference_model, str(tmp_path), "model_0.onnx", ex)
+    m = onnx_lite.read_model(file)
+    feeds = {n: ex[n][:1].cpu().numpy() for n, _ in m["inputs"]}
+    with torch.no_grad():
+        want = algo.alg.act_inference({k: ex[k][:1] for k in ex}, hist_encoding=True).cpu().numpy()
+    assert np.abs(onnx_lite.run(m, feeds)[0] - want).max() <= 1e-5
 
 
 def test_ppo_mimic_learn_runs_two_iterations():
