@@ -142,3 +142,68 @@ def synth_replay(ml, skel, N, T, start_times, ep_len, dt, origins, seed, feet, h
         cf[k, :, feet, 2] = on * (300.0 + 50.0 * torch.randn(N, 2, generator=g))
         cf[k, :, feet, 0:2] = on.unsqueeze(-1) * 20.0 * torch.randn(N, 2, 2, generator=g)
     return root, qp, qv, cf
+
+
+# ---- the reference's recorded sim2sim rollout (tests/golden/deploy_student23_recording.npz) -----------------------------------
+# actor_obs layout of the shipped student policy: sorted keys of obs_dict.actor_obs (deploy/urcirobot.py:349-354)
+DEPLOY_LAYOUT = [("actions", 23), ("anchor_ref_rot", 6), ("base_ang_vel", 3), ("dof_pos", 23), ("dof_vel", 23), ("history_actor", 740),
+                 ("next_step_ref_motion", 57), ("roll_pitch", 2)]
+
+
+def deploy_layout_slices():
+    out, o = {}, 0
+    for k, w in DEPLOY_LAYOUT:
+        out[k] = slice(o, o + w)
+        o += w
+    return out
+
+
+def deploy_recording_states(rec, oml, default_dof_pos, obs_scales, dt):
+    """Robot states the recorded observations were built from, rows 1..T-1 -> (root [T-1,13], dof_pos, dof_vel [T-1,D]).
+
+    The state columns of the recording lag the observation by one physics sub-step (see gen_deploy_recording_fixture.py), so the state
+    is recovered from the observation row itself: joint positions / velocities and the body-frame angular velocity by undoing offset and
+    scale, and the base orientation from `anchor_ref_rot` = first two columns of R_robot^T R_ref (deploy/urcirobot.py:466-475; the
+    robot starts on the clip's first frame, so the deploy stack's initial-yaw alignment is the identity to 1e-7) with R_ref from the
+    oracle motion library at (row+1)*dt.  What this leaves to be checked, independently of the inputs: `roll_pitch` (Euler convention
+    + anchor formula + library root rotation), `next_step_ref_motion` (library interpolation, FK, anchor-local key bodies, local root
+    velocity), the key-major newest-first history and the whole layout / scaling."""
+    from oracle import rotations as R
+
+    sl = deploy_layout_slices()
+    A = torch.from_numpy(rec["actor_obs"])
+    T = A.shape[0]
+    ids = torch.zeros(1, dtype=torch.long)
+    roots, qs, qds = [], [], []
+    for r in range(1, T):
+        row = A[r]
+        ref = oml.get_motion_state(ids, torch.tensor([(r + 1) * dt], dtype=torch.float32))
+        Rref = R.quaternion_to_matrix_wxyz(R.xyzw_to_wxyz(ref["root_rot"]))[0]
+        c = row[sl["anchor_ref_rot"]].reshape(3, 2)
+        M = torch.cat([c, torch.linalg.cross(c[:, 0], c[:, 1])[:, None]], dim=1)
+        q = R.wxyz_to_xyzw(R.matrix_to_quaternion_wxyz((Rref @ M.T)[None]))[0]
+        q = q / q.norm()
+        w_world = R.quat_rotate(q[None], (row[sl["base_ang_vel"]] / obs_scales["base_ang_vel"])[None])[0]
+        roots.append(torch.cat([torch.from_numpy(rec["root_trans_offset"][r - 1]), q, torch.from_numpy(rec["root_lin_vel"][r - 1]), w_world]))
+        qs.append(row[sl["dof_pos"]] / obs_scales["dof_pos"] + default_dof_pos)
+        qds.append(row[sl["dof_vel"]] / obs_scales["dof_vel"])
+    return torch.stack(roots), torch.stack(qs), torch.stack(qds)
+
+
+def fresh_episode_state(orc):
+    """Oracle-format state dict of an episode that starts at clip time 0 with zero actions and an empty history."""
+    st = {k: v.clone() for k, v in orc.s.items()}
+    for k in ["actions", "last_actions", "actions_after_delay", "action_queue", "last_dof_vel", "torques", "motion_start_times"]:
+        st[k] = torch.zeros_like(st[k])
+    for k in ["episode_length_buf", "last_episode_length_buf", "action_delay_idx"]:
+        st[k] = torch.zeros_like(st[k])
+    st["motion_len"] = orc.ml.motion_len[orc.motion_ids].clone()
+    flat = {k: v.numpy() for k, v in st.items()}
+    for k in orc.sums:
+        flat["sum__" + k] = np.zeros(orc.N, np.float32)
+    for k in orc.hist:
+        flat["hist__" + k] = np.zeros(tuple(orc.hist[k].shape), np.float32)
+    for k in orc.sigma:
+        flat["sigma__" + k] = orc.sigma[k]
+    flat.update(reward_penalty_scale=1.0, average_episode_length=0.0, motion_far_threshold=1.5)
+    return flat

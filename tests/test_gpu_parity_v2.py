@@ -313,3 +313,59 @@ def test_periodic_motion_resampling_resets_every_env():
     obs, _, reset, _ = env.step({"actions": act})
     torch.cuda.synchronize()
     assert all(torch.isfinite(v).all() for v in obs.values())
+
+
+def test_hip_env_reproduces_recorded_deploy_observations():
+    """The reference's own recorded sim2sim rollout (tests/test_deploy_recording.py explains fixture, state recovery and tolerances): the
+    fused HIP step, fed the recorded actions and recovered robot states through the replay stub, reproduces every recorded 877-wide
+    `actor_obs` row — layout, scales, Euler convention, anchor frame, key-major history and the reference-motion block."""
+    from tests.helpers import deploy_layout_slices, deploy_recording_states, fresh_episode_state
+    from tests.test_deploy_recording import check_rows
+    from tests.test_oracle_env_v2 import build_oracle_v2
+
+    rec = dict(np.load(os.path.join(GOLDEN, "deploy_student23_recording.npz")))
+    g, orc, skel = build_oracle_v2("student23", "v2_g1_23dof_student.yaml", "g1_23dof")
+    N = orc.N
+    cfg, env = build_hip_env("v2_g1_23dof_student.yaml", N, general=True, overrides={"domain_rand.push_robots": False})
+    env.env_origins.zero_()
+    load_state_into_hip_env(env, fresh_episode_state(orc))
+    root, qp, qv = deploy_recording_states(rec, orc.ml, orc.default_dof_pos.reshape(-1)[: orc.D], orc.cfg.obs.obs_scales, orc.dt)
+    T = root.shape[0]
+    rep = lambda a: a[:, None].repeat(1, N, *([1] * (a.dim() - 1))).contiguous().to(DEV)
+    env.simulator.set_replay(rep(root), rep(qp), rep(qv), torch.zeros(T, N, env.simulator.num_bodies, 3, device=DEV))
+    acts = torch.from_numpy(rec["action"]).to(DEV)
+    worst = {}
+    for r in range(1, T + 1):
+        obs, rew, reset, extras = env.step({"actions": acts[r - 1][None].repeat(N, 1).contiguous()})
+        a = obs["actor_obs"].cpu()
+        assert not reset.any(), f"row {r}: unexpected termination"
+        assert a.shape == (N, 877) and torch.equal(a[0], a[N - 1])
+        check_rows(a[0].numpy(), rec["actor_obs"][r], r, worst)
+        assert torch.equal(obs["prop_history"].cpu()[0], a[0][deploy_layout_slices()["history_actor"]])
+    assert worst["actions"] == 0.0 and worst["roll_pitch"] > 0
+
+
+def test_hip_env_reproduces_sim2sim_log():
+    """Second recording of the reference's deploy stack (exact observation-time robot state logged, 199 consecutive steps on g1_walk_45cms,
+    futures running past the clip end): actor_obs (877) and future_motion_targets (600) of the fused HIP step against the logged rows."""
+    from tests.helpers import fresh_episode_state
+    from tests.test_deploy_recording import LAST_ROW, WALK_CLIP, check_log_row, sim2sim_log_frames, student_walk_oracle
+
+    log = dict(np.load(os.path.join(GOLDEN, "deploy_sim2sim_log_walk.npz")))
+    N = 8
+    orc, skel = student_walk_oracle(N)
+    cfg, env = build_hip_env("v2_g1_23dof_student.yaml", N, general=True, overrides={"domain_rand.push_robots": False, "robot.motion.motion_file": WALK_CLIP})
+    env.env_origins.zero_()
+    load_state_into_hip_env(env, fresh_episode_state(orc))
+    root, qp, qv = sim2sim_log_frames(log, orc.ml)
+    rep = lambda a: a[:, None].repeat(1, N, 1).contiguous().to(DEV)
+    env.simulator.set_replay(rep(root), rep(qp), rep(qv), torch.zeros(LAST_ROW, N, env.simulator.num_bodies, 3, device=DEV))
+    acts = torch.from_numpy(log["action"]).to(DEV)
+    worst = {}
+    for r in range(1, LAST_ROW + 1):
+        obs, rew, reset, extras = env.step({"actions": acts[r - 1][None].repeat(N, 1).contiguous()})
+        assert not reset.any(), f"row {r}: unexpected termination"
+        o = {k: obs[k].cpu() for k in ("actor_obs", "future_motion_targets")}
+        assert torch.equal(o["actor_obs"][0], o["actor_obs"][N - 1])
+        check_log_row(o, log, r, worst)
+    assert worst["anchor_ref_rot"] > 0 and worst["actions"] == 0.0
