@@ -211,7 +211,7 @@ def main():
     algo.setup()
     T = algo.num_steps_per_env
     obs = env.reset_all()
-    frames = (K + W) * T + 2
+    frames = (K + max(W, 2)) * T + 2
     env.simulator.set_replay(*make_replay_on_device(env, frames, seed=99 + rank))
     algo._train_mode()
     from pbhc_amd import _lib
@@ -223,6 +223,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # setup, not measurement: the policy forward is captured into hipGraphs on the second rollout (the first runs eagerly so that
+    # GEMM solution selection sees every shape outside a capture) — make sure that has happened even when --warmup < 2
+    for _ in range(max(0, 2 - W)):
+        obs = algo._rollout_step(obs)
+        algo._training_step()
     for _ in range(W):
         obs = algo._rollout_step(obs)
         algo._training_step()

@@ -1200,43 +1200,53 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
     tot[threadIdx.x] = t;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  // the scalar updates are independent chains of dependent global loads / double divisions: one lane (of different waves) per chain
   const double N = (double)c.num_envs;
-  // adaptive sigma (motion_tracking.py:1030-1048, general_tracking.py:972-996)
-  if (c.adaptive_sigma)
-    for (int i = 0; i < PBHC_NUM_SIGMA; ++i)
-      if (c.sigma_active[i]) {
-        double mean = (double)(float)(tot[P_ERR + i] / N);
-        double ema = glob[PBHC_G_EMA + i] * (1.0 - (double)c.adaptive_alpha) + mean * (double)c.adaptive_alpha;
-        glob[PBHC_G_EMA + i] = ema;
-        const double sg = glob[PBHC_G_SIGMA + i];
-        double nsg;
-        switch (c.adaptive_type) {
-          case 1: nsg = (fmin(ema, sg) + ema) / 2.0; break;
-          case 2: nsg = fmin(ema * (double)c.adaptive_scale, sg); break;
-          case 3: nsg = ema; break;
-          default: nsg = fmin(ema, sg);
-        }
-        glob[PBHC_G_SIGMA + i] = nsg;
+  const int tid = threadIdx.x;
+  // adaptive sigma (motion_tracking.py:1030-1048, general_tracking.py:972-996): lane i of wave 0 owns term i
+  if (tid < PBHC_NUM_SIGMA) {
+    const int i = tid;
+    if (c.adaptive_sigma && c.sigma_active[i]) {
+      double mean = (double)(float)(tot[P_ERR + i] / N);
+      double ema = glob[PBHC_G_EMA + i] * (1.0 - (double)c.adaptive_alpha) + mean * (double)c.adaptive_alpha;
+      glob[PBHC_G_EMA + i] = ema;
+      const double sg = glob[PBHC_G_SIGMA + i];
+      double nsg;
+      switch (c.adaptive_type) {
+        case 1: nsg = (fmin(ema, sg) + ema) / 2.0; break;
+        case 2: nsg = fmin(ema * (double)c.adaptive_scale, sg); break;
+        case 3: nsg = ema; break;
+        default: nsg = fmin(ema, sg);
       }
+      glob[PBHC_G_SIGMA + i] = nsg;
+    }
+    return;
+  }
   double* L = glob + PBHC_G_LOG;
   const double nreset = tot[P_RESET_CNT];
-  L[PBHC_L_UPPER_BODY_DIFF_NORM] = tot[P_UPPER_NORM] / N; L[PBHC_L_LOWER_BODY_DIFF_NORM] = tot[P_LOWER_NORM] / N;
-  L[PBHC_L_VR_3POINT_DIFF_NORM] = tot[P_VR_NORM] / N; L[PBHC_L_JOINT_POS_DIFF_NORM] = tot[P_JOINT_NORM] / N;
-  L[PBHC_L_ACTION_CLIP_FRAC] = tot[P_CLIP_CNT] / (N * (double)c.skel.num_dof);
   const double rfrac = nreset / N;
-  L[PBHC_L_RESET_FRAC] = rfrac; L[PBHC_L_NUM_RESETS] = nreset;
-  L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
-  L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
-  L[PBHC_L_REW_MEAN] = tot[P_REW_SUM] / N;
-  if (c.tracking_mode) {
-    L[PBHC_L_KEY_BODY_DIFF_NORM] = tot[P_KEY_NORM] / N; L[PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM] = tot[P_LUP_NORM] / N;
-    L[PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM] = tot[P_LLO_NORM] / N; L[PBHC_L_LOCAL_VR_3POINT_DIFF_NORM] = tot[P_LVR_NORM] / N;
-    L[PBHC_L_LOCAL_KEY_BODY_DIFF_NORM] = tot[P_LKEY_NORM] / N;
-    L[PBHC_L_TERM_REF_POS_Z] = (tot[P_TERM_REFZ] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_REF_ORI] = (tot[P_TERM_REFORI] / N) / (rfrac + 1e-15);
-    L[PBHC_L_TERM_BODY_Z] = (tot[P_TERM_BODYZ] / N) / (rfrac + 1e-15);
-  }
-  if (nreset > 0.0) {
+  if (tid == 64) {
+    L[PBHC_L_UPPER_BODY_DIFF_NORM] = tot[P_UPPER_NORM] / N; L[PBHC_L_LOWER_BODY_DIFF_NORM] = tot[P_LOWER_NORM] / N;
+    L[PBHC_L_VR_3POINT_DIFF_NORM] = tot[P_VR_NORM] / N; L[PBHC_L_JOINT_POS_DIFF_NORM] = tot[P_JOINT_NORM] / N;
+    L[PBHC_L_ACTION_CLIP_FRAC] = tot[P_CLIP_CNT] / (N * (double)c.skel.num_dof);
+    L[PBHC_L_RESET_FRAC] = rfrac; L[PBHC_L_NUM_RESETS] = nreset;
+    L[PBHC_L_REW_MEAN] = tot[P_REW_SUM] / N;
+    glob[PBHC_G_STEP_COUNTER] += 1.0;
+    frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
+  } else if (tid == 128) {
+    L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
+    L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
+    if (c.tracking_mode) {
+      L[PBHC_L_TERM_REF_POS_Z] = (tot[P_TERM_REFZ] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_REF_ORI] = (tot[P_TERM_REFORI] / N) / (rfrac + 1e-15);
+      L[PBHC_L_TERM_BODY_Z] = (tot[P_TERM_BODYZ] / N) / (rfrac + 1e-15);
+    }
+  } else if (tid == 192) {
+    if (c.tracking_mode) {
+      L[PBHC_L_KEY_BODY_DIFF_NORM] = tot[P_KEY_NORM] / N; L[PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM] = tot[P_LUP_NORM] / N;
+      L[PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM] = tot[P_LLO_NORM] / N; L[PBHC_L_LOCAL_VR_3POINT_DIFF_NORM] = tot[P_LVR_NORM] / N;
+      L[PBHC_L_LOCAL_KEY_BODY_DIFF_NORM] = tot[P_LKEY_NORM] / N;
+    }
+  } else if (tid == 256 && nreset > 0.0) {
     // _update_average_episode_length (legged_robot_base.py:875-879), fp32 like the reference's 0-dim tensor
     float cur = (float)(tot[P_RESET_EPLEN] / nreset);
     double frac = nreset / (double)c.num_compute_average_epl;
@@ -1248,19 +1258,18 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
       else if (avg > c.penalty_up) p *= (1.0 + (double)c.penalty_degree);
       glob[PBHC_G_PENALTY_SCALE] = fmin(fmax(p, (double)c.penalty_min), (double)c.penalty_max);
     }
-    double mean = tot[P_ETR_SUM] / N;
-    L[PBHC_L_END_TIME_RATIO] = mean;
-    double var = (tot[P_ETR_SQ] - N * mean * mean) / (N - 1.0);
-    L[PBHC_L_END_TIME_RATIO_STD] = var > 0.0 ? sqrt(var) : 0.0;
     if (c.terminate_when_motion_far && c.motion_far_curriculum) {   // motion_tracking.py:309-317
       double t = glob[PBHC_G_MOTION_FAR_THR];
       if (avg < c.motion_far_down) t *= (1.0 + (double)c.motion_far_degree);
       else if (avg > c.motion_far_up) t *= (1.0 - (double)c.motion_far_degree);
       glob[PBHC_G_MOTION_FAR_THR] = fmin(fmax(t, (double)c.motion_far_min), (double)c.motion_far_max);
     }
+  } else if (tid == 320 && nreset > 0.0) {
+    double mean = tot[P_ETR_SUM] / N;
+    L[PBHC_L_END_TIME_RATIO] = mean;
+    double var = (tot[P_ETR_SQ] - N * mean * mean) / (N - 1.0);
+    L[PBHC_L_END_TIME_RATIO_STD] = var > 0.0 ? sqrt(var) : 0.0;
   }
-  glob[PBHC_G_STEP_COUNTER] += 1.0;
-  frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
 }
 
 // =================================================================================================

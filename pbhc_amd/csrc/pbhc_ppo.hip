@@ -273,10 +273,19 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
                                                       const double* __restrict__ part, int nparts, const float* __restrict__ lr, float* __restrict__ step,
                                                       float max_norm, float b1, float b2, float eps, float weight_decay, float* __restrict__ norm_out) {
   __shared__ float s_clip, s_bc1, s_bc2s, s_lr;
-  if (threadIdx.x == 0) {
+  __shared__ double sh[ADAM_T];
+  {                                                    // ||g||^2 from the block partials: strided loads + a fixed-order tree (deterministic)
     double t = 0.0;
-    for (int i = 0; i < nparts; ++i) t += part[i];
-    const float norm = (float)sqrt(t);
+    for (int i = threadIdx.x; i < nparts; i += ADAM_T) t += part[i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = ADAM_T / 2; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(sh[0]);
     const float c = max_norm / (norm + 1e-6f);
     s_clip = c < 1.0f ? c : 1.0f;
     const float st = step[0] + 1.0f;                 // every block reads the pre-increment value; block 0 writes it back below
