@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 2
+#define PBHC_ABI_VERSION 3
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -316,6 +316,11 @@ typedef struct PbhcStepIO {
   float* ref_body_pos_extend;     /* [N,Bx,3] may be NULL */
   float* ref_body_rot_extend;     /* [N,Bx,4] may be NULL */
   float* episode_rew_out;         /* [N,num_sum_cols] episode_sums / max_episode_length_s of envs reset this step (else unchanged), may be NULL */
+  /* Data-parallel runs: NULL -> the step finalizes its batch statistics itself.  Non-NULL -> device double[PBHC_NUM_TOTALS]: the step
+   * only writes this shard's batch sums there (and advances the RNG counter / frame cursor); the caller sums them over ranks and calls
+   * pbhc_env_finalize, so adaptive sigma, average episode length, the curricula and the logged means are those of ONE batch of
+   * all ranks' envs (the reference is single-process: motion_tracking.py:1030-1048, legged_robot_base.py:875-900). */
+  double* totals_out;
   /* row pitches in floats (0 = dense).  Rows padded to a multiple of 32 floats start on 128-B lines: no cache line is shared by two envs,
    * so no line is written twice by different workgroups. */
   int32_t obs_pitch[PBHC_MAX_GROUPS];
@@ -354,6 +359,10 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
 void pbhc_env_destroy(PbhcEnv* env);
 /* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */
 int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
+/* Second half of a step launched with io->totals_out: `totals` = the element-wise sum over ranks of every shard's totals_out,
+ * `num_envs_total` = the number of envs of all ranks.  Must run before the next pbhc_env_step of this env. */
+#define PBHC_NUM_TOTALS 64
+int pbhc_env_finalize(PbhcEnv* env, const double* totals, double num_envs_total, void* stream);
 
 /* Measurement aid: when enabled, k_env_step of each following pbhc_env_step is bracketed by a pair of HIP
  * events on the launch stream (ring of PBHC_PROFILE_RING pairs).  pbhc_env_profile_read synchronises on the

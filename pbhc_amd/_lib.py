@@ -86,7 +86,7 @@ PbhcStepIO = _S["PbhcStepIO"]
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
-           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias"]
+           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize"]
 
 
 class PbhcError(RuntimeError):
@@ -113,6 +113,7 @@ def _load():
     lib.pbhc_env_destroy.argtypes = [vp]
     lib.pbhc_env_destroy.restype = None
     lib.pbhc_env_step.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
+    lib.pbhc_env_finalize.argtypes = [vp, vp, C.c_double, vp]
     lib.pbhc_env_profile.argtypes = [vp, i]
     lib.pbhc_env_profile_read.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(C.c_int)]
     lib.pbhc_ppo_loss.argtypes = [vp] * 10 + [i, i, i, f, f, f, i, f, i] + [vp] * 6 + [vp]

@@ -103,6 +103,8 @@ class PPO:
         self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world_size > 1 else 0
+        if self.world_size > 1 and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
+            self.env.enable_global_statistics()          # sigma / episode-length curricula from the batch of all ranks' envs
         _ = self.env.reset_all()
         self.learn = self.learn_RL if not self.train_distill else self.learn_distill
 
@@ -577,7 +579,7 @@ class PPO:
         for k, v in log["loss_dict"].items():
             w.add_scalar("Loss/" + k, float(v), it)
         w.add_scalar("Loss/learning_rate", float(self._lr[0]), it)
-        w.add_scalar("Policy/mean_noise_std", float(self.alg.std.mean()), it)
+        w.add_scalar("Policy/mean_noise_std", float(self.alg.std.detach().mean()), it)
         w.add_scalar("Perf/total_fps", fps, it)
         w.add_scalar("Perf/collection_time", log["collection_time"], it)
         w.add_scalar("Perf/learning_time", log["learn_time"], it)

@@ -64,6 +64,7 @@ enum {
   P_NUM
 };
 static_assert(P_NUM <= PBHC_NP, "partials");
+static_assert(PBHC_NP == PBHC_NUM_TOTALS, "totals");
 
 // reduction slots per env (LDS)
 enum {
@@ -1174,14 +1175,17 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
 //  k_env_finalize: the scalars the reference updates on the host each step
 // =================================================================================================
 #define PBHC_FIN_CHUNKS 16
-__global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks, int32_t* frame_cursor, int num_frames) {
+__global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const PbhcEnvConfig* __restrict__ cfgp, double* __restrict__ glob, const float* __restrict__ partials, int nblocks, int32_t* frame_cursor, int num_frames,
+                                                                    const double* __restrict__ ext_tot, double* __restrict__ tot_out, double n_total) {
+  // three uses: (partials) reduce + apply [single process]; (partials, tot_out) reduce only, sums to tot_out [data-parallel, first half];
+  // (ext_tot) apply sums that the caller has added up over ranks [second half]
   __shared__ double acc[PBHC_FIN_CHUNKS][64];
   __shared__ double tot[PBHC_NP];
   const PbhcEnvConfig& c = *cfgp;
   const int k = threadIdx.x & 63, chunk = threadIdx.x >> 6;
   // column sums of the workgroup partials in a FIXED order (chunk-strided, then chunk order): deterministic
   double s = 0.0;
-  if (k < PBHC_NP) {
+  if (k < PBHC_NP && !ext_tot) {
     int b = chunk;
     for (; b + 7 * PBHC_FIN_CHUNKS < nblocks; b += 8 * PBHC_FIN_CHUNKS) {       // 8 independent loads in flight, summed in the same fixed order
       float v[8];
@@ -1197,12 +1201,21 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
   if (threadIdx.x < PBHC_NP) {
     double t = 0.0;
     for (int ch = 0; ch < PBHC_FIN_CHUNKS; ++ch) t += acc[ch][threadIdx.x];
+    if (ext_tot) t = ext_tot[threadIdx.x];
     tot[threadIdx.x] = t;
+    if (tot_out) tot_out[threadIdx.x] = t;
   }
   __syncthreads();
   // the scalar updates are independent chains of dependent global loads / double divisions: one lane (of different waves) per chain
-  const double N = (double)c.num_envs;
+  const double N = ext_tot ? n_total : (double)c.num_envs;
   const int tid = threadIdx.x;
+  if (tot_out) {                                     // reduce-only half: the per-launch counters still advance here
+    if (tid == 64) {
+      glob[PBHC_G_STEP_COUNTER] += 1.0;
+      frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
+    }
+    return;
+  }
   // adaptive sigma (motion_tracking.py:1030-1048, general_tracking.py:972-996): lane i of wave 0 owns term i
   if (tid < PBHC_NUM_SIGMA) {
     const int i = tid;
@@ -1231,8 +1244,10 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
     L[PBHC_L_ACTION_CLIP_FRAC] = tot[P_CLIP_CNT] / (N * (double)c.skel.num_dof);
     L[PBHC_L_RESET_FRAC] = rfrac; L[PBHC_L_NUM_RESETS] = nreset;
     L[PBHC_L_REW_MEAN] = tot[P_REW_SUM] / N;
-    glob[PBHC_G_STEP_COUNTER] += 1.0;
-    frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
+    if (!ext_tot) {
+      glob[PBHC_G_STEP_COUNTER] += 1.0;
+      frame_cursor[0] = (frame_cursor[0] + 1) % num_frames;
+    }
   } else if (tid == 128) {
     L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
     L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
@@ -1723,8 +1738,17 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   else
     hipLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride, e->d_skc, e->cfg.map_image);
   if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
-  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames,
+                     (const double*)nullptr, io->totals_out, 0.0);
   e->step_ctr++;
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_env_finalize(PbhcEnv* e, const double* totals, double num_envs_total, void* stream) {
+  ARG_CHECK(e && totals && num_envs_total >= 1.0);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, (hipStream_t)stream, e->d_cfg, e->d_glob, (const float*)nullptr, 0, (int32_t*)nullptr, 1,
+                     totals, (double*)nullptr, num_envs_total);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }

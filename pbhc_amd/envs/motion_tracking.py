@@ -91,6 +91,7 @@ class LeggedRobotMotionTracking:
         self._c.ref_init_yaw = self.ref_init_yaw
         self._env = C.c_void_p()
         _lib.check(self._lib.pbhc_env_create(C.byref(self._c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(self._env)), "pbhc_env_create")
+        self._totals, self._stat_pending, self._stat_group, self._num_envs_total = None, None, None, float(N)     # enable_global_statistics()
         self._init_buffers()
         self._init_obs_buffers()
         self._build_io()
@@ -168,6 +169,7 @@ class LeggedRobotMotionTracking:
         ppo_mimic's distillation adds the teacher's observation groups after the env exists, ppo_mimic.py:131-134).  State is kept;
         the set of history keys must not change."""
         old = self.layout
+        self._flush_statistics()
         c, L = env_config.build(_TopView(self.config), self.skeleton, self._motion_lib, self.num_envs, self.device, self.simulator._link_mass_scale.shape[1],
                                 seed=self._seed, mode=self.TRACKING_MODE)
         if (L.hist_keys, L.hist_len, L.hist_dim) != (old.hist_keys, old.hist_len, old.hist_dim) or L.sum_names != old.sum_names:
@@ -229,6 +231,7 @@ class LeggedRobotMotionTracking:
         io.rew_buf = p(self.rew_buf)
         io.ref_body_pos_extend, io.ref_body_rot_extend = p(self.ref_body_pos_extend), p(self.ref_body_rot_extend)
         io.episode_rew_out = p(self._episode_rew_out)
+        io.totals_out = self._totals.data_ptr() if getattr(self, "_totals", None) is not None else None
         self._io = io
         self._overrides = {}
         self._replay_version = -1
@@ -249,6 +252,33 @@ class LeggedRobotMotionTracking:
         self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay)
         for k, v in self._overrides.items():
             setattr(self._io, k, None if v is None else v.data_ptr())
+
+    # ---- data-parallel runs: batch statistics over ALL ranks' envs ---------------------------
+    def enable_global_statistics(self, group=None):
+        """One process per GPU, envs sharded over ranks: adaptive sigma, average episode length, the curricula keyed on it and the logged
+        means are batch statistics of the reference's single process (motion_tracking.py:1030-1048, legged_robot_base.py:875-900).  With this
+        on, each step writes its shard's batch sums (PBHC_NUM_TOTALS doubles), they are summed over the ranks by one tiny all-reduce that
+        overlaps the next policy forward, and `pbhc_env_finalize` applies them — right before the next step launches, which is the first
+        consumer.  Every rank then holds the same sigma / curriculum state as ONE process with all the envs would."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return False
+        self._flush_statistics()
+        self._stat_group = group
+        n = torch.tensor([float(self.num_envs)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(n, group=group)
+        self._num_envs_total = float(n)
+        self._totals = torch.zeros(K["PBHC_NUM_TOTALS"], dtype=torch.float64, device=self.device)
+        self._io.totals_out = self._totals.data_ptr()
+        return True
+
+    def _flush_statistics(self):
+        h = self._stat_pending
+        if h is not None:
+            self._stat_pending = None
+            h.wait()
+            _lib.check(self._lib.pbhc_env_finalize(self._env, self._totals.data_ptr(), self._num_envs_total, _lib.current_stream()), "pbhc_env_finalize")
 
     # ------------------------------------------------------------------------------------
     def set_is_evaluating(self):
@@ -286,8 +316,16 @@ class LeggedRobotMotionTracking:
         for t in (self.actions, self.last_actions, self.actions_after_delay, self.last_dof_pos, self.last_dof_vel, self.feet_air_time,
                   self.contacts, self.contacts_filt, self.last_contacts, self.last_contacts_filt, self._hist):
             t.zero_()
+        self._flush_statistics()
         cur = torch.mean(self.last_episode_length_buf, dtype=torch.float)
-        frac = N / self._c.num_compute_average_epl
+        n_all = N
+        if self._totals is not None:                       # every rank resets all its envs: the mean over all ranks' envs
+            import torch.distributed as dist
+
+            m = torch.stack([self.last_episode_length_buf.sum().double(), torch.tensor(float(N), dtype=torch.float64, device=dev)])
+            dist.all_reduce(m, group=self._stat_group)
+            cur, n_all = (m[0] / m[1]).float(), float(m[1])
+        frac = n_all / self._c.num_compute_average_epl
         avg = g[K["PBHC_G_AVG_EP_LEN"]].float() * (1 - frac) + cur * frac
         g[K["PBHC_G_AVG_EP_LEN"]] = avg.double()
         self._episode_length_buf.zero_()
@@ -351,7 +389,12 @@ class LeggedRobotMotionTracking:
             io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
             self._replay_version = s.replay_version
         io.frame_index = s.take_host_frame()
+        self._flush_statistics()
         _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
+        if self._totals is not None:
+            import torch.distributed as dist
+
+            self._stat_pending = dist.all_reduce(self._totals, group=self._stat_group, async_op=True)
         self.common_step_counter += 1
         # _update_tasks_callback (motion_tracking.py:320-325, general_tracking.py:216-222): periodic slot -> clip resampling + reset of every
         # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
@@ -367,6 +410,7 @@ class LeggedRobotMotionTracking:
 
     # ---- logging: device-side means, read back on demand (no per-step sync) ----------------
     def read_log(self):
+        self._flush_statistics()
         g = self.globals.cpu().numpy()
         L0 = K["PBHC_G_LOG"]
         out = {

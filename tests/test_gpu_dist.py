@@ -93,3 +93,78 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     for k, v in ref.items():
         assert torch.allclose(got[k], v, atol=2e-4, rtol=2e-4), k                   # Adam-amplified rounding, see test_mhppo_update_matches_reference
         assert float((got[k] - v).norm() / v.norm().clamp(min=1e-6)) < 1e-4, k
+
+
+# ---- env batch statistics over ranks -----------------------------------------------------------------------------------------
+def _slice_envs(d, sl, N):
+    return {k: (v[sl] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == N else v) for k, v in d.items()}
+
+
+def _env_rank_main(rank, world, port, out_path):
+    from pbhc_amd import _lib
+    from pbhc_amd.envs.env_config import SIGMA_KEYS
+    from tests.helpers import load_env_golden, load_state_into_hip_env, state_dict_from_golden
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        g = load_env_golden("horse")
+        T, N, D = g["actions_in"].shape
+        n = N // world
+        sl = slice(rank * n, (rank + 1) * n)
+        cfg, env = build_hip_env("v1_g1_23dof_horse_stance.yaml", n)
+        gs = {k: g[k][sl] for k in ("env_origins", "base_com_bias", "link_mass_scale", "friction_coeffs", "base_mass_scale") if k in g}
+        load_state_into_hip_env(env, _slice_envs(state_dict_from_golden(g), sl, N), gs)
+        assert env.enable_global_statistics() and env._num_envs_total == N
+        tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        env.simulator.set_replay(*[tg(g[k][:, sl]) for k in ("replay_root", "replay_dof_pos", "replay_dof_vel", "replay_contact")])
+        K = _lib.K
+        rows = []
+        for k in range(T):
+            st = lambda name, dt=torch.float32: tg(g["step__state__" + name][k][sl]).to(dt)
+            env.set_injected_draws(u_rfi=tg(g["step__u_rfi"][k][sl]), start_time=st("motion_start_times"), kp=st("kp_scale"), kd=st("kd_scale"),
+                                   rfi_lim=st("rfi_lim_scale"), rao=st("rao_scale"), delay=st("action_delay_idx", torch.long))
+            obs, rew, reset, extras = env.step({"actions": tg(g["actions_in"][k][sl])})
+            log = env.read_log()                       # flushes the pending all-reduce + finalize
+            gl = env.globals.cpu().numpy()
+            rows.append(dict(rew=rew.cpu().clone(), reset=reset.cpu().clone(), sigma=gl[K["PBHC_G_SIGMA"]:K["PBHC_G_SIGMA"] + len(SIGMA_KEYS)].copy(),
+                             penalty=gl[K["PBHC_G_PENALTY_SCALE"]], avg=gl[K["PBHC_G_AVG_EP_LEN"]], far=gl[K["PBHC_G_MOTION_FAR_THR"]],
+                             upper=log["upper_body_diff_norm"], grav=log["terminate_by_gravity"]))
+        torch.save(rows, out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_env_statistics_over_two_ranks_follow_the_single_process_trace(tmp_path):
+    """2 ranks x 16 envs replay the two halves of the reference's 32-env trace (tests/golden/env_v1_horse.npz) with global batch statistics
+    on: adaptive sigma, penalty / motion-far curricula, average episode length and the logged means on BOTH ranks follow the reference's
+    single-process values step by step, and so do the rewards of each half (they depend on the sigma of the previous step)."""
+    from pbhc_amd.envs.env_config import SIGMA_KEYS
+    from tests.helpers import load_env_golden
+    from tests.test_gpu_parity import close
+
+    g = load_env_golden("horse")
+    T, N, D = g["actions_in"].shape
+    world = 2
+    out = str(tmp_path / "rows.pt")
+    mp.spawn(_env_rank_main, args=(world, 29541, out), nprocs=world, join=True)
+    n = N // world
+    moved = 0
+    for rank in range(world):
+        rows = torch.load(out + f".{rank}", weights_only=False)
+        sl = slice(rank * n, (rank + 1) * n)
+        for k, r in enumerate(rows):
+            w = f"rank {rank} step {k}: "
+            assert torch.equal(r["reset"], torch.from_numpy(g["step__reset_buf_out"][k][sl])), w + "reset"
+            close(r["rew"], g["step__rew_buf"][k][sl], 3e-5, w + "rew_buf", rtol=1e-4)
+            for i, name in enumerate(SIGMA_KEYS):
+                if "step__state__sigma__" + name in g:
+                    ref = float(g["step__state__sigma__" + name][k])
+                    assert abs(r["sigma"][i] - ref) <= 2e-6 * abs(ref), w + "sigma " + name
+                    moved += int(k > 0 and ref != float(g["step__state__sigma__" + name][k - 1]))
+            assert abs(r["penalty"] - float(g["step__state__reward_penalty_scale"][k])) < 1e-9, w + "penalty scale"
+            assert abs(r["avg"] - float(g["step__state__average_episode_length"][k])) < 1e-5, w + "average episode length"
+            assert abs(r["far"] - float(g["step__state__motion_far_threshold"][k])) < 1e-9, w + "motion far threshold"
+            close(torch.tensor(r["upper"]), g["step__log__upper_body_diff_norm"][k], 1e-4, w + "log upper_body_diff_norm")
+            close(torch.tensor(r["grav"]), g["step__log__terminate_by_gravity"][k], 1e-4, w + "log terminate_by_gravity")
+    assert moved > 0            # sigma did change during the trace
