@@ -373,7 +373,8 @@ int pbhc_env_profile_read(PbhcEnv* env, float* ms_out, int max_count, int* count
 
 /* Rollout-side fusions of MHPPO._rollout_step (mh_ppo.py:270-342).
  * pbhc_policy_sample: a ~ Normal(mu, std) (Philox keyed by seed / counter[0] / env), log-prob, and the writes of one rollout-buffer
- * step: actions, action_mean, action_sigma [N,A], actions_log_prob [N], values [N,R] (copied from `value`).
+ * step: actions, action_mean, action_sigma [N,A], actions_log_prob [N], values [N,R] (copied from `value`; both may be NULL when the
+ * critic runs on another stream and stores its own output).
  * counter: device double, read (not advanced) — pass the env globals' step counter. */
 int pbhc_policy_sample(const float* mu, const float* std, const float* value, int N, int A, int R, uint64_t seed, const double* counter,
                        float* actions, float* action_mean, float* action_sigma, float* logp, float* values_out, void* stream);

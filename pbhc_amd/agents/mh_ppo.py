@@ -83,6 +83,7 @@ def policy_forward_graphs(self, eager, key=0):
         graphs[t].replay()
         return outs[t]
 
+    replay.outs = outs                         # static output tensors per step index (another graph may read them)
     return replay
 
 
@@ -353,26 +354,23 @@ class MHPPO:
         with torch.inference_mode():
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
-            def fwd_eager(t):
-                # actor and critic are independent chains of small (4096-row) GEMMs: two branches (parallel nodes once captured)
-                cur = torch.cuda.current_stream()
-                br = self._branch_stream
+            # Per control step only the actor is on the critical path (actions -> env step).  The critic of slab t — written by the env step
+            # of t-1 — runs on a branch stream next to the actor chain, the sampling kernel and the fused env step, and is joined
+            # before the bootstrap kernel that consumes its values.  Each chain is one hipGraph launch per step.
+            cur, br = torch.cuda.current_stream(), self._branch_stream
+            actor_fwd = policy_forward_graphs(self, lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t]), key="actor")
+            critic_fwd = policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
+            for t in range(T):
                 br.wait_stream(cur)
                 with torch.cuda.stream(br):
-                    value = self.critic.critic_module(getattr(st, "critic_obs")[t])
-                mu = self.actor.actor_module(getattr(st, "actor_obs")[t])
-                cur.wait_stream(br)
-                value.record_stream(cur)
-                return mu, value
-
-            fwd = policy_forward_graphs(self, fwd_eager)
-            for t in range(T):
-                mu, value = fwd(t)
-                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
+                    st.values[t].copy_(critic_fwd(t))
+                mu = actor_fwd(t)
+                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), None, N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
-                                                  st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
+                                                  st.actions_log_prob[t].data_ptr(), None, stream), "pbhc_policy_sample")
                 env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
                 nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
+                cur.wait_stream(br)
                 if self._need_next:
                     for k in keys:
                         getattr(st, "next_" + k)[t].copy_(nxt[k])

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__
   }
   lp = gsum32(lp);
   if (valid && lane == 0) logp[row] = lp;
-  if (valid && lane < R) values_out[(size_t)row * R + lane] = value[(size_t)row * R + lane];
+  if (value && valid && lane < R) values_out[(size_t)row * R + lane] = value[(size_t)row * R + lane];
 }
 
 __global__ __launch_bounds__(256) void k_rollout_post(const float* __restrict__ rew, const float* __restrict__ values, const int64_t* __restrict__ reset_buf,
@@ -373,7 +373,7 @@ extern "C" {
 
 int pbhc_policy_sample(const float* mu, const float* std, const float* value, int N, int A, int R, uint64_t seed, const double* counter,
                        float* actions, float* action_mean, float* action_sigma, float* logp, float* values_out, void* stream) {
-  ARG_CHECK(mu && std && value && counter && actions && action_mean && action_sigma && logp && values_out && N >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
+  ARG_CHECK(mu && std && (!value || values_out) && counter && actions && action_mean && action_sigma && logp && N >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
   hipLaunchKernelGGL(k_policy_sample, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, mu, std, value, N, A, R, seed, counter, actions, action_mean,
                      action_sigma, logp, values_out);
   HIP_CHECK(hipGetLastError());
