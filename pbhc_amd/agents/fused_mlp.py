@@ -30,6 +30,20 @@ def supported(module_seq):
     return not any(isinstance(a, nn.ELU) and a.alpha != 1.0 for a in acts)
 
 
+def _wgrad(d, x, out):
+    """out[n, k] = d^T[n, B] x[B, k].  With B (minibatch rows, 24 576) >> n, k the single GEMM has few output tiles and a very long K loop:
+    rocBLAS / hipBLASLt run it on part of the chip (128 x 256: 53 us = 30 TFLOP/s on MI355X).  Split over P row chunks it is a batched GEMM that
+    fills the 256 CUs, followed by a [P, n, k] sum (23 us for the same shape); measured with tools/wgrad_splitk_probe.py."""
+    n, k = out.shape
+    B = d.shape[0]
+    nk = n * k
+    P = 0 if n < 64 else 32 if nk <= 128 * 256 else 8 if nk <= 128 * 512 else 16 if nk <= 256 * 512 else 8 if nk <= 512 * 384 else 0
+    if P == 0 or B % P or B // P < 256:
+        return torch.mm(d.t(), x, out=out)
+    part = torch.bmm(d.view(P, B // P, n).transpose(1, 2), x.view(P, B // P, k))
+    return torch.sum(part, 0, out=out)
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, seq, *params):
@@ -76,10 +90,10 @@ class _FusedMLP(torch.autograd.Function):
             else:
                 _lib.check(lib.pbhc_act_bwd_bias(d.data_ptr(), None, B, n, 0, d.data_ptr(), gb.data_ptr(), scratch.data_ptr(), st), "pbhc_act_bwd_bias")
             if direct:
-                torch.mm(d.t(), ins[i], out=l.weight.grad)
+                _wgrad(d, ins[i], l.weight.grad)
                 ret_w.append((None, None))
             else:
-                ret_w.append((d.t() @ ins[i], gb))
+                ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device)), gb))
             if i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
         dx = d if ctx.needs_input_grad[0] else None
