@@ -411,6 +411,18 @@ int pbhc_ppo_loss_scratch_floats(int B);
  * output.  dy/saved/dz [B,n] row-major (dz may alias dy), grad_bias [n], scratch >= PBHC_ACT_MAX_BLOCKS * n floats. */
 #define PBHC_ACT_MAX_BLOCKS 512
 int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream);
+/* The same in two halves, so that a whole network's bias gradients are finished by ONE launch: pbhc_act_bwd_partials does the slab pass
+ * and leaves per-row-block column sums in `scratch` (returns their count in *num_row_blocks); pbhc_colsum_final sums up to
+ * PBHC_MAX_COLSUM_JOBS such scratch areas into their grad_bias vectors (fixed order, deterministic). */
+#define PBHC_MAX_COLSUM_JOBS 8
+typedef struct PbhcColsumJob {
+  const float* part;   /* [num_row_blocks, n] */
+  float* out;          /* [n] */
+  int32_t num_row_blocks;
+  int32_t n;
+} PbhcColsumJob;
+int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int act, float* dz, float* scratch, int* num_row_blocks, void* stream);
+int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
 
 /* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,
  * ppo_mimic.py:184-190,682-686) over ONE flat fp32 segment of n

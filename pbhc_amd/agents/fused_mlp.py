@@ -10,6 +10,8 @@ Same arithmetic as autograd's (the column sums are two-stage fp32 in a fixed ord
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -78,17 +80,26 @@ class _FusedMLP(torch.autograd.Function):
         ins, acts = saved[:L], saved[L:]
         d = dout.contiguous()
         B = d.shape[0]
-        scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * max(l.out_features for l in lin), device=d.device)
+        if L > _lib.K["PBHC_MAX_COLSUM_JOBS"]:
+            raise _lib.PbhcError("fused MLP backward: too many layers")
+        widths = [l.out_features for l in lin]
+        MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
+        scratch = torch.empty(MAXB * sum(widths), device=d.device)       # per-layer row-block column sums, finished by ONE launch below
+        jobs = (_lib._S["PbhcColsumJob"] * L)()
+        nb = C.c_int(0)
         ret_w = []
+        off = 0
         for i in reversed(range(L)):
             l = lin[i]
             n = l.out_features
             direct = l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
-            if i < L - 1:
-                _lib.check(lib.pbhc_act_bwd_bias(d.data_ptr(), acts[i].data_ptr(), B, n, ctx.act, d.data_ptr(), gb.data_ptr(), scratch.data_ptr(), st), "pbhc_act_bwd_bias")
-            else:
-                _lib.check(lib.pbhc_act_bwd_bias(d.data_ptr(), None, B, n, 0, d.data_ptr(), gb.data_ptr(), scratch.data_ptr(), st), "pbhc_act_bwd_bias")
+            part = scratch[off:off + MAXB * n]
+            off += MAXB * n
+            _lib.check(lib.pbhc_act_bwd_partials(d.data_ptr(), acts[i].data_ptr() if i < L - 1 else None, B, n, ctx.act if i < L - 1 else 0, d.data_ptr(),
+                                                 part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
+            j = jobs[L - 1 - i]
+            j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
             if direct:
                 _wgrad(d, ins[i], l.weight.grad)
                 ret_w.append((None, None))
@@ -96,6 +107,7 @@ class _FusedMLP(torch.autograd.Function):
                 ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device)), gb))
             if i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
+        _lib.check(lib.pbhc_colsum_final(jobs, L, st), "pbhc_colsum_final")
         dx = d if ctx.needs_input_grad[0] else None
         flat = []
         for gw, gbias in reversed(ret_w):

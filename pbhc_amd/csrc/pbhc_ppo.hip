@@ -228,9 +228,20 @@ __global__ __launch_bounds__(ACT_T) void k_act_bwd_bias(const float* __restrict_
   }
 }
 // second stage: 64 columns x 4 slices per block, fixed order
+__device__ __forceinline__ void colsum_final_block(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int block);
 __global__ __launch_bounds__(ACT_T) void k_colsum_final(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out) {
+  colsum_final_block(part, nblocks, n, out, blockIdx.x);
+}
+struct ColsumJobs { PbhcColsumJob job[PBHC_MAX_COLSUM_JOBS]; int first_block[PBHC_MAX_COLSUM_JOBS]; };
+// the second stage of several layers in one launch (the bias gradients of a whole MLP backward)
+__global__ __launch_bounds__(ACT_T) void k_colsum_final_multi(ColsumJobs J, int num_jobs) {
+  int j = 0;
+  while (j + 1 < num_jobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+  colsum_final_block(J.job[j].part, J.job[j].num_row_blocks, J.job[j].n, J.job[j].out, (int)blockIdx.x - J.first_block[j]);
+}
+__device__ __forceinline__ void colsum_final_block(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int block) {
   __shared__ double sh[4][64];
-  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + col;
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6, c = block * 64 + col;
   double s = 0.0;
   if (c < n) {
     int b = slice;
@@ -408,9 +419,7 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
   return PBHC_OK;
 }
 
-int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream) {
-  ARG_CHECK(dy && dz && grad_bias && scratch && B >= 1 && n >= 1 && act >= 0 && act <= 3 && (act == 0 || saved));
-  hipStream_t st = (hipStream_t)stream;
+static int act_bwd_launch(const float* dy, const float* saved, int B, int n, int act, float* dz, float* scratch, hipStream_t st) {
   // row blocks: enough workgroups to fill 256 CUs (x column blocks when n > 256), at least 32 rows each
   const int colblocks = (n + ACT_T - 1) / ACT_T;
   int nb = (B + 31) / 32;
@@ -419,7 +428,41 @@ int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act
   const int rpb = (B + nb - 1) / nb;
   nb = (B + rpb - 1) / rpb;
   hipLaunchKernelGGL(k_act_bwd_bias, dim3(nb, colblocks), dim3(ACT_T), 0, st, dy, saved, B, n, act, dz, scratch, rpb);
+  return nb;
+}
+
+int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream) {
+  ARG_CHECK(dy && dz && grad_bias && scratch && B >= 1 && n >= 1 && act >= 0 && act <= 3 && (act == 0 || saved));
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = act_bwd_launch(dy, saved, B, n, act, dz, scratch, st);
   hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(ACT_T), 0, st, scratch, nb, n, grad_bias);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int act, float* dz, float* scratch, int* num_row_blocks, void* stream) {
+  ARG_CHECK(dy && dz && scratch && num_row_blocks && B >= 1 && n >= 1 && act >= 0 && act <= 3 && (act == 0 || saved));
+  *num_row_blocks = act_bwd_launch(dy, saved, B, n, act, dz, scratch, (hipStream_t)stream);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream) {
+  ARG_CHECK(jobs && num_jobs >= 1 && num_jobs <= PBHC_MAX_COLSUM_JOBS);
+  ColsumJobs J;
+  int blocks = 0;
+  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) {
+    if (j < num_jobs) {
+      ARG_CHECK(jobs[j].part && jobs[j].out && jobs[j].num_row_blocks >= 1 && jobs[j].n >= 1);
+      J.job[j] = jobs[j];
+      blocks += (jobs[j].n + 63) / 64;
+    } else {
+      J.job[j] = PbhcColsumJob{nullptr, nullptr, 0, 0};
+    }
+  }
+  int acc = 0;
+  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) { J.first_block[j] = acc; acc += (J.job[j].n + 63) / 64; }
+  hipLaunchKernelGGL(k_colsum_final_multi, dim3(blocks), dim3(ACT_T), 0, (hipStream_t)stream, J, num_jobs);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
