@@ -22,8 +22,6 @@ class LeggedRobotGeneralTracking(LeggedRobotMotionTracking):
     TRACKING_MODE = 1
 
     def __init__(self, config, device):
-        if getattr(config.robot.motion, "motion_max_len", -1) != -1:
-            raise NotImplementedError("robot.motion.motion_max_len (random sub-clip trimming at load)")
         super().__init__(config, device)
         L = self.layout
         self.key_body_id = L.key
@@ -35,13 +33,13 @@ class LeggedRobotGeneralTracking(LeggedRobotMotionTracking):
         self.motion_start_idx = 0
 
     def _load_motions_initial(self):
-        self._motion_lib.load_motions(random_sample=False)                 # general_tracking.py:57-61: init not random sample
+        self._motion_lib.load_motions(random_sample=False, max_len=self.max_len)                 # general_tracking.py:57-61: init not random sample
 
     def next_task(self):
         self.motion_start_idx += self.num_envs
         if self.motion_start_idx >= self.num_motions:
             self.motion_start_idx = 0
-        self._motion_lib.load_motions(random_sample=False, start_idx=self.motion_start_idx)
+        self._motion_lib.load_motions(random_sample=False, start_idx=self.motion_start_idx, max_len=self.max_len)
         self.curr_motion_ids = self._motion_lib.slot_clip
         self.reset_all()
 

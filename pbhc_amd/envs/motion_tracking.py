@@ -68,7 +68,8 @@ class LeggedRobotMotionTracking:
         # ---- motion library (motion_tracking.py:171-199)
         self.skeleton = self.simulator.skeleton
         rc.motion.step_dt = self.dt
-        self._motion_lib = MotionLib.from_config(rc.motion, self.skeleton, N, dev)
+        self.max_len = int(getattr(rc.motion, "motion_max_len", -1)) if self.TRACKING_MODE == 1 else -1     # general_tracking.py:60
+        self._motion_lib = MotionLib.from_config(rc.motion, self.skeleton, N, dev, max_len=self.max_len)
         self._load_motions_initial()
         for e in rc.motion.get("extend_config", []):
             self.simulator._body_list.append(e["joint_name"])           # motion_tracking.py:226
@@ -215,7 +216,7 @@ class LeggedRobotMotionTracking:
         io.episode_sums, io.hist = p(self._episode_sums), p(self._hist)
         io.episode_length_buf, io.last_episode_length_buf = p(self._episode_length_buf), p(self.last_episode_length_buf)
         io.reset_buf, io.action_delay_idx = p(self.reset_buf), p(self.action_delay_idx)
-        self._slot_clip = self._motion_lib.slot_clip.contiguous()
+        self._slot_clip = self._motion_lib.slot_table.contiguous()
         io.motion_ids = p(self._slot_clip)
         io.time_out_buf = p(self.time_out_buf)
         io.env_origins = p(self.env_origins)
@@ -296,7 +297,7 @@ class LeggedRobotMotionTracking:
 
     def resample_motion(self):
         """motion_tracking.py:385-389 / general_tracking.py:291-297"""
-        self._motion_lib.load_motions(random_sample=True)
+        self._motion_lib.load_motions(random_sample=True, max_len=self.max_len)
         self.curr_motion_ids = self._motion_lib.slot_clip
         self._reset_all_state()
 

@@ -55,8 +55,10 @@ def save_motion_npz(path, clips):
 
 
 class MotionLib:
-    def __init__(self, skeleton, clips, num_envs, device):
-        """clips: list of clip dicts (see load_motion_file)."""
+    def __init__(self, skeleton, clips, num_envs, device, max_len=-1):
+        """clips: list of clip dicts (see load_motion_file).  max_len > 0: `load_motions` gives every env slot its own random crop of at most
+        `max_len` frames of its clip (motion_lib_base.py:420-428) — the tables are then per SLOT (num_envs entries of max_len rows, allocated
+        once so that the step kernel's pointers stay valid) instead of per unique clip."""
         self.skeleton = skeleton
         self.device = torch.device(device)
         self.num_envs = num_envs
@@ -65,6 +67,21 @@ class MotionLib:
         self.row = 2 * D + 2 + 13 * Bx
         self.has_contact_mask = all("contact_mask" in c for c in clips)
         self._contact_size = 2
+        self.max_len = int(max_len)
+        self._num_unique_motions = len(clips)
+        # sampling hooks of the reference (setup_constants, motion_lib_base.py:109-118): per-unique-clip tensors a curriculum may write
+        self._sampling_prob = torch.ones(len(clips), device=self.device) / len(clips)
+        self._termination_history = torch.zeros(len(clips), device=self.device)
+        self._success_rate = torch.zeros(len(clips), device=self.device)
+        self._sampling_history = torch.zeros(len(clips), device=self.device)
+        self.slot_clip = torch.zeros(num_envs, dtype=torch.long, device=self.device)
+        self.table = _lib.PbhcMotionTable()
+        if self.max_len > 0 and any(np.asarray(c["pose_aa"]).shape[0] >= self.max_len for c in clips):
+            self._init_slot_tables(clips)
+            return
+        self.max_len = -1
+        self._raw = None
+        self.slot_table = self.slot_clip                 # the kernel's motion ids: unique-clip tables, slot -> clip
         rows, starts, nframes, dts, lens = [], [], [], [], []
         s = 0
         st = _lib.current_stream()
@@ -93,42 +110,88 @@ class MotionLib:
         self.num_frames = torch.tensor(nframes, dtype=torch.int32, device=self.device)
         self._motion_dt = torch.tensor(dts, dtype=torch.float32, device=self.device)
         self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=self.device)
-        self._num_unique_motions = len(clips)
-        # sampling hooks of the reference (setup_constants, motion_lib_base.py:109-118): per-unique-clip tensors a curriculum may write
-        self._sampling_prob = torch.ones(len(clips), device=self.device) / len(clips)
-        self._termination_history = torch.zeros(len(clips), device=self.device)
-        self._success_rate = torch.zeros(len(clips), device=self.device)
-        self._sampling_history = torch.zeros(len(clips), device=self.device)
-        self.slot_clip = torch.zeros(num_envs, dtype=torch.long, device=self.device)
-        self.table = _lib.PbhcMotionTable()
+        self._fill_table(len(clips), int(nframes[0]), dts[0], lens[0])
+
+    def _fill_table(self, num_entries, f0, dt0, len0):
         self.table.frames = self.frames.data_ptr()
         self.table.row = self.row
-        self.table.num_motions = len(clips)
+        self.table.num_motions = num_entries
         self.table.length_starts = self.length_starts.data_ptr()
         self.table.num_frames = self.num_frames.data_ptr()
         self.table.motion_dt = self._motion_dt.data_ptr()
         self.table.motion_len = self._motion_lengths.data_ptr()
-        self.table.single_num_frames = int(nframes[0])
-        self.table.single_dt = float(torch.tensor(dts[0], dtype=torch.float32))
-        self.table.single_len = float(torch.tensor(lens[0], dtype=torch.float32))
+        self.table.single_num_frames = int(f0)
+        self.table.single_dt = float(torch.tensor(dt0, dtype=torch.float32))
+        self.table.single_len = float(torch.tensor(len0, dtype=torch.float32))
+
+    # ---- per-slot crops (max_len) -----------------------------------------------------------
+    def _init_slot_tables(self, clips):
+        N, K, dev = self.num_envs, self.max_len, self.device
+        Bx = self.skeleton.num_bodies_ext
+        self._raw = []
+        for c in clips:
+            pose = torch.as_tensor(np.asarray(c["pose_aa"], dtype=np.float32)[:, :Bx]).contiguous().to(dev)
+            if pose.shape[1] != Bx:
+                raise _lib.PbhcError(f"pose_aa has {pose.shape[1]} bodies, skeleton needs {Bx}")
+            trans = torch.as_tensor(np.asarray(c["root_trans_offset"], dtype=np.float32)).contiguous().to(dev)
+            contact = torch.as_tensor(np.asarray(c["contact_mask"], dtype=np.float32)).contiguous().to(dev) if self.has_contact_mask else None
+            self._raw.append((pose, trans, contact, int(c["fps"])))
+        self.frames = torch.zeros(N * K, self.row, device=dev)
+        self.length_starts = (torch.arange(N, dtype=torch.int32, device=dev) * K).contiguous()
+        self.num_frames = torch.ones(N, dtype=torch.int32, device=dev)
+        self._motion_dt = torch.ones(N, dtype=torch.float32, device=dev)
+        self._motion_lengths = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.slot_table = torch.arange(N, dtype=torch.long, device=dev)          # slot i reads table entry i
+        self._scratch = torch.empty(K * Bx * 14, device=dev)
+        self.crop_starts = torch.zeros(N, dtype=torch.long)
+        self._fill_table(max(N, 2), 1, 1.0, 0.0)          # >= 2: the kernel reads the per-entry arrays, never the by-value single-clip meta
+
+    def _build_slot_crops(self, crop_starts=None):
+        """FK + filtered velocities of every slot's crop, written in place (the reference crops BEFORE FK, so the velocity filter sees the
+        crop's own edges, motion_lib_base.py:420-434)."""
+        import random
+
+        N, K = self.num_envs, self.max_len
+        clip_of = self.slot_clip.tolist()
+        nf, dts, lens = [], [], []
+        st = _lib.current_stream()
+        for i in range(N):
+            pose, trans, contact, fps = self._raw[clip_of[i]]
+            F = pose.shape[0]
+            if F < K:
+                a, b = 0, F
+            else:
+                a = int(crop_starts[i]) if crop_starts is not None else random.randint(0, F - K)
+                b = a + K
+            self.crop_starts[i] = a
+            n = b - a
+            _lib.check(_lib.lib().pbhc_motion_build(C.byref(self._csk), _lib.ptr(pose[a:b]), _lib.ptr(trans[a:b]), _lib.ptr(contact[a:b]) if contact is not None else None,
+                                                    n, 1.0 / fps, _lib.ptr(self.frames[i * K:i * K + n]), _lib.ptr(self._scratch), st), "pbhc_motion_build")
+            nf.append(n); dts.append(1.0 / fps); lens.append(1.0 / fps * (n - 1))
+        self.num_frames.copy_(torch.tensor(nf, dtype=torch.int32))
+        self._motion_dt.copy_(torch.tensor(dts, dtype=torch.float32))
+        self._motion_lengths.copy_(torch.tensor(lens, dtype=torch.float32))
 
     @classmethod
-    def from_config(cls, mcfg, skeleton, num_envs, device):
-        """mcfg = config.robot.motion (motion_file = .pkl / .npz / directory)."""
+    def from_config(cls, mcfg, skeleton, num_envs, device, max_len=-1):
+        """mcfg = config.robot.motion (motion_file = .pkl / .npz / directory); max_len: see __init__."""
         path = str(mcfg.motion_file)
         if not os.path.isabs(path) and not os.path.exists(path):
             path = os.path.join(_lib.ROOT, path)
         clips = [c for _, c in load_motion_file(path)]
         if mcfg.get("motion_lib_type", "origin") == "WJX" and len(clips) != 1:
             raise _lib.PbhcError("Not Allowed to load more than one motion!")     # motion_lib_robot_WJX.py:202
-        return cls(skeleton, clips, num_envs, device)
+        return cls(skeleton, clips, num_envs, device, max_len=max_len)
 
     # ---- slot -> clip assignment (load_motions, motion_lib_base.py:293-305) -----------------
-    def load_motions(self, random_sample=True, start_idx=0, max_len=-1, target_heading=None, sampling_prob=None):
-        """Slot -> clip assignment only: the per-clip FK tables were built once at construction (the reference re-runs FK for every
-        slot here).  `max_len` random crops and `target_heading` re-basing would need per-slot tables and are not supported."""
-        if max_len != -1 or target_heading is not None:
-            raise NotImplementedError("load_motions(max_len / target_heading)")
+    def load_motions(self, random_sample=True, start_idx=0, max_len=-1, target_heading=None, sampling_prob=None, crop_starts=None):
+        """Slot -> clip assignment; the per-clip FK tables were built once at construction (the reference re-runs FK for every slot here).
+        With a library built for `max_len` crops, every slot's crop is re-drawn and its table rebuilt (crop_starts: fixed starts, tests).
+        `target_heading` re-basing is not supported."""
+        if target_heading is not None:
+            raise NotImplementedError("load_motions(target_heading)")
+        if max_len != -1 and max_len != self.max_len and (self.max_len != -1 or any(int(f) >= max_len for f in self.num_frames.tolist())):
+            raise _lib.PbhcError(f"load_motions(max_len={max_len}): the library was built with max_len={self.max_len} (pass robot.motion.motion_max_len at construction)")
         # in place: the step kernel holds the pointer of this tensor
         if random_sample:
             prob = self._sampling_prob if sampling_prob is None else sampling_prob
@@ -136,12 +199,14 @@ class MotionLib:
         else:
             self.slot_clip.copy_(torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions))
         self._curr_motion_ids = self.slot_clip
+        if self.max_len > 0:
+            self._build_slot_crops(crop_starts)
         return self.slot_clip
 
     def get_motion_length(self, slot_ids=None):
         if slot_ids is None:
-            return self._motion_lengths[self.slot_clip]
-        return self._motion_lengths[self.slot_clip[slot_ids]]
+            return self._motion_lengths[self.slot_table]
+        return self._motion_lengths[self.slot_table[slot_ids]]
 
     def sample_time(self, slot_ids):
         # motion_lib_base.py:486-495
@@ -152,7 +217,7 @@ class MotionLib:
         """motion_lib_base.py:123-259; returns the reference's dict keys (views of one packed buffer)."""
         n = slot_ids.shape[0]
         D, Bx, B = self.skeleton.num_dof, self.skeleton.num_bodies_ext, self.skeleton.num_bodies
-        ids = self.slot_clip[slot_ids].contiguous()
+        ids = self.slot_table[slot_ids].contiguous()
         times = motion_times.to(torch.float32).contiguous()
         off = None if offset is None else offset.to(torch.float32).contiguous()
         out = torch.empty(n, self.row, device=self.device)

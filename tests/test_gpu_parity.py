@@ -487,3 +487,60 @@ def test_adam_clip_matches_torch_adam_and_adamw():
             assert abs(float(norm) - float(tn)) < 1e-4 * float(tn)
             close(p, ref.detach(), 2e-6, f"{opt_cls.__name__} step {it}", rtol=2e-6)
         assert float(step) == 5.0
+
+
+def test_motion_lib_max_len_crops_match_oracle_on_the_cropped_clips():
+    """load_motions(max_len) (motion_lib_base.py:420-434): every env slot plays its own random crop of at most max_len frames, FK and the
+    velocity filter run on the crop.  The HIP library's per-slot tables against the oracle library built from the same crops."""
+    from oracle.motion_lib import MotionLib as OML
+    from pbhc_amd.motion_lib import MotionLib
+    from pbhc_amd.skeleton import Skeleton
+
+    walk, horse = clip_from_env_golden(load_env_golden("walk")), clip_from_env_golden(load_env_golden("horse"))
+    horse = {k: v for k, v in horse.items() if k != "contact_mask"}
+    short = dict(pose_aa=walk["pose_aa"][:30], root_trans_offset=walk["root_trans_offset"][:30], fps=walk["fps"])        # shorter than max_len: kept whole
+    clips = [walk, horse, short]
+    N, K = 9, 48
+    sk = Skeleton.from_json(os.path.join(GOLDEN, "skeleton_g1_23dof_lock_wrist_fitmotionONLY.json"))
+    ml = MotionLib(sk, clips, N, DEV, max_len=K)
+    starts = torch.tensor([0, 5, 0, 74, 162, 0, 33, 100, 0])
+    ml.load_motions(random_sample=False, max_len=K, crop_starts=starts)
+    assert ml.slot_clip.tolist() == [i % 3 for i in range(N)] and ml.slot_table.tolist() == list(range(N))
+    crops = []
+    for i in range(N):
+        c = clips[i % 3]
+        F = c["pose_aa"].shape[0]
+        a, b = (0, F) if F < K else (int(starts[i]), int(starts[i]) + K)
+        crops.append(dict(pose_aa=c["pose_aa"][a:b], root_trans_offset=c["root_trans_offset"][a:b], fps=c["fps"]))
+    assert ml.num_frames.tolist() == [c["pose_aa"].shape[0] for c in crops] == [48, 48, 30] * 3
+    oml = OML(skel_from_golden(), crops)
+    assert torch.allclose(ml.get_motion_length().cpu(), oml.motion_len, atol=1e-6)
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.arange(N).repeat(8)
+    times = torch.rand(ids.shape[0], generator=gen) * oml.motion_len[ids] * 1.1 - 0.05          # incl. t < 0 and t > len
+    off = torch.randn(ids.shape[0], 3, generator=gen)
+    res = ml.get_motion_state(ids.to(DEV), times.to(DEV), off.to(DEV))
+    ref = oml.get_motion_state(ids, times, off)
+    for k in ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos_t", "rg_rot_t", "body_vel_t", "body_ang_vel_t"]:
+        extra = ANGVEL if "ang_vel" in k else (SLERP if "rot" in k else {})
+        close(res[k], ref[k], 5e-5, f"crop:{k}", **extra)
+    # a second load re-draws the crops in place (same device buffers: the step kernel keeps its pointers)
+    ptr = ml.frames.data_ptr()
+    ml.load_motions(random_sample=True, max_len=K)
+    assert ml.frames.data_ptr() == ptr and ml.table.frames == ptr and all(0 <= int(a) <= 210 - K for a in ml.crop_starts)
+
+
+def test_general_tracking_env_with_motion_max_len_runs_and_resamples():
+    cfg, env = build_hip_env("v2_g1_23dof_student.yaml", 64, general=True, overrides={"robot.motion.motion_max_len": 40})
+    assert env.max_len == 40 and env._motion_lib.max_len == 40
+    obs = env.reset_all()
+    assert torch.allclose(env.motion_len, torch.full_like(env.motion_len, 39 / 30.0), atol=1e-6)
+    first = env._motion_lib.crop_starts.clone()
+    for _ in range(45):                                  # past the end of the 40-frame crops: motion-end resets
+        obs, rew, reset, extras = env.step({"actions": torch.zeros(64, env.num_dof, device=DEV)})
+    assert all(torch.isfinite(v).all() for v in obs.values()) and torch.isfinite(rew).all()
+    assert float(env.read_log()["terminate_by_motion_end"]) >= 0.0
+    env.resample_motion()
+    assert not torch.equal(env._motion_lib.crop_starts, first)
+    obs, rew, reset, extras = env.step({"actions": torch.zeros(64, env.num_dof, device=DEV)})
+    assert all(torch.isfinite(v).all() for v in obs.values())
