@@ -2,9 +2,9 @@
 ActorCritic, with the reference's `state_dict()` key names so checkpoints load both ways with `strict=True`
 (reference: humanoidverse/agents/modules/agent_modules.py:11-166, encoder_modules.py:22-107, modules.py:5-66).
 
-The two Conv1d layers of an encoder see 20 (or 10) time steps and leave 3: each is evaluated as ONE GEMM over the unfolded
-windows (`[B*L, C_in*k] x [C_in*k, C_out]`, rocBLAS/hipBLASLt) in the `[B, T, C]` layout the per-step Linear already produces,
-instead of a per-row MIOpen convolution; the parameters keep nn.Conv1d's shapes and names.
+The two Conv1d layers of an encoder see 20 (or 10) time steps and leave 3: each output position is a strided GEMM on a window VIEW
+of the `[B, T, C]` activations the per-step Linear already produces (`_WindowConv1d`: no unfolded copy, no MIOpen convolution);
+the parameters keep nn.Conv1d's shapes and names.
 """
 from __future__ import annotations
 
@@ -42,6 +42,54 @@ def _linear(x, lin):
     if x.requires_grad or lin.weight.requires_grad:
         return _TallSkinnyLinear.apply(x.contiguous(), lin.weight, lin.bias)
     return F.linear(x, lin.weight, lin.bias)
+
+
+class _WindowConv1d(torch.autograd.Function):
+    """nn.Conv1d(C -> O, kernel k, stride s, no padding) on x [B, T, C] (time-major rows, the layout the per-step Linear produces) -> [B, L, O].
+
+    Output position l reads the k consecutive time steps l*s .. l*s+k-1, which are ONE contiguous run of k*C floats per row of x: the
+    window matrix A_l = x[:, l*s : l*s+k, :] is a [B, k*C] view with row stride T*C, so each output position is a plain strided GEMM
+    with the weight reordered to (k, C) — no unfolded copy of the activations (283 MB per conv layer and minibatch at 24 576 rows), no
+    `unfold_backward` scatter: the input gradient accumulates through L overlapping strided GEMM outputs (beta = 1), the weight gradient
+    through L split-K batched GEMMs (see _TallSkinnyLinear)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, s):
+        B, T, Cin = x.shape
+        O = w.shape[0]
+        L = (T - k) // s + 1
+        wp = w.permute(0, 2, 1).reshape(O, k * Cin)                    # [O, (k, C)]
+        out = torch.empty(B, L, O, device=x.device, dtype=x.dtype)
+        for l in range(L):
+            torch.addmm(b, x[:, l * s:l * s + k, :].reshape(B, k * Cin), wp.t(), out=out[:, l, :])
+        ctx.save_for_backward(x, w)
+        ctx.k, ctx.s = k, s
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, s = ctx.k, ctx.s
+        B, T, Cin = x.shape
+        O = w.shape[0]
+        L = dy.shape[1]
+        dy = dy.contiguous()
+        wp = w.permute(0, 2, 1).reshape(O, k * Cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            for l in range(L):                                           # overlapping windows: sequential accumulation
+                dx[:, l * s:l * s + k, :].reshape(B, k * Cin).addmm_(dy[:, l, :], wp)
+        P = 1
+        while P < 64 and B % (2 * P) == 0 and B // (2 * P) >= 256:
+            P *= 2
+        part = None
+        for l in range(L):
+            a = x[:, l * s:l * s + k, :].reshape(B, k * Cin).view(P, B // P, k * Cin)
+            g = dy[:, l, :].view(P, B // P, O).transpose(1, 2)
+            part = torch.bmm(g, a) if part is None else torch.baddbmm(part, g, a, out=part)
+        dw = part.sum(0).view(O, k, Cin).permute(0, 2, 1)
+        return dx, dw, dy.sum((0, 1)), None, None
 
 
 _CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
@@ -91,10 +139,12 @@ class ConvEncoder(nn.Module):
         for i, s in enumerate(self._strides):
             conv = self.conv_module[2 * i]
             k = conv.kernel_size[0]
-            w = x.unfold(1, k, s)                                          # [B, L, C, k]
-            L = w.shape[1]
-            x = self._act(_TallSkinnyLinear.apply(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)
-                          if torch.is_grad_enabled() else F.linear(w.reshape(B * L, -1), conv.weight.view(conv.out_channels, -1), conv.bias)).view(B, L, conv.out_channels)
+            if torch.is_grad_enabled():
+                x = self._act(_WindowConv1d.apply(x.contiguous(), conv.weight, conv.bias, k, s))       # [B, L, O]
+            else:
+                # rollout (4096 rows, inside a captured graph): one GEMM over the unfolded copy beats L small ones
+                w = x.unfold(1, k, s)                                      # [B, L, C, k]
+                x = self._act(F.linear(w.reshape(B * w.shape[1], -1), conv.weight.view(conv.out_channels, -1), conv.bias)).view(B, w.shape[1], conv.out_channels)
         return self.output_layer(x.transpose(1, 2).reshape(B, -1))       # flatten(start_dim=1) of [B, C, 3]
 
 
