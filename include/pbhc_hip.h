@@ -430,6 +430,10 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
  * scratch: 512 doubles.  norm_out (may be NULL): the pre-clip gradient norm. */
 int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
+/* Two consecutive segments (actor [0,n0), critic [n0,n0+n1): MHPPO's two clip_grad_norm_ + two Adam steps, mh_ppo.py:519-524) in ONE launch
+ * pair: lr, step, norm_out are 2-element device arrays, scratch 2 x 512 doubles; each segment is clipped by its own norm. */
+int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n0, int n1, const float* lr, float* step, float max_norm, float beta1,
+                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -455,11 +455,10 @@ class MHPPO:
             self._gflat.div_(self.world_size)
         else:
             torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
-        for k, (o, n) in enumerate(((0, na), (na, nc))):
-            _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
-                                          self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
-                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, 0.0, self._adam_scratch[k].data_ptr(),
-                                          self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
+        # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm)
+        _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
+                                       self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
+                                       self.adam_eps, 0.0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
         loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         return loss
 
@@ -506,11 +505,10 @@ class MHPPO:
             self._allreduce_grads()
         lib, st = _lib.lib(), _lib.current_stream()
         na, nc = self._n_actor, self._n_critic
-        for k, (o, n) in enumerate(((0, na), (na, nc))):
-            _lib.check(lib.pbhc_adam_clip(self._pflat[o:o + n].data_ptr(), self._gflat[o:o + n].data_ptr(), self._mflat[o:o + n].data_ptr(),
-                                          self._vflat[o:o + n].data_ptr(), n, self._lr[k:k + 1].data_ptr(), self._adam_step[k:k + 1].data_ptr(),
-                                          float(self.max_grad_norm), self.betas[0], self.betas[1], self.adam_eps, 0.0, self._adam_scratch[k].data_ptr(),
-                                          self._grad_norms[k:k + 1].data_ptr(), st), "pbhc_adam_clip")
+        # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm)
+        _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
+                                       self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
+                                       self.adam_eps, 0.0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
         with torch.no_grad():
             loss["Value"] += value_loss.detach(); loss["Surrogate"] += surrogate.detach(); loss["Entropy"] += entropy_loss.detach()
             loss["L2C2_Value"] += l2c2_v.detach(); loss["L2C2_Policy"] += l2c2_p.detach()

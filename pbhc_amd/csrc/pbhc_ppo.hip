@@ -261,10 +261,25 @@ __device__ __forceinline__ void colsum_final_block(const float* __restrict__ par
 
 // ---- global-norm clipping + Adam over a flat parameter segment ---------------------------------
 #define ADAM_T 256
-__global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(const float* __restrict__ g, int n, double* __restrict__ part) {
+// One or two flat segments (actor, critic) per launch pair.  Segment s: blocks [first_block[s], first_block[s+1]).
+#define ADAM_MAX_SEGS 2
+struct AdamSegs {
+  float *p[ADAM_MAX_SEGS], *g[ADAM_MAX_SEGS], *m[ADAM_MAX_SEGS], *v[ADAM_MAX_SEGS];
+  const float* lr[ADAM_MAX_SEGS];
+  float* step[ADAM_MAX_SEGS];
+  double* part[ADAM_MAX_SEGS];
+  float* norm_out[ADAM_MAX_SEGS];
+  int n[ADAM_MAX_SEGS], nparts[ADAM_MAX_SEGS], first_norm_block[ADAM_MAX_SEGS + 1], first_adam_block[ADAM_MAX_SEGS + 1];
+  int num;
+};
+__global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(AdamSegs S) {
   __shared__ double sh[ADAM_T];
+  const int seg = (S.num > 1 && (int)blockIdx.x >= S.first_norm_block[1]) ? 1 : 0;
+  const int b = blockIdx.x - S.first_norm_block[seg], nb = S.first_norm_block[seg + 1] - S.first_norm_block[seg];
+  const float* __restrict__ g = S.g[seg];
+  const size_t n = (size_t)S.n[seg];
   double s = 0.0;
-  for (size_t i = (size_t)blockIdx.x * ADAM_T + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * ADAM_T) {
+  for (size_t i = (size_t)b * ADAM_T + threadIdx.x; i < n; i += (size_t)nb * ADAM_T) {
     const float v = g[i];
     s += (double)v * (double)v;
   }
@@ -274,20 +289,24 @@ __global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(const float* __restri
     if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) {
+    S.part[seg][b] = sh[0];
+    if (b == 0) S.step[seg][0] += 1.0f;               // Adam's step count: advanced here, read (post-increment) by every block of k_adam_clip
+  }
 }
 
 // torch.optim.Adam (no amsgrad, no weight decay), after nn.utils.clip_grad_norm_(max_norm):
 //   clip = min(1, max_norm / (||g|| + 1e-6));  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                                                      const double* __restrict__ part, int nparts, const float* __restrict__ lr, float* __restrict__ step,
-                                                      float max_norm, float b1, float b2, float eps, float weight_decay, float* __restrict__ norm_out) {
+__global__ __launch_bounds__(ADAM_T) void k_adam_clip(AdamSegs S, float max_norm, float b1, float b2, float eps, float weight_decay) {
   __shared__ float s_clip, s_bc1, s_bc2s, s_lr;
   __shared__ double sh[ADAM_T];
+  const int seg = (S.num > 1 && (int)blockIdx.x >= S.first_adam_block[1]) ? 1 : 0;
+  const int b = blockIdx.x - S.first_adam_block[seg], nb = S.first_adam_block[seg + 1] - S.first_adam_block[seg];
   {                                                    // ||g||^2 from the block partials: strided loads + a fixed-order tree (deterministic)
+    const double* __restrict__ part = S.part[seg];
     double t = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += ADAM_T) t += part[i];
+    for (int i = threadIdx.x; i < S.nparts[seg]; i += ADAM_T) t += part[i];
     sh[threadIdx.x] = t;
     __syncthreads();
     for (int st = ADAM_T / 2; st > 0; st >>= 1) {
@@ -299,16 +318,21 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
     const float norm = (float)sqrt(sh[0]);
     const float c = max_norm / (norm + 1e-6f);
     s_clip = c < 1.0f ? c : 1.0f;
-    const float st = step[0] + 1.0f;                 // every block reads the pre-increment value; block 0 writes it back below
+    const float st = S.step[seg][0];                  // already advanced by k_sqnorm_partial
     s_bc1 = 1.0f - powf(b1, st);
     s_bc2s = sqrtf(1.0f - powf(b2, st));
-    s_lr = lr[0];
-    if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+    s_lr = S.lr[seg][0];
+    if (b == 0 && S.norm_out[seg]) S.norm_out[seg][0] = norm;
   }
   __syncthreads();
+  float* __restrict__ p = S.p[seg];
+  float* __restrict__ g = S.g[seg];
+  float* __restrict__ m = S.m[seg];
+  float* __restrict__ v = S.v[seg];
+  const size_t n = (size_t)S.n[seg];
   const float clipc = s_clip, step_size = s_lr / s_bc1, bc2s = s_bc2s;
   const float decay = 1.0f - s_lr * weight_decay;              // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
-  for (size_t i = (size_t)blockIdx.x * ADAM_T + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * ADAM_T) {
+  for (size_t i = (size_t)b * ADAM_T + threadIdx.x; i < n; i += (size_t)nb * ADAM_T) {
     const float gi = g[i] * clipc;
     g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
     const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
@@ -318,7 +342,6 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(float* __restrict__ p, flo
     p[i] = p[i] * decay - step_size * (mi / denom);
   }
 }
-__global__ void k_step_inc(float* step) { step[0] += 1.0f; }
 
 // ---- rollout-side fusions (mh_ppo.py:270-342) ------------------------------------------------------
 #include "pbhc_math.h"
@@ -469,17 +492,41 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream) {
 
 int pbhc_ppo_loss_scratch_floats(int B) { return ((B + LOSS_ROWS - 1) / LOSS_ROWS) * (LOSS_NP + 32); }
 
+static void adam_fill(AdamSegs& S, int k, float* param, float* grad, float* m, float* v, int n, const float* lr, float* step, double* scratch, float* norm_out) {
+  S.p[k] = param; S.g[k] = grad; S.m[k] = m; S.v[k] = v; S.n[k] = n; S.lr[k] = lr; S.step[k] = step; S.part[k] = scratch; S.norm_out[k] = norm_out;
+  int nb = (n + ADAM_T * 8 - 1) / (ADAM_T * 8);
+  if (nb > 512) nb = 512;
+  int nb2 = (n + ADAM_T * 4 - 1) / (ADAM_T * 4);
+  if (nb2 > 1024) nb2 = 1024;
+  S.nparts[k] = nb;
+  S.first_norm_block[k + 1] = S.first_norm_block[k] + nb;
+  S.first_adam_block[k + 1] = S.first_adam_block[k] + nb2;
+}
+
 int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream) {
   ARG_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step && scratch && n >= 1);
   hipStream_t st = (hipStream_t)stream;
-  int nb = (n + ADAM_T * 8 - 1) / (ADAM_T * 8);
-  if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(k_sqnorm_partial, dim3(nb), dim3(ADAM_T), 0, st, grad, n, scratch);
-  int nb2 = (n + ADAM_T * 4 - 1) / (ADAM_T * 4);
-  if (nb2 > 1024) nb2 = 1024;
-  hipLaunchKernelGGL(k_adam_clip, dim3(nb2), dim3(ADAM_T), 0, st, param, grad, exp_avg, exp_avg_sq, n, scratch, nb, lr, step, max_norm, beta1, beta2, eps, weight_decay, norm_out);
-  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step);
+  AdamSegs S = {};
+  S.num = 1;
+  adam_fill(S, 0, param, grad, exp_avg, exp_avg_sq, n, lr, step, scratch, norm_out);
+  S.first_norm_block[2] = S.first_norm_block[1]; S.first_adam_block[2] = S.first_adam_block[1];
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(S.first_norm_block[1]), dim3(ADAM_T), 0, st, S);
+  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[1]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n0, int n1, const float* lr, float* step, float max_norm, float beta1,
+                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream) {
+  ARG_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step && scratch && n0 >= 1 && n1 >= 1);
+  hipStream_t st = (hipStream_t)stream;
+  AdamSegs S = {};
+  S.num = 2;
+  adam_fill(S, 0, param, grad, exp_avg, exp_avg_sq, n0, lr, step, scratch, norm_out);
+  adam_fill(S, 1, param + n0, grad + n0, exp_avg + n0, exp_avg_sq + n0, n1, lr + 1, step + 1, scratch + 512, norm_out ? norm_out + 1 : nullptr);
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(S.first_norm_block[2]), dim3(ADAM_T), 0, st, S);
+  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[2]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
