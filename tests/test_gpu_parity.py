@@ -344,6 +344,11 @@ def test_learn_runs_two_iterations():
         assert torch.isfinite(p).all()
     log = env.read_log()
     assert np.isfinite(log["reward_mean"])
+    # evaluate_policy_steps (mh_ppo.py:702-775): eval mode, every env restarts its clip at t = 0, deterministic actions
+    obs = algo.evaluate_policy_steps(3)
+    torch.cuda.synchronize()
+    assert env.is_evaluating and torch.isfinite(obs["actor_obs"]).all()
+    assert int(env.episode_length_buf.max()) <= 4
 
 
 def test_policy_sample_and_rollout_post():

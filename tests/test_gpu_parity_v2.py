@@ -146,6 +146,9 @@ def test_ppo_mimic_learn_runs_two_iterations():
         assert torch.isfinite(p).all()
     log = env.read_log()
     assert np.isfinite(log["reward_mean"])
+    obs = algo.evaluate_policy_steps(3)              # ppo_mimic.py:880-975: history-encoder inference path
+    torch.cuda.synchronize()
+    assert env.is_evaluating and all(torch.isfinite(v).all() for v in obs.values())
 
 
 def test_general_tracking_multi_clip_matches_oracle():
