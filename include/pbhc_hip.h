@@ -364,8 +364,8 @@ int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
 #define PBHC_NUM_TOTALS 64
 int pbhc_env_finalize(PbhcEnv* env, const double* totals, double num_envs_total, void* stream);
 
-/* Measurement aid: when enabled, k_env_step of each following pbhc_env_step is bracketed by a pair of HIP
- * events on the launch stream (ring of PBHC_PROFILE_RING pairs).  pbhc_env_profile_read synchronises on the
+/* Measurement aid: when enabled, k_env_step of each following pbhc_env_step carries a pair of HIP
+ * events attached to its dispatch (kernel begin / end) on the launch stream (ring of PBHC_PROFILE_RING pairs).  pbhc_env_profile_read synchronises on the
  * recorded events and returns the most recent durations in milliseconds (oldest first). */
 #define PBHC_PROFILE_RING 512
 int pbhc_env_profile(PbhcEnv* env, int enable);

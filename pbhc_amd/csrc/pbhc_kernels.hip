@@ -7,6 +7,7 @@
 // the joint chain, the reference frames and the feature row are staged in LDS.
 // This is HBM-bound float work: no MFMA on purpose.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
@@ -1732,12 +1733,16 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(io->hist_pitch == 0 || io->hist_pitch >= e->cfg.hist_dim);
   hipStream_t st = (hipStream_t)stream;
   const int slot = e->prof_count % PBHC_PROFILE_RING;
-  if (e->profile) HIP_CHECK(hipEventRecord(e->ev0[slot], st));
+  // profiling: the event pair is attached to the dispatch itself (hipExtLaunchKernelGGL: start / stop taken from the kernel's own
+  // begin / end timestamps), so the reading is the kernel's execution time, without the dispatch gap a hipEventRecord pair would add
+  hipEvent_t pe0 = e->profile ? e->ev0[slot] : nullptr, pe1 = e->profile ? e->ev1[slot] : nullptr;
   if (e->cfg.tracking_mode)
-    hipLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride, e->d_skc, e->cfg.map_image);
+    hipExtLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
+                          (const double*)e->d_glob, e->d_partials, e->lds_stride, (const float*)e->d_skc, (const uint32_t*)e->cfg.map_image);
   else
-    hipLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, e->d_cfg, e->tbl, *io, e->d_glob, e->d_partials, e->lds_stride, e->d_skc, e->cfg.map_image);
-  if (e->profile) { HIP_CHECK(hipEventRecord(e->ev1[slot], st)); e->prof_count++; }
+    hipExtLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
+                          (const double*)e->d_glob, e->d_partials, e->lds_stride, (const float*)e->d_skc, (const uint32_t*)e->cfg.map_image);
+  if (e->profile) e->prof_count++;
   hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames,
                      (const double*)nullptr, io->totals_out, 0.0);
   e->step_ctr++;
