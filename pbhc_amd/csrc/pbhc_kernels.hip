@@ -35,9 +35,12 @@ thread_local char g_pbhc_err[512] = "";
 // boundaries of k_env_step, written to a buffer nothing else reads.  The product build contains none of this.
 #ifdef PBHC_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_wg_times[2 * 4096];          // [workgroup][entry, exit] on the constant 100 MHz clock (comparable across CUs)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#define WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg_times[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define WG_STAMP(k) do { } while (0)
 #endif
 #define HIP_CHECK(x)                                                                          \
   do {                                                                                        \
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   // The config is read through the CONSTANT address space: the kernel never writes it, and saying so lets the compiler keep its
   // scalars in SGPRs across the kernel's global stores (through a plain global pointer every `c.x` after a store is reloaded and
   // waited for with s_waitcnt lgkmcnt(0), which also drains the LDS queue: ~8 reloads per batch of 8 stores in the observation phase).
+  WG_STAMP(0);
   typedef const PbhcEnvConfig __attribute__((address_space(4))) ConstCfg;
   ConstCfg& rt = *(ConstCfg*)cfgp;
 #ifdef PBHC_STATIC_CFG
@@ -1170,6 +1174,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     partials[(size_t)blockIdx.x * PBHC_NP + threadIdx.x] = v;
   }
   STAMP(11);
+  WG_STAMP(1);
 }
 
 // =================================================================================================
@@ -1554,6 +1559,11 @@ int pbhc_abi_version(void) { return PBHC_ABI_VERSION; }
 int pbhc_debug_read_stamps(unsigned long long* out, int n) {
   HIP_CHECK(hipDeviceSynchronize());
   HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32)));
+  return PBHC_OK;
+}
+int pbhc_debug_read_wg_times(unsigned long long* out, int num_workgroups) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(unsigned long long) * 2 * (num_workgroups < 4096 ? num_workgroups : 4096)));
   return PBHC_OK;
 }
 #endif

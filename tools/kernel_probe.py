@@ -41,3 +41,17 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
             prev = st[13 + 2 * g]
         if st[20]:
             print(f"  group 1 first batch: map reads {st[20] - st[13]} cyc, feature+segment reads {st[21] - st[20]} cyc, scale/clip/stores {st[22] - st[21]} cyc")
+
+if hasattr(lib, "pbhc_debug_read_wg_times"):
+    nwg = (N + 3) // 4
+    wt = (C.c_ulonglong * (2 * nwg))()
+    lib.pbhc_debug_read_wg_times(wt, nwg)
+    import statistics
+    t0 = min(wt[2 * i] for i in range(nwg))
+    starts = sorted((wt[2 * i] - t0) / 100.0 for i in range(nwg))                     # 100 MHz clock -> us
+    ends = sorted((wt[2 * i + 1] - t0) / 100.0 for i in range(nwg))
+    durs = sorted((wt[2 * i + 1] - wt[2 * i]) / 100.0 for i in range(nwg))
+    q = lambda v, p: v[min(len(v) - 1, int(p * len(v)))]
+    print(f"  workgroups {nwg}: entry  min {starts[0]:.2f} median {q(starts, .5):.2f} p99 {q(starts, .99):.2f} max {starts[-1]:.2f} us after the first")
+    print(f"                  exit   min {ends[0]:.2f} median {q(ends, .5):.2f} p99 {q(ends, .99):.2f} max {ends[-1]:.2f} us")
+    print(f"                  in-kernel time per workgroup: min {durs[0]:.2f} median {q(durs, .5):.2f} p99 {q(durs, .99):.2f} max {durs[-1]:.2f} us")
