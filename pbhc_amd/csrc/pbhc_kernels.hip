@@ -245,12 +245,21 @@ __device__ __forceinline__ void frame_blend(float t, float len, int nf, float dt
 
 // ---- phase lookup of one env: lerp/slerp of the two packed frame rows into LDS
 // (MotionLibBase.get_motion_state motion_lib_base.py:123-259) ------------------------------------
+// clip meta (length, frames, dt, first row) by value: the step kernel has them in registers since its prologue, so a lookup on the reset
+// path is ONE memory round trip (the two rows) instead of two (table meta, then rows)
+__device__ __forceinline__ void motion_lookup_meta(const PbhcMotionTable& tbl, int D, int Bx, int lane, float m_len, int m_nf, float m_dt, int m_row0, float t, f3 off,
+                                                   bool bodies, float* rdof, float* rdofv, float* rcontact, float* rp, float* rq, float* rv, float* rw);
 __device__ __forceinline__ void motion_lookup(const PbhcMotionTable& tbl, int D, int Bx, int lane, int mid, float t, f3 off, bool bodies,
                                               float* rdof, float* rdofv, float* rcontact, float* rp, float* rq, float* rv, float* rw) {
+  motion_lookup_meta(tbl, D, Bx, lane, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], tbl.length_starts[mid], t, off, bodies, rdof, rdofv, rcontact,
+                     rp, rq, rv, rw);
+}
+__device__ __forceinline__ void motion_lookup_meta(const PbhcMotionTable& tbl, int D, int Bx, int lane, float m_len, int m_nf, float m_dt, int m_row0, float t, f3 off,
+                                                   bool bodies, float* rdof, float* rdofv, float* rcontact, float* rp, float* rq, float* rv, float* rw) {
   int f0, f1; float b;
-  frame_blend(t, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &b);
-  const float* r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
-  const float* r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+  frame_blend(t, m_len, m_nf, m_dt, &f0, &f1, &b);
+  const float* r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
+  const float* r1 = tbl.frames + (size_t)(m_row0 + f1) * tbl.row;
   float a = 1.0f - b;
   for (int d = lane; d < D; d += PBHC_G) {
     rdof[d] = a * r0[d] + b * r1[d];
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   const float pf_noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
   const float* r0 = nullptr;
   const float* r1 = nullptr;
+  float m_len = tbl.single_len, m_dt = tbl.single_dt;          // this env's clip: length, frame time, frames, first table row
+  int m_nf = tbl.single_num_frames, m_row0 = 0;
   float clipcnt = 0.0f;
   const int hoff = c.feat_off[PBHC_F_HISTORY];
   const int Q = c.queue_len;
@@ -417,15 +428,12 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     // ---- consume (2): reference rows, issued now, consumed after the FK chain
     tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
     int f0, f1;
-    if (tbl.num_motions == 1) {                                 // single clip: its meta travels in the kernel arguments
-      frame_blend(tref, tbl.single_len, tbl.single_num_frames, tbl.single_dt, &f0, &f1, &blend);
-      r0 = tbl.frames + (size_t)f0 * tbl.row;
-      r1 = tbl.frames + (size_t)f1 * tbl.row;
-    } else {
-      frame_blend(tref, tbl.motion_len[mid], tbl.num_frames[mid], tbl.motion_dt[mid], &f0, &f1, &blend);
-      r0 = tbl.frames + (size_t)(tbl.length_starts[mid] + f0) * tbl.row;
-      r1 = tbl.frames + (size_t)(tbl.length_starts[mid] + f1) * tbl.row;
+    if (tbl.num_motions != 1) {                                 // single clip: its meta travels in the kernel arguments
+      m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid];
     }
+    frame_blend(tref, m_len, m_nf, m_dt, &f0, &f1, &blend);
+    r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
+    r1 = tbl.frames + (size_t)(m_row0 + f1) * tbl.row;
     const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
     {
       const int lb = min(lane, Bx - 1), lc = min(lane, 1);
@@ -836,9 +844,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
     float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
     const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
-    int row0 = 0, nf_c = tbl.single_num_frames;
-    float len_c = tbl.single_len, dt_c = tbl.single_dt;
-    if (valid && tbl.num_motions != 1) { row0 = tbl.length_starts[mid]; nf_c = tbl.num_frames[mid]; len_c = tbl.motion_len[mid]; dt_c = tbl.motion_dt[mid]; }
+    const int row0 = m_row0, nf_c = m_nf;
+    const float len_c = m_len, dt_c = m_dt;
     const float tb = (float)ep1 * dt + start;
     if (valid)
       for (int st = lane; st < NS; st += PBHC_G) {
@@ -914,14 +921,16 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     const int Q = c.queue_len;
     for (int d = lane; d < D; d += PBHC_G) {
       act[d] = 0.0f; actd[d] = 0.0f;
+      float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
+      pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, d, ur);
       if (c.randomize_pd_gain) {
-        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * rng_uniform(rt.seed, env, step_ctr, 2, d) + c.kp_range[0];
-        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * rng_uniform(rt.seed, env, step_ctr, 3, d) + c.kd_range[0];
+        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
+        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
       }
       if (c.randomize_rfi_lim)
-        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * rng_uniform(rt.seed, env, step_ctr, 4, d) + c.rfi_lim_range[0];
+        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
       if (c.use_rao)
-        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * rng_uniform(rt.seed, env, step_ctr, 5, d) + (-c.rao_lim);
+        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
       if (c.randomize_ctrl_delay)
         for (int k = 0; k < Q; ++k) io.action_queue[((size_t)env * Q + k) * D + d] *= 0.0f;
     }
@@ -939,14 +948,16 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       float old_start = misc[M_START];
       float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
       io.end_time_ratio_buf[env] = etr;
-      float mlen = tbl.motion_len[mid];
+      float mlen = m_len;                                  // = tbl.motion_len[mid], in registers since the prologue
       io.motion_len[env] = mlen;
-      float ns = io.ovr_start_time ? io.ovr_start_time[env] : rng_uniform(rt.seed, env, step_ctr, 6, 0) * mlen;   // sample_time motion_lib_base.py:486-495
+      float ue[4];                                     // start phase and control delay of the new episode from one Philox call
+      pbhc::rng_uniform4(rt.seed, env, step_ctr, 6, 0, ue);
+      float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
       io.motion_start_times[env] = ns;
       misc[M_NEWSTART] = ns;
       if (c.randomize_ctrl_delay) {
         long long nd = io.ovr_delay ? io.ovr_delay[env]
-                                    : (long long)c.ctrl_delay_range[0] + (long long)(rng_uniform(rt.seed, env, step_ctr, 7, 0) * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
+                                    : (long long)c.ctrl_delay_range[0] + (long long)(ue[1] * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
         io.action_delay_idx[env] = nd;
         misc[M_DELAY] = (float)nd;
       }
@@ -961,10 +972,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     if (MODE) {
       // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
       // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
-      motion_lookup(tbl, D, Bx, lane, mid, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
-      motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
+      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
     } else {
-      motion_lookup(tbl, D, Bx, lane, mid, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
     }
   }
   LDS_BARRIER();

@@ -203,6 +203,12 @@ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0
 }
 // uniform in [0,1): 24 mantissa bits
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// four uniforms of one Philox call, keyed (env, step, stream, idx): for draws that are consumed together
+__device__ __forceinline__ void rng_uniform4(uint64_t seed, uint32_t env, uint32_t step, uint32_t stream, uint32_t idx, float u[4]) {
+  uint32_t o[4];
+  philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), env, step, stream, idx, o);
+  u[0] = u01(o[0]); u[1] = u01(o[1]); u[2] = u01(o[2]); u[3] = u01(o[3]);
+}
 __device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t env, uint32_t step, uint32_t stream, uint32_t idx) {
   uint32_t o[4];
   philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), env, step, stream, idx >> 2, o);

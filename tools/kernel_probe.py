@@ -55,3 +55,9 @@ if hasattr(lib, "pbhc_debug_read_wg_times"):
     print(f"  workgroups {nwg}: entry  min {starts[0]:.2f} median {q(starts, .5):.2f} p99 {q(starts, .99):.2f} max {starts[-1]:.2f} us after the first")
     print(f"                  exit   min {ends[0]:.2f} median {q(ends, .5):.2f} p99 {q(ends, .99):.2f} max {ends[-1]:.2f} us")
     print(f"                  in-kernel time per workgroup: min {durs[0]:.2f} median {q(durs, .5):.2f} p99 {q(durs, .99):.2f} max {durs[-1]:.2f} us")
+    rb = env.reset_buf.cpu().view(-1)
+    has = [bool(rb[4 * i:4 * i + 4].any()) for i in range(nwg)]
+    d_all = [(wt[2 * i + 1] - wt[2 * i]) / 100.0 for i in range(nwg)]
+    a = [d for d, h in zip(d_all, has) if h]; b = [d for d, h in zip(d_all, has) if not h]
+    if a and b:
+        print(f"                  workgroups with a resetting env: {len(a)} (mean {sum(a) / len(a):.2f} us, max {max(a):.2f}); without: {len(b)} (mean {sum(b) / len(b):.2f} us, max {max(b):.2f})")
