@@ -25,7 +25,9 @@ using namespace pbhc;
 #ifndef PBHC_G
 #define PBHC_G 32     // lanes per env
 #endif
+#ifndef PBHC_EPB
 #define PBHC_EPB 4    // envs per workgroup
+#endif
 #define PBHC_NP 64    // partial sums per workgroup
 
 thread_local char g_pbhc_err[512] = "";
