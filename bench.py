@@ -277,7 +277,7 @@ def main():
                                 "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase (GEMMs via rocBLAS + gather + Adam), fp32"},
         }
         if world == 1 and not a.no_cpu_baseline and a.workload == "v1_walk":
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(num_envs_sample=N)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
