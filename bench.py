@@ -8,9 +8,11 @@ gradient all-reduce per optimiser step when N > 1).  env-steps/s = envs * 24 * K
 reference's own `Perf/total_fps` formula (mh_ppo.py:649-652).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          # starts the 8 ranks itself (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) re-starts itself under
+`torch.distributed.run` BEFORE anything touches the GPU, so the 1 -> 8 curve needs no wrapper.
 """
 import argparse
 import ctypes as C
@@ -182,6 +184,73 @@ def cpu_baseline(num_envs_sample=4096, iterations=2):
                       f"{secs:.1f} s (rollout {sum(r['rollout_s'] for r in rs):.1f} s, update {sum(r['update_s'] for r in rs):.1f} s)"}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as children of this process — which has made no
+    GPU call — relay their output and exit with their code."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def allreduce_probe(numel, device, reps=20):
+    """Stand-alone cost of the per-optimiser-step gradient exchange: `reps` all-reduces of a flat fp32 bucket of the gradient's size,
+    barrier-bracketed, max over ranks (ms per call).  Outside the timed region."""
+    buf = torch.ones(numel, device=device)
+    for _ in range(3):
+        dist.all_reduce(buf)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+# BASELINE.json's metric string, verbatim; the GPU count a line was measured on is `n_gpus` / `measured_on`
+METRIC = "env-steps/s (obs+reward+PPO update), 4096 G1 envs @1/2/4/8 MI355X"
+
+
+def dry_run(a, world, rank):
+    """PBHC_BENCH_DRYRUN=1: rendezvous + the collective pattern of one PPO iteration on host tensors over gloo — what a CPU-only box can
+    rehearse of the N-rank launch (the product itself has no CPU path).  Prints the JSON line with value = null."""
+    backend = os.environ.get("PBHC_BENCH_BACKEND", "gloo")
+    if world > 1:
+        dist.init_process_group(backend=backend)
+    from pbhc_amd import dist as pdist
+
+    pdist.reset_counters()
+    grads = torch.full((1_308_995,), float(rank + 1))             # the v1 actor+critic bucket (362 286 + 946 709 parameters)
+    pdist.allreduce_mean_(grads)
+    assert abs(float(grads[0]) - (world + 1) / 2.0) < 1e-6
+    adv = torch.arange(64.0) + 100.0 * rank
+    pdist.global_normalize_(adv)
+    lr = torch.tensor([1e-3, 1e-3])
+    pdist.kl_lr_rule_(lr, torch.tensor(0.05 * (rank + 1)), 0.01)
+    ar_ms = allreduce_probe(1_308_995, "cpu", reps=3) if world > 1 else 0.0
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "measured_on": f"{world} process(es), no GPU (dry run)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry run: rendezvous + collectives only (no GPU)", "envs_per_gpu": a.envs, "global_envs": a.envs * world,
+                                     "parallelism": f"dp{world}"},
+                          "collectives": {"backend": backend, "dry_run_all_reduces": pdist.COUNTERS["all_reduce"], "grad_allreduce_ms": ar_ms}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,9 +261,15 @@ def main():
     ap.add_argument("--workload", default="v1_walk", choices=sorted(WORKLOADS.keys()))
     ap.add_argument("--clips", type=int, default=1, help="synthetic motion library of this many clips (general-tracking workloads)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))          # no GPU call has happened in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks (use --nproc-per-node == --gpus)")
+    if os.environ.get("PBHC_BENCH_DRYRUN", "0") == "1":
+        return dry_run(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # rehearsal hooks (one-GPU box): PBHC_BENCH_DEVICE pins every rank to one device, PBHC_BENCH_BACKEND=gloo replaces RCCL
@@ -202,9 +277,20 @@ def main():
     backend = os.environ.get("PBHC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
-    if world > 1:
+    # PBHC_DIST_FORCE=1: a ONE-rank process group takes the data-parallel code path too (RCCL rehearsal on a one-GPU box)
+    force = os.environ.get("PBHC_DIST_FORCE", "0") == "1"
+    if world > 1 or force:
+        if force and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend=backend, **({"device_id": torch.device(device)} if backend == "nccl" else {}))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dp = world > 1 or force
     N, K, W = a.envs, a.steps, a.warmup
     cfg, env, MHPPO = build(N, device, seed=1234 + rank, workload=a.workload, num_clips=a.clips)
     algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=device)
@@ -217,9 +303,11 @@ def main():
     from pbhc_amd import _lib
     lib = _lib.lib()
 
+    from pbhc_amd import dist as pdist
+
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -234,6 +322,7 @@ def main():
     _lib.check(lib.pbhc_env_profile(env._env, 1))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
     sync()
+    pdist.reset_counters()
     t0 = time.perf_counter()
     for i in range(K):
         ev[3 * i].record()
@@ -244,7 +333,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    coll = dict(pdist.COUNTERS)
+    if dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     rollout_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K
@@ -260,9 +350,11 @@ def main():
     nets = list(algo.alg.named_parameters()) if hasattr(algo, "alg") else list(algo.actor.named_parameters()) + list(algo.critic.named_parameters())
     flops_per_sample = 2.0 * sum(p.numel() for n, p in nets if n.endswith("weight") and p.dim() == 2)     # Linear layers only (conv windows not counted)
     upd_flops = 3.0 * flops_per_sample * T * N * algo.num_learning_epochs
+    n_grad = sum(p.numel() for _, p in nets)
+    ar_ms = allreduce_probe(n_grad, device) if dp else None
     if rank == 0:
         out = {
-            "metric": "env-steps/s (obs+reward+PPO update), 4096 G1 envs @1/2/4/8 MI355X",
+            "metric": METRIC, "measured_on": f"{world} x MI355X, {N} envs per GPU",
             "value": N * world * T * K / dt, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N} envs/GPU, {WORKLOADS[a.workload]['desc']}" + (f", synthetic library of {a.clips} clips" if a.clips > 1 else "") +
@@ -276,10 +368,16 @@ def main():
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase (GEMMs via rocBLAS + gather + Adam), fp32"},
         }
+        if dp:
+            out["collectives"] = {"backend": backend, "all_reduces_per_iter": coll["all_reduce"] / K, "all_reduce_bytes_per_iter": coll["all_reduce_bytes"] / K,
+                                  "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": 4 * n_grad,
+                                  "note": "per PPO iteration and rank: 2 gradient-segment all-reduces + 1 KL scalar per optimiser step (20), 1 advantage-moment "
+                                          "exchange, 1 x 512-byte env-statistics exchange per control step (24); grad_allreduce_ms = one stand-alone all-reduce "
+                                          "of the whole gradient bucket, max over ranks"}
         if world == 1 and not a.no_cpu_baseline and a.workload == "v1_walk":
             out["cpu_baseline"] = cpu_baseline(num_envs_sample=N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -4,13 +4,17 @@ MI355X: the GEMMs stay library GEMMs (hipBLASLt / rocBLAS through torch), everyt
 * the activation backward and the bias gradient of the layer below are ONE pass (`pbhc_act_bwd_bias`) instead of an
   `elu_backward` + a column-sum launch;
 * weight / bias gradients are written by the GEMM (`out=`) and the fused kernel straight into the parameter's `.grad` — a view of
-  the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear;
+  the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear.  That store
+  OVERWRITES, so it is opt-in: only a stack whose owner declared `grad_direct(seq)` — "I zero the gradient buffer before every backward"
+  (the agents do) — takes it, and only while the stack has ONE live application; a stack applied twice in outstanding graphs, and
+  every stack of user code, hands its gradients back to autograd, which accumulates as usual;
 * ELU runs in place and its derivative is taken from the output (`y > 0 ? 1 : y + 1`), so pre-activations are not kept.
 Same arithmetic as autograd's (the column sums are two-stage fp32 in a fixed order); pinned by the update-parity tests.
 """
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -19,6 +23,20 @@ import torch.nn.functional as F
 from .. import _lib
 
 _ACT_ID = {nn.ELU: 1, nn.SiLU: 2, nn.ReLU: 3}
+
+
+class _Live:
+    """one per forward application of a stack, owned by its autograd context: alive while that graph can still run backward"""
+    __slots__ = ("__weakref__",)
+
+
+def grad_direct(seq, on=True):
+    """Owner's declaration for `seq` (an nn.Sequential of Linear / activation): every parameter's `.grad` is a preallocated contiguous
+    tensor that the owner zeroes before each backward, so the backward may store into it instead of returning gradients to autograd."""
+    seq._grad_direct = bool(on)
+    if not hasattr(seq, "_fused_live"):
+        seq._fused_live = weakref.WeakSet()
+        seq._fused_shared = False
 
 
 def supported(module_seq):
@@ -68,6 +86,10 @@ class _FusedMLP(torch.autograd.Function):
                 saved_act.append(z)                    # SiLU' needs the pre-activation
                 h = F.silu(z)
         ctx.seq, ctx.act, ctx.n = seq, act, len(lin)
+        ctx.live = None
+        if getattr(seq, "_grad_direct", False):
+            ctx.live = _Live()
+            seq._fused_live.add(ctx.live)
         ctx.save_for_backward(*saved_in, *saved_act)
         return out
 
@@ -89,10 +111,18 @@ class _FusedMLP(torch.autograd.Function):
         nb = C.c_int(0)
         ret_w = []
         off = 0
+        # direct stores only for a declared stack with one live application; once two applications were outstanding together, every
+        # backward of that batch accumulates through autograd (the first one's direct store would otherwise be overwritten by the second)
+        seq = ctx.seq
+        may_direct = False
+        if ctx.live is not None:
+            if len(seq._fused_live) > 1:
+                seq._fused_shared = True
+            may_direct = not seq._fused_shared
         for i in reversed(range(L)):
             l = lin[i]
             n = l.out_features
-            direct = l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
+            direct = may_direct and l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
             part = scratch[off:off + MAXB * n]
             off += MAXB * n
@@ -108,6 +138,11 @@ class _FusedMLP(torch.autograd.Function):
             if i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
         _lib.check(lib.pbhc_colsum_final(jobs, L, st), "pbhc_colsum_final")
+        if ctx.live is not None:
+            seq._fused_live.discard(ctx.live)
+            ctx.live = None
+            if len(seq._fused_live) == 0:
+                seq._fused_shared = False
         dx = d if ctx.needs_input_grad[0] else None
         flat = []
         for gw, gbias in reversed(ret_w):

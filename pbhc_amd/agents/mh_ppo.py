@@ -48,6 +48,51 @@ def _make_writer(log_dir):
         return _NullWriter()
 
 
+class PhaseTimer:
+    """`Perf/collection_time` / `Perf/learning_time` (mh_ppo.py:223-230,325-327) as DEVICE time.  The reference's host clock deltas mean
+    "time the phase took" only because its rollout synchronises with the host every step; an iteration here is fully asynchronous, so the
+    phases are bracketed by HIP events on the compute stream and read back when a logging interval ends (one synchronisation per
+    interval, none per iteration)."""
+
+    def __init__(self):
+        self._cur, self._pending = None, []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._cur = [e]
+
+    def split(self):
+        """end of the phase that started at the previous mark (no-op outside learn())"""
+        if self._cur is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._cur.append(e)
+            if len(self._cur) == 3:
+                self._pending.append(self._cur)
+                self._cur = None
+
+    def resolve(self):
+        """-> [(collection_s, learn_s)] of the iterations finished since the last call (synchronises on the last one)."""
+        out = []
+        if self._pending:
+            self._pending[-1][2].synchronize()
+            out = [(a.elapsed_time(b) * 1e-3, b.elapsed_time(c) * 1e-3) for a, b, c in self._pending]
+            self._pending = []
+        return out
+
+
+def _load_checkpoint(path, device):
+    """Checkpoints — ours, the reference's, a third party's `model_*.pt` — hold tensors, numbers, strings, tuples, lists, dicts and None
+    (state dicts, torch.optim state, `iter`, `infos`): they are read with the non-executing loader only.  A file that needs more than
+    that is refused, never unpickled."""
+    try:
+        return torch.load(path, map_location=device, weights_only=True)
+    except Exception as e:          # pickle.UnpicklingError / RuntimeError from the restricted unpickler
+        raise _lib.PbhcError(f"checkpoint {path}: not loadable with torch.load(weights_only=True) ({type(e).__name__}: {str(e)[:300]}); "
+                             "pbhc_amd does not unpickle arbitrary objects — re-save the file with plain tensors / numbers in `infos`") from e
+
+
 def policy_forward_graphs(self, eager, key=0):
     """The rollout is launch-bound on the host (≈18 launches per control step): the policy forward of step t — 14 of them, reading the
     fixed rollout slab t and the in-place-updated flat weights — is captured once as a hipGraph per step index and replayed with one
@@ -138,6 +183,7 @@ class MHPPO:
         self.writer = _make_writer(log_dir)
         self.start_time = self.stop_time = 0
         self.collection_time = self.learn_time = 0
+        self._timer = PhaseTimer()
         self._init_config()
         self.tot_timesteps = 0
         self.tot_time = 0
@@ -150,9 +196,9 @@ class MHPPO:
         self.cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
         # device-side episode statistics: [sum of returns, sum of lengths, count] of finished episodes
         self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
-        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world_size > 1 else 0
-        if self.world_size > 1 and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
+        self.world_size, self.rank = pdist.world(), pdist.rank()
+        self._dp = pdist.active()                    # data-parallel exchanges on (more than one rank, or a forced one-rank rehearsal)
+        if self._dp and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
             self.env.enable_global_statistics()          # sigma / episode-length curricula from the batch of all ranks' envs
         _ = self.env.reset_all()
 
@@ -199,9 +245,9 @@ class MHPPO:
         self.actor = PPOActor(obs_dim_dict=self.algo_obs_dim_dict, module_config_dict=c.module_dict.actor, num_actions=self.num_act,
                               init_noise_std=c.init_noise_std).to(self.device)
         self.critic = PPOCritic(obs_dim_dict=self.algo_obs_dim_dict, module_config_dict=c.module_dict.critic).to(self.device)
-        if self.world_size > 1:      # replicas start from rank 0's weights
+        if self._dp:      # replicas start from rank 0's weights
             for p in list(self.actor.parameters()) + list(self.critic.parameters()):
-                dist.broadcast(p.data, src=0)
+                pdist.broadcast(p.data, src=0)
         self._flatten_parameters()
 
     def _flatten_parameters(self):
@@ -238,6 +284,13 @@ class MHPPO:
         # kept for checkpoint (de)serialisation in torch.optim.Adam's format
         self.actor_optimizer = _FlatAdamView(self, 0)
         self.critic_optimizer = _FlatAdamView(self, 1)
+        # every update zeroes `_gflat` before its backward: the MLP stacks may store their gradients into it directly
+        from . import fused_mlp
+        from .modules import BaseModule
+
+        for m in list(self.actor.modules()) + list(self.critic.modules()):
+            if isinstance(m, BaseModule):
+                fused_mlp.grad_direct(m.module)
 
     def _setup_storage(self):
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
@@ -261,7 +314,7 @@ class MHPPO:
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
         self._last_obs = {k: torch.zeros(N, _lib.padded_width(d), device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
-        self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
+        self._sample_seed = pdist.rank_seed(int(torch.randint(0, 2**62, (1,)).item()))
         self._branch_stream = torch.cuda.Stream(device=self.device)
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd MHPPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
@@ -281,7 +334,7 @@ class MHPPO:
     def load(self, ckpt_path):
         if ckpt_path is None:
             return None
-        d = torch.load(ckpt_path, map_location=self.device, weights_only=False)   # our own / user-trusted checkpoint
+        d = _load_checkpoint(ckpt_path, self.device)
         self.actor.load_state_dict(d["actor_model_state_dict"])
         self.critic.load_state_dict(d["critic_model_state_dict"])
         if self.load_optimizer:
@@ -319,13 +372,11 @@ class MHPPO:
         n = self.num_learning_iterations if num_iterations is None else num_iterations
         tot_iter = self.current_learning_iteration + n
         for it in range(self.current_learning_iteration, tot_iter):
-            self.start_time = time.time()
-            obs_dict = self._rollout_step(obs_dict)
+            self._timer.start()
+            obs_dict = self._rollout_step(obs_dict)           # ends with _timer.split(): collection | learning
             loss_dict = self._training_step()
-            self.stop_time = time.time()
-            self.learn_time = self.stop_time - self.start_time
-            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
-                                          num_learning_iterations=n))
+            self._timer.split()
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, num_learning_iterations=n))
             if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
                 self.current_learning_iteration = it
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
@@ -378,9 +429,7 @@ class MHPPO:
                                                  float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
                                                  self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
             st.step = T
-            self.stop_time = time.time()
-            self.collection_time = self.stop_time - self.start_time
-            self.start_time = self.stop_time
+            self._timer.split()
             self._compute_returns(self._last_obs)
         return self._last_obs
 
@@ -393,7 +442,7 @@ class MHPPO:
         _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,
                                        float(self.gamma), float(self.lam), st.returns.data_ptr(), adv.data_ptr(), self._gae_stats.data_ptr(),
                                        _lib.current_stream()), "pbhc_gae")
-        if self.world_size > 1:
+        if self._dp:
             # same normalisation as one big batch: undo the local one, re-normalise with global moments
             nb = (T * N + 255) // 256
             mean_l, std_l = self._gae_stats[2 * nb].float(), self._gae_stats[2 * nb + 1].float()
@@ -434,7 +483,7 @@ class MHPPO:
         self._gflat.zero_()
         so, sn = self._std_slice
         adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
-        on_device_lr = adapt if self.world_size == 1 else 0
+        on_device_lr = adapt if not self._dp else 0
         st = _lib.current_stream()
         _lib.check(lib.pbhc_ppo_loss(mu.data_ptr(), self.actor.std.data_ptr(), value.data_ptr(), b["actions"].data_ptr(), b["actions_log_prob"].data_ptr(),
                                      b["action_mean"].data_ptr(), b["action_sigma"].data_ptr(), b["advantages"].data_ptr(), b["returns"].data_ptr(),
@@ -443,12 +492,12 @@ class MHPPO:
                                      self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._gflat[so:so + sn].data_ptr(), self._loss_scalars.data_ptr(),
                                      self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
         na, nc = self._n_actor, self._n_critic
-        if self.world_size > 1:
+        if self._dp:
             # the actor's gradient segment is all-reduced while the critic's backward runs; the tiny KL exchange rides in between
             torch.autograd.backward([mu], [self._grad_mu])
-            h_a = dist.all_reduce(self._gflat[:na], async_op=True)
+            h_a = pdist.all_reduce(self._gflat[:na], async_op=True)
             torch.autograd.backward([value], [self._grad_value])
-            h_c = dist.all_reduce(self._gflat[na:na + nc], async_op=True)
+            h_c = pdist.all_reduce(self._gflat[na:na + nc], async_op=True)
             if adapt:
                 pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
             h_a.wait(); h_c.wait()
@@ -473,8 +522,8 @@ class MHPPO:
                 old_s, old_m = b["action_sigma"], b["action_mean"]
                 kl = torch.sum(torch.log(sigma / old_s + 1.0e-5) + (old_s.square() + (old_m - mu).square()) / (2.0 * sigma.square()) - 0.5, axis=-1)
                 kl_mean = kl.mean()
-                if self.world_size > 1:
-                    dist.all_reduce(kl_mean)
+                if self._dp:
+                    pdist.all_reduce(kl_mean)
                     kl_mean = kl_mean / self.world_size
                 up = kl_mean > self.desired_kl * 2.0
                 down = (kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0)
@@ -501,7 +550,7 @@ class MHPPO:
         self._gflat.zero_()
         actor_loss.backward()
         critic_loss.backward()
-        if self.world_size > 1:
+        if self._dp:
             self._allreduce_grads()
         lib, st = _lib.lib(), _lib.current_stream()
         na, nc = self._n_actor, self._n_critic
@@ -538,9 +587,14 @@ class MHPPO:
     # ---- logging (mh_ppo.py:547-700, reduced to the Perf/* + Loss/* + Train/* scalars) ------
     def _post_epoch_logging(self, log, width=80, pad=40):
         self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.world_size
-        it_time = log["collection_time"] + log["learn_time"]
-        self.tot_time += it_time
-        if log["it"] % self.logging_interval != 0 or self.rank != 0:
+        if log["it"] % self.logging_interval != 0:
+            return
+        for c, l in self._timer.resolve():                  # device time of every iteration since the last logging interval
+            self.collection_time, self.learn_time = c, l
+            self.tot_time += c + l
+        log["collection_time"], log["learn_time"] = self.collection_time, self.learn_time
+        it_time = self.collection_time + self.learn_time
+        if self.rank != 0:
             return
         stats = self._ep_stats.tolist()           # the only read-back, once per logging interval
         self._ep_stats.zero_()

@@ -28,7 +28,7 @@ import torch.distributed as dist
 from .. import _lib
 from .. import dist as pdist
 from .agent_modules import Actor, ActorCritic
-from .mh_ppo import _make_writer, policy_forward_graphs
+from .mh_ppo import PhaseTimer, _load_checkpoint, _make_writer, policy_forward_graphs
 from .modules import RolloutStorage
 
 
@@ -90,6 +90,7 @@ class PPO:
         self.writer = _make_writer(log_dir)
         self.start_time = self.stop_time = 0
         self.collection_time = self.learn_time = 0
+        self._timer = PhaseTimer()
         self._init_config()
         self.tot_timesteps = 0
         self.tot_time = 0
@@ -101,9 +102,9 @@ class PPO:
         self.cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
         self.cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
         self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
-        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world_size > 1 else 0
-        if self.world_size > 1 and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
+        self.world_size, self.rank = pdist.world(), pdist.rank()
+        self._dp = pdist.active()                    # data-parallel exchanges on (more than one rank, or a forced one-rank rehearsal)
+        if self._dp and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
             self.env.enable_global_statistics()          # sigma / episode-length curricula from the batch of all ranks' envs
         _ = self.env.reset_all()
         self.learn = self.learn_RL if not self.train_distill else self.learn_distill
@@ -194,9 +195,9 @@ class PPO:
             self.alg.actor.history_encoder.load_state_dict(self.teacher_actor.history_encoder.state_dict())
             for p in self.alg.actor.history_encoder.parameters():
                 p.requires_grad_(False)
-        if self.world_size > 1:
+        if self._dp:
             for p in self.alg.parameters():
-                dist.broadcast(p.data, src=0)
+                pdist.broadcast(p.data, src=0)
         self._flatten_parameters()
 
     def _flatten_parameters(self):
@@ -238,6 +239,13 @@ class PPO:
         self.betas, self.adam_eps, self.weight_decay = (0.9, 0.999), 1e-8, 0.01     # torch.optim.AdamW defaults
         self.optimizer = _FlatAdamWView(self, 0)
         self.hist_encoder_optimizer = _FlatAdamWView(self, 1)
+        # every update zeroes its segment of `_gflat` before its backward: the MLP stacks may store their gradients into it directly
+        from . import fused_mlp
+        from .modules import BaseModule
+
+        for m in self.alg.modules():
+            if isinstance(m, BaseModule):
+                fused_mlp.grad_direct(m.module)
 
     def _setup_storage(self):
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
@@ -261,7 +269,7 @@ class PPO:
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
         self._last_obs = {k: torch.zeros(N, _lib.padded_width(w), device=self.device)[:, :w] for k, w in self._obs_width.items()}
-        self._sample_seed = int(torch.randint(0, 2**62, (1,)).item())
+        self._sample_seed = pdist.rank_seed(int(torch.randint(0, 2**62, (1,)).item()))
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd PPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
         self._mb = (T * N) // self.num_mini_batches
@@ -279,7 +287,7 @@ class PPO:
     def load(self, ckpt_path):
         if ckpt_path is None:
             return None
-        d = torch.load(ckpt_path, map_location=self.device, weights_only=False)   # our own / user-trusted checkpoint
+        d = _load_checkpoint(ckpt_path, self.device)
         self.alg.load_state_dict(d["model_state_dict"])
         if self.load_optimizer:
             self.optimizer.load_state_dict(d["optimizer_state_dict"])
@@ -309,15 +317,13 @@ class PPO:
         tot_iter = self.current_learning_iteration + n
         for it in range(self.current_learning_iteration, tot_iter):
             self.hist_encoding = it % self.dagger_update_freq == 0
-            self.start_time = time.time()
-            obs_dict = self._rollout_step(obs_dict)
+            self._timer.start()
+            obs_dict = self._rollout_step(obs_dict)           # ends with _timer.split(): collection | learning
             loss_dict = self._training_step()
             if self.hist_encoding:
                 loss_dict = self._training_step_dagger()
-            self.stop_time = time.time()
-            self.learn_time = self.stop_time - self.start_time
-            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
-                                          num_learning_iterations=n))
+            self._timer.split()
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, num_learning_iterations=n))
             if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
                 self.current_learning_iteration = it
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
@@ -336,13 +342,11 @@ class PPO:
         tot_iter = self.current_learning_iteration + n
         for it in range(self.current_learning_iteration, tot_iter):
             self.hist_encoding = True
-            self.start_time = time.time()
+            self._timer.start()
             obs_dict = self._rollout_step_distill(obs_dict)
             loss_dict = self._training_step_distill()
-            self.stop_time = time.time()
-            self.learn_time = self.stop_time - self.start_time
-            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, collection_time=self.collection_time, learn_time=self.learn_time,
-                                          num_learning_iterations=n))
+            self._timer.split()
+            self._post_epoch_logging(dict(it=it, loss_dict=loss_dict, num_learning_iterations=n))
             if self.log_dir is not None and it % self.save_interval == 0 and self.rank == 0:
                 self.current_learning_iteration = it
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
@@ -373,9 +377,7 @@ class PPO:
                                                  0.0, st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
                                                  self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
             st.step = T
-            self.stop_time = time.time()
-            self.collection_time = self.stop_time - self.start_time
-            self.start_time = self.stop_time
+            self._timer.split()
         return self._last_obs
 
     def _training_step_distill(self, indices=None):
@@ -395,7 +397,7 @@ class PPO:
         bc = (b["teacher_actions"] - mu).norm(p=2, dim=1).mean()
         self._gflat[: self._n_main].zero_()
         bc.backward()
-        if self.world_size > 1:
+        if self._dp:
             pdist.allreduce_mean_(self._gflat[: self._n_main])
         self._adam(0, 0, self._n_main, self._lr[0:1])
         loss["bc_loss"] += bc.detach()
@@ -437,9 +439,7 @@ class PPO:
                                                  float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
                                                  self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
             st.step = T
-            self.stop_time = time.time()
-            self.collection_time = self.stop_time - self.start_time
-            self.start_time = self.stop_time
+            self._timer.split()
             self._compute_returns(self._last_obs)
         return self._last_obs
 
@@ -452,7 +452,7 @@ class PPO:
         _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,
                                        float(self.gamma), float(self.lam), st.returns.data_ptr(), adv.data_ptr(), self._gae_stats.data_ptr(),
                                        _lib.current_stream()), "pbhc_gae")
-        if self.world_size > 1:
+        if self._dp:
             nb = (T * N + 255) // 256
             mean_l, std_l = self._gae_stats[2 * nb].float(), self._gae_stats[2 * nb + 1].float()
             adv.copy_(pdist.global_normalize_(adv * (std_l + 1e-8) + mean_l))
@@ -506,7 +506,7 @@ class PPO:
         sigma = alg.sigma().detach().contiguous()
         self._gflat[: self._n_main].zero_()
         adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
-        flags = (adapt if self.world_size == 1 else 0) | 2                      # bit 1: the ppo_mimic KL form
+        flags = (adapt if not self._dp else 0) | 2                      # bit 1: the ppo_mimic KL form
         st = _lib.current_stream()
         _lib.check(lib.pbhc_ppo_loss(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), b["actions"].data_ptr(), b["actions_log_prob"].data_ptr(),
                                      b["action_mean"].data_ptr(), b["action_sigma"].data_ptr(), b["advantages"].data_ptr(), b["returns"].data_ptr(),
@@ -523,7 +523,7 @@ class PPO:
             so, sn = self._std_slice
             std = alg.std.detach()
             self._gflat[so:so + sn] = self._g_sigma * ((std >= alg.min_sigma) & (std <= alg.max_sigma))
-        if self.world_size > 1:
+        if self._dp:
             if adapt:
                 pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
             pdist.allreduce_mean_(self._gflat[: self._n_main])
@@ -539,7 +539,7 @@ class PPO:
         hist_loss = (priv_latent - a.history_encoding(b["prop_history"])).norm(p=2, dim=1).mean()
         self._gflat[self._n_main:].zero_()
         hist_loss.backward()
-        if self.world_size > 1:
+        if self._dp:
             pdist.allreduce_mean_(self._gflat[self._n_main:])
         self._adam(1, self._n_main, self._n_hist, self._lr_hist)
         loss["hist_latent_loss"] += hist_loss.detach()
@@ -568,9 +568,14 @@ class PPO:
 
     def _post_epoch_logging(self, log, width=80, pad=40):
         self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.world_size
-        it_time = log["collection_time"] + log["learn_time"]
-        self.tot_time += it_time
-        if log["it"] % self.logging_interval != 0 or self.rank != 0:
+        if log["it"] % self.logging_interval != 0:
+            return
+        for c, l in self._timer.resolve():                  # device time of every iteration since the last logging interval
+            self.collection_time, self.learn_time = c, l
+            self.tot_time += c + l
+        log["collection_time"], log["learn_time"] = self.collection_time, self.learn_time
+        it_time = self.collection_time + self.learn_time
+        if self.rank != 0:
             return
         stats = self._ep_stats.tolist()
         self._ep_stats.zero_()

@@ -13,15 +13,47 @@ from __future__ import annotations
 
 import ctypes as C
 import importlib
+import sys
+from collections.abc import Mapping
 
 import numpy as np
 import torch
 
 from .. import _lib
+from .. import dist as pdist
 from ..motion_lib import MotionLib
 from . import env_config
 
 K = _lib.K
+
+
+class EpisodeExtras(Mapping):
+    """`extras["episode"]` of a step (legged_robot_base.py:510-515): `rew_<term>` = the finished episodes' reward sums / max_episode_length_s
+    and `end_epis_length`, one entry per env reset in that step.  Their shape depends on how many envs reset, which the reference learns with
+    a host synchronisation every step (`nonzero`); here the kernel leaves the per-env values on the device and this mapping gathers them on
+    first access.  It reads env-owned buffers of ITS step: `env.step()` materialises a mapping somebody still holds before it launches the
+    next step, so a consumer may keep it (the reference's agents append it to `ep_infos` and read it at logging time)."""
+
+    def __init__(self, env):
+        self._env, self._data = env, None
+
+    def materialise(self):
+        if self._data is None:
+            e = self._env
+            ids = e.reset_buf.nonzero(as_tuple=False).flatten()
+            d = {"rew_" + k: e._episode_rew_out[ids, i] for i, k in enumerate(e.layout.sum_names)}
+            d["end_epis_length"] = e.last_episode_length_buf[ids]
+            self._data, self._env = d, None
+        return self._data
+
+    def __getitem__(self, k):
+        return self.materialise()[k]
+
+    def __iter__(self):
+        return iter(self.materialise())
+
+    def __len__(self):
+        return len(self.materialise())
 
 
 def get_class(path):
@@ -70,12 +102,21 @@ class LeggedRobotMotionTracking:
         rc.motion.step_dt = self.dt
         self.max_len = int(getattr(rc.motion, "motion_max_len", -1)) if self.TRACKING_MODE == 1 else -1     # general_tracking.py:60
         self._motion_lib = MotionLib.from_config(rc.motion, self.skeleton, N, dev, max_len=self.max_len)
+        # host-side draws (slot -> clip sampling, start phases and episodic DR of reset_all): the torch global generator on rank 0 — as the
+        # reference — and a rank-keyed generator on the other ranks of a data-parallel run, so that equal seeds do not replicate envs
+        self._gen = pdist.host_generator(dev)
+        self._motion_lib.generator = self._gen
+        if self._gen is not None:
+            import random
+
+            self._motion_lib.pyrand = random.Random(self._gen.initial_seed())
         self._load_motions_initial()
         for e in rc.motion.get("extend_config", []):
             self.simulator._body_list.append(e["joint_name"])           # motion_tracking.py:226
         self.num_extend_bodies = len(rc.motion.get("extend_config", []))
         # ---- static config -> device
-        self._seed = int(torch.randint(0, 2**31 - 1, (1,)).item())
+        # Philox key of this env shard: the torch-seeded draw, with the rank mixed in (same config.seed on every rank must not replicate streams)
+        self._seed = pdist.rank_seed(int(torch.randint(0, 2**31 - 1, (1,)).item()), bits=31)
         self._c, self.layout = env_config.build(_TopView(config), self.skeleton, self._motion_lib, N, dev, self.simulator._link_mass_scale.shape[1],
                                                 seed=self._seed, mode=self.TRACKING_MODE)
         L = self.layout
@@ -135,7 +176,7 @@ class LeggedRobotMotionTracking:
         self.action_queue = f(N, self._c.queue_len, D)
         dr = self.config.domain_rand
         if dr.randomize_ctrl_delay:
-            self.action_delay_idx = torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev)
+            self.action_delay_idx = torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev, generator=self._gen)
         else:
             self.action_delay_idx = torch.zeros(N, dtype=torch.long, device=dev)
         self.last_dof_pos, self.last_dof_vel, self.torques = f(N, D), f(N, D), f(N, D)
@@ -261,14 +302,12 @@ class LeggedRobotMotionTracking:
         on, each step writes its shard's batch sums (PBHC_NUM_TOTALS doubles), they are summed over the ranks by one tiny all-reduce that
         overlaps the next policy forward, and `pbhc_env_finalize` applies them — right before the next step launches, which is the first
         consumer.  Every rank then holds the same sigma / curriculum state as ONE process with all the envs would."""
-        import torch.distributed as dist
-
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not pdist.active(group):
             return False
         self._flush_statistics()
         self._stat_group = group
         n = torch.tensor([float(self.num_envs)], dtype=torch.float64, device=self.device)
-        dist.all_reduce(n, group=group)
+        pdist.all_reduce(n, group=group)
         self._num_envs_total = float(n)
         self._totals = torch.zeros(K["PBHC_NUM_TOTALS"], dtype=torch.float64, device=self.device)
         self._io.totals_out = self._totals.data_ptr()
@@ -295,11 +334,11 @@ class LeggedRobotMotionTracking:
         else:
             self.motion_start_times[env_ids] = self._motion_lib.sample_time(self.motion_ids[env_ids])
 
-    def resample_motion(self):
+    def resample_motion(self, keep_reset_buf=False):
         """motion_tracking.py:385-389 / general_tracking.py:291-297"""
         self._motion_lib.load_motions(random_sample=True, max_len=self.max_len)
         self.curr_motion_ids = self._motion_lib.slot_clip
-        self._reset_all_state()
+        self._reset_all_state(keep_reset_buf=keep_reset_buf)
 
     def reset_all(self):
         """base_task.py:83-93: reset every env, then one step with zero actions.  Start-up path,
@@ -308,8 +347,9 @@ class LeggedRobotMotionTracking:
         obs_dict, _, _, _ = self.step({"actions": torch.zeros(self.num_envs, self.dim_actions, device=self.device)})
         return obs_dict
 
-    def _reset_all_state(self):
-        """reset_envs_idx(arange(N)) (legged_robot_base.py:491-517)."""
+    def _reset_all_state(self, keep_reset_buf=False):
+        """reset_envs_idx(arange(N)) (legged_robot_base.py:491-517).  keep_reset_buf: the periodic resample inside step() — the reference's
+        resample_motion() resets every env WITHOUT touching reset_buf, the dones of that step stay those of its own _check_termination."""
         N, dev = self.num_envs, self.device
         ids = torch.arange(N, device=dev)
         g = self.globals
@@ -321,20 +361,19 @@ class LeggedRobotMotionTracking:
         cur = torch.mean(self.last_episode_length_buf, dtype=torch.float)
         n_all = N
         if self._totals is not None:                       # every rank resets all its envs: the mean over all ranks' envs
-            import torch.distributed as dist
-
             m = torch.stack([self.last_episode_length_buf.sum().double(), torch.tensor(float(N), dtype=torch.float64, device=dev)])
-            dist.all_reduce(m, group=self._stat_group)
+            pdist.all_reduce(m, group=self._stat_group)
             cur, n_all = (m[0] / m[1]).float(), float(m[1])
         frac = n_all / self._c.num_compute_average_epl
         avg = g[K["PBHC_G_AVG_EP_LEN"]].float() * (1 - frac) + cur * frac
         g[K["PBHC_G_AVG_EP_LEN"]] = avg.double()
         self._episode_length_buf.zero_()
-        self.reset_buf.fill_(1)
+        if not keep_reset_buf:
+            self.reset_buf.fill_(1)
         # _episodic_domain_randomization (legged_robot_base.py:599-635)
         dr = self.config.domain_rand
         D = self.num_dof
-        u = lambda lo, hi: (hi - lo) * torch.rand(N, D, device=dev) + lo
+        u = lambda lo, hi: (hi - lo) * torch.rand(N, D, device=dev, generator=self._gen) + lo
         if dr.randomize_pd_gain:
             self._kp_scale.copy_(u(dr.kp_range[0], dr.kp_range[1]))
             self._kd_scale.copy_(u(dr.kd_range[0], dr.kd_range[1]))
@@ -344,7 +383,7 @@ class LeggedRobotMotionTracking:
             self._rao_scale.copy_(u(-dr.rao_lim, dr.rao_lim))
         if dr.randomize_ctrl_delay:
             self.action_queue.zero_()
-            self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev))
+            self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev, generator=self._gen))
         # curricula keyed on average_episode_length (legged_robot_base.py:882-900, motion_tracking.py:309-317)
         c = self._c
         avg_f = float(avg)
@@ -368,6 +407,7 @@ class LeggedRobotMotionTracking:
         s.robot_root_states[:, 0:3] = ref["root_pos"]; s.robot_root_states[:, 3:7] = ref["root_rot"]
         s.robot_root_states[:, 7:10] = ref["root_vel"]; s.robot_root_states[:, 10:13] = ref["root_ang_vel"]
         self.extras["episode"] = {"rew_" + k: (v / self.max_episode_length_s).clone() for k, v in self.episode_sums.items()}
+        self.extras["episode"]["end_epis_length"] = self.last_episode_length_buf.clone()
         self._episode_sums.zero_()
         self.extras["time_outs"] = self.time_out_buf
 
@@ -390,18 +430,24 @@ class LeggedRobotMotionTracking:
             io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
             self._replay_version = s.replay_version
         io.frame_index = s.take_host_frame()
+        # the previous step's lazy extras["episode"]: gather it now if somebody kept it (its buffers are about to be overwritten)
+        prev = self.extras.pop("episode", None)
+        if isinstance(prev, EpisodeExtras) and prev._data is None and sys.getrefcount(prev) > 2:
+            prev.materialise()
+        del prev
         self._flush_statistics()
         _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
         if self._totals is not None:
-            import torch.distributed as dist
-
-            self._stat_pending = dist.all_reduce(self._totals, group=self._stat_group, async_op=True)
+            self._stat_pending = pdist.all_reduce(self._totals, group=self._stat_group, async_op=True)
         self.common_step_counter += 1
         # _update_tasks_callback (motion_tracking.py:320-325, general_tracking.py:216-222): periodic slot -> clip resampling + reset of every
         # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
         # it takes effect one control step later — once every resample_time_interval (50 000 - 100 000 steps in the shipped configs).
+        # The dones returned for this step stay the kernel's own (the reference's resample_motion does not touch reset_buf).
         if self.config.get("resample_motion_when_training", False) and self.common_step_counter % self.resample_time_interval == 0:
-            self.resample_motion()
+            self.resample_motion(keep_reset_buf=True)
+        else:
+            self.extras["episode"] = EpisodeExtras(self)
         self.extras["time_outs"] = self.time_out_buf
         self.extras["ref_body_pos_extend"] = self.ref_body_pos_extend
         self.extras["ref_body_rot_extend"] = self.ref_body_rot_extend

@@ -68,6 +68,7 @@ class MotionLib:
         self.has_contact_mask = all("contact_mask" in c for c in clips)
         self._contact_size = 2
         self.max_len = int(max_len)
+        self.generator = None              # torch.Generator for the sampling draws (None: the global one, as the reference)
         self._num_unique_motions = len(clips)
         # sampling hooks of the reference (setup_constants, motion_lib_base.py:109-118): per-unique-clip tensors a curriculum may write
         self._sampling_prob = torch.ones(len(clips), device=self.device) / len(clips)
@@ -151,6 +152,7 @@ class MotionLib:
         crop's own edges, motion_lib_base.py:420-434)."""
         import random
 
+        rnd = getattr(self, "pyrand", None) or random
         N, K = self.num_envs, self.max_len
         clip_of = self.slot_clip.tolist()
         nf, dts, lens = [], [], []
@@ -161,7 +163,7 @@ class MotionLib:
             if F < K:
                 a, b = 0, F
             else:
-                a = int(crop_starts[i]) if crop_starts is not None else random.randint(0, F - K)
+                a = int(crop_starts[i]) if crop_starts is not None else rnd.randint(0, F - K)
                 b = a + K
             self.crop_starts[i] = a
             n = b - a
@@ -195,7 +197,7 @@ class MotionLib:
         # in place: the step kernel holds the pointer of this tensor
         if random_sample:
             prob = self._sampling_prob if sampling_prob is None else sampling_prob
-            self.slot_clip.copy_(torch.multinomial(prob, num_samples=self.num_envs, replacement=True))
+            self.slot_clip.copy_(torch.multinomial(prob, num_samples=self.num_envs, replacement=True, generator=self.generator))
         else:
             self.slot_clip.copy_(torch.remainder(torch.arange(self.num_envs, device=self.device) + start_idx, self._num_unique_motions))
         self._curr_motion_ids = self.slot_clip
@@ -210,7 +212,7 @@ class MotionLib:
 
     def sample_time(self, slot_ids):
         # motion_lib_base.py:486-495
-        phase = torch.rand(slot_ids.shape, device=self.device)
+        phase = torch.rand(slot_ids.shape, device=self.device, generator=self.generator)
         return phase * self.get_motion_length(slot_ids)
 
     def get_motion_state(self, slot_ids, motion_times, offset=None):

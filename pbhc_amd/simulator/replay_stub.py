@@ -15,6 +15,7 @@ import ctypes as C
 import torch
 
 from .. import _lib
+from .. import dist as pdist
 from ..skeleton import Skeleton
 
 
@@ -69,7 +70,8 @@ class ReplaySimStub:
         self.base_init_state = base_init_state
         dr = self.env_config.domain_rand
         N, dev = num_envs, self.device
-        u = lambda *s: torch.rand(*s, device=dev)
+        gen = pdist.host_generator(dev)          # rank-keyed on ranks > 0 of a data-parallel run
+        u = lambda *s: torch.rand(*s, device=dev, generator=gen)
         self._base_com_bias = torch.zeros(N, 3, device=dev)
         if dr.get("randomize_base_com", False):
             r = dr.base_com_range

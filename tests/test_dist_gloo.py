@@ -67,3 +67,38 @@ def test_single_process_is_identity_on_world_1():
     assert torch.allclose(pdist.global_normalize_(x.clone()), ref, atol=1e-6)
     f = torch.randn(10)
     assert torch.equal(pdist.allreduce_mean_(f.clone()), f)
+
+
+def _seed_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)                                  # the same config.seed on every rank
+    base = int(torch.randint(0, 2**62, (1,)).item())
+    gen = pdist.host_generator("cpu")
+    draws = torch.rand(8, generator=gen).tolist()         # rank 0: the global generator; rank 1: its own rank-keyed one
+    q.put((rank, base, pdist.rank_seed(base), gen is None, draws))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_equal_torch_seeds_do_not_replicate_streams_across_ranks():
+    """Philox keys were (seed, LOCAL env, step) with the seed drawn from the torch generator — equal on every rank under the
+    usual config.seed.  The rank is now mixed into the key, and host-issued draws of ranks > 0 come from a rank-keyed generator."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(2):
+        r, base, seed, is_global, draws = q.get(timeout=120)
+        out[r] = (base, seed, is_global, draws)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][0] == out[1][0]                                   # same torch seed -> same base draw on both ranks ...
+    assert out[0][1] == out[0][0] and out[1][1] != out[0][1]        # ... rank 0 keeps it (single-process streams unchanged), rank 1 does not
+    assert out[0][2] and not out[1][2]
+    assert out[0][3] != out[1][3]
+    assert pdist.rank_seed(12345) == 12345 and pdist.host_generator("cpu") is None      # no process group: identity

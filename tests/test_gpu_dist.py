@@ -36,6 +36,14 @@ def _load_storage(algo, g, env_slice):
         getattr(algo.storage, k).copy_(g["st__" + k][:, env_slice].to(DEV))
 
 
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _rank_main(rank, world, port, perms, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -86,7 +94,7 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     del algo
     # ---- 2 processes x 4 envs (both on this GPU, gloo)
     out = str(tmp_path / "rank0.pt")
-    mp.spawn(_rank_main, args=(world, 29533, perms, out), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), perms, out), nprocs=world, join=True)
     got = torch.load(out, weights_only=True)
     assert torch.allclose(got["adv"], adv1[:, :n], atol=2e-5, rtol=1e-5)            # globally normalised advantages
     assert torch.allclose(got["lr"], lr1, rtol=1e-6)                                # same KL decisions
@@ -147,7 +155,7 @@ def test_env_statistics_over_two_ranks_follow_the_single_process_trace(tmp_path)
     T, N, D = g["actions_in"].shape
     world = 2
     out = str(tmp_path / "rows.pt")
-    mp.spawn(_env_rank_main, args=(world, 29541, out), nprocs=world, join=True)
+    mp.spawn(_env_rank_main, args=(world, _free_port(), out), nprocs=world, join=True)
     n = N // world
     moved = 0
     for rank in range(world):
@@ -168,3 +176,35 @@ def test_env_statistics_over_two_ranks_follow_the_single_process_trace(tmp_path)
             close(torch.tensor(r["upper"]), g["step__log__upper_body_diff_norm"][k], 1e-4, w + "log upper_body_diff_norm")
             close(torch.tensor(r["grav"]), g["step__log__terminate_by_gravity"][k], 1e-4, w + "log terminate_by_gravity")
     assert moved > 0            # sigma did change during the trace
+
+
+# ---- equal seeds on every rank must not replicate the random streams ---------------------------------------------------------
+def _seed_rank_main(rank, world, port, out_path):
+    from pbhc_amd.agents.mh_ppo import MHPPO
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(11)                              # the same config.seed on both ranks
+        cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 64)
+        algo = MHPPO(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+        algo.setup()
+        obs = env.reset_all()
+        algo._train_mode()
+        algo._rollout_step(obs)
+        torch.cuda.synchronize()
+        torch.save(dict(seed=env._seed, sample_seed=algo._sample_seed, actions=algo.storage.actions.cpu().clone(), start=env.motion_start_times.cpu().clone(),
+                        kp=env._kp_scale.cpu().clone(), w0=algo.actor.actor_module.module[0].weight.detach().cpu().clone()), out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_equal_seeds_give_different_streams_but_equal_weights(tmp_path):
+    out = str(tmp_path / "seed.pt")
+    mp.spawn(_seed_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0", weights_only=True), torch.load(out + ".1", weights_only=True)
+    assert a["seed"] != b["seed"] and a["sample_seed"] != b["sample_seed"]
+    assert torch.equal(a["w0"], b["w0"])                                          # replicas start from rank 0's weights
+    assert not torch.allclose(a["actions"], b["actions"])                         # action noise (in-kernel Philox, sample seed)
+    assert not torch.allclose(a["start"], b["start"])                             # start phases (reset_all: host generator; resets: env Philox)
+    assert not torch.allclose(a["kp"], b["kp"])                                   # episodic domain randomisation

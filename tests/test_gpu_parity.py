@@ -223,6 +223,7 @@ def _env_step_vs_oracle(N, T):
     load_state_into_hip_env(env, flat)
     tg = lambda a: a.contiguous().to(DEV)
     env.simulator.set_replay(tg(root[1:]), tg(qp[1:]), tg(qv[1:]), tg(cf[1:]))
+    kept = []
     for k in range(T):
         act = 0.5 * torch.randn(N, 23, generator=gen)
         u = torch.rand(N, 23, generator=gen)
@@ -245,6 +246,20 @@ def _env_step_vs_oracle(N, T):
         close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
+        # extras["episode"] (legged_robot_base.py:510-515): per reset env, gathered lazily on the device.  Step k's mapping is read one step
+        # LATE (after step k+1 ran): env.step() materialises a mapping that somebody kept before it overwrites the buffers.
+        if int(o_reset.sum()) > 0:
+            ids = o_reset.nonzero().flatten()
+            want = dict(orc.episode_extras)
+            want = {n: v.clone() for n, v in want.items()}
+            want["end_epis_length"] = orc.s["last_episode_length_buf"][ids].clone()
+            kept.append((k, extras["episode"], want, ids))
+    assert kept, "no step with a reset"
+    for k, ep, want, ids in kept:
+        assert set(ep.keys()) == {"rew_" + n for n in env.episode_sums} | {"end_epis_length"}
+        assert ep["end_epis_length"].shape[0] == len(ids)
+        for name, v in want.items():
+            close(ep[name].float(), v.float(), 3e-5, f"step {k}: extras episode {name}", rtol=2e-4)
 
 
 def test_gae_matches_reference_storage():
