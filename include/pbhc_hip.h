@@ -435,6 +435,33 @@ int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
 int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n0, int n1, const float* lr, float* step, float max_norm, float beta1,
                     float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
 
+/* Test-only: the device functions of csrc/pbhc_math.h (the quaternion / rotation algebra every kernel inlines; SURVEY 8 row a1:
+ * isaac_utils/rotations.py:28-669, utils/torch_utils.py:51-79,239-296) applied elementwise, so that they can be pinned directly against
+ * the reference's own outputs.  a / b / c: device operand arrays of n elements ([n,4] xyzw quaternions, [n,3] vectors, [n] scalars,
+ * [n,9] row-major matrices, as the function takes them); out: [n, width of the result]. */
+enum PbhcDebugFn {
+  PBHC_DBG_QUAT_ROTATE = 0,        /* a q, b v -> [n,3] */
+  PBHC_DBG_QUAT_ROTATE_INVERSE,    /* a q, b v -> [n,3] */
+  PBHC_DBG_QUAT_APPLY,             /* a q, b v -> [n,3] */
+  PBHC_DBG_QUAT_MUL,               /* a q, b p -> [n,4] */
+  PBHC_DBG_QUAT_CONJ,              /* a q -> [n,4] */
+  PBHC_DBG_SLERP,                  /* a q0, b q1, c t -> [n,4] */
+  PBHC_DBG_CALC_HEADING,           /* a q -> [n] */
+  PBHC_DBG_CALC_HEADING_QUAT,      /* a q -> [n,4] */
+  PBHC_DBG_CALC_HEADING_QUAT_INV,  /* a q -> [n,4] */
+  PBHC_DBG_EULER_XYZ,              /* a q -> [n,3] roll pitch yaw */
+  PBHC_DBG_QUAT_FROM_ANGLE_AXIS,   /* a angle [n], b axis -> [n,4] */
+  PBHC_DBG_QUAT_ANGLE,             /* a q -> [n]: quat_to_angle_axis(q)[0] */
+  PBHC_DBG_AXIS_ANGLE_TO_QUAT_WXYZ,/* a axis-angle [n,3] -> [n,4] wxyz */
+  PBHC_DBG_QUAT_TO_MATRIX,         /* a q (xyzw) -> [n,9] */
+  PBHC_DBG_MATRIX_TO_QUAT,         /* a [n,9] -> [n,4] xyzw */
+  PBHC_DBG_YAW_QUAT,               /* a q -> [n,4] */
+  PBHC_DBG_QUAT_TO_MAT6,           /* a q -> [n,6]: first two columns of R, row-major */
+  PBHC_DBG_QUAT_UNIT,              /* a q -> [n,4] */
+  PBHC_DBG_NUM
+};
+int pbhc_debug_rotations(int fn, const float* a, const float* b, const float* c, int n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,7 +86,7 @@ PbhcStepIO = _S["PbhcStepIO"]
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
-           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2"]
+           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations"]
 
 
 class PbhcError(RuntimeError):
@@ -126,6 +126,7 @@ def _load():
     lib.pbhc_policy_sample.argtypes = [vp, vp, vp, i, i, i, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.pbhc_rollout_post.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp]
     lib.pbhc_gae.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp]
+    lib.pbhc_debug_rotations.argtypes = [i, vp, vp, vp, i, vp, vp]
     return lib
 
 

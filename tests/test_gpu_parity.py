@@ -481,6 +481,61 @@ def test_act_bwd_bias_matches_torch():
             close(gb, ref_dz.double().sum(0).float(), 2e-3 if B > 1000 else 1e-4, f"grad_bias act={act} {B}x{n}", rtol=1e-5)
 
 
+def test_fused_mlp_keeps_autograd_accumulation():
+    """the fused MLP backward may STORE weight / bias gradients into `.grad` (the agents' flat buffer, zeroed before every
+    backward) — but only for a stack its owner declared `grad_direct`, and only with one live application.  User code (no declaration), a
+    stack applied twice in one graph, and two backwards without zeroing must all behave like plain autograd (`grad += ...`)."""
+    from pbhc_amd.agents import fused_mlp
+    from pbhc_amd.agents.modules import BaseModule
+
+    def make(declare):
+        torch.manual_seed(3)
+        m = BaseModule({"o": 40}, {"input_dim": ["o"], "output_dim": [7], "layer_config": {"type": "MLP", "hidden_dims": [64, 32], "activation": "ELU"}}).to(DEV)
+        flat = torch.zeros(sum(p.numel() for p in m.parameters()), device=DEV)
+        o = 0
+        for p in m.parameters():
+            p.grad = flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        if declare:
+            for b in m.modules():
+                if isinstance(b, BaseModule):
+                    fused_mlp.grad_direct(b.module)
+        return m, flat
+
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1, x2 = torch.randn(512, 40, device=DEV, generator=g), torch.randn(512, 40, device=DEV, generator=g)
+    ref, rflat = make(False)
+    ref._fused = False                                     # plain nn.Sequential + autograd
+    (ref(x1).square().sum() + ref(x2).sum()).backward()
+    want_twice = rflat.clone()
+    rflat.zero_()
+    ref(x1).square().sum().backward()
+    want_once = rflat.clone()
+    for declare in (False, True):
+        m, flat = make(declare)
+        assert m._fused
+        # (1) applied twice in ONE graph
+        (m(x1).square().sum() + m(x2).sum()).backward()
+        close(flat, want_twice, 2e-4, f"declare={declare}: module applied twice in one graph", rtol=1e-4)
+        # (2) one application after zeroing (the agents' pattern): the direct store when declared
+        flat.zero_()
+        m(x1).square().sum().backward()
+        close(flat, want_once, 2e-4, f"declare={declare}: single application", rtol=1e-4)
+        if not declare:
+            # (3) a second backward WITHOUT zeroing accumulates (undeclared stacks never overwrite)
+            m(x1).square().sum().backward()
+            close(flat, 2.0 * want_once, 4e-4, "two backwards without zeroing", rtol=1e-4)
+        # (4) two graphs alive together, backward one after the other
+        flat.zero_()
+        ya, yb = m(x1).square().sum(), m(x2).sum()
+        ya.backward(); yb.backward()
+        close(flat, want_twice, 2e-4, f"declare={declare}: two live graphs", rtol=1e-4)
+        # ... and the direct path is back afterwards
+        flat.zero_()
+        m(x1).square().sum().backward()
+        close(flat, want_once, 2e-4, f"declare={declare}: single application again", rtol=1e-4)
+
+
 def test_adam_clip_matches_torch_adam_and_adamw():
     """pbhc_adam_clip over a flat segment == clip_grad_norm_ + torch.optim.Adam / AdamW (decoupled weight decay) for 5 steps."""
     from pbhc_amd import _lib
