@@ -123,6 +123,33 @@ enum {
 // data through LDS only; same-address global accesses stay inside one wave, where program order holds.
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Reductions over the 32 lanes of an env (half a wave64), every lane receiving the result.  `__shfl_xor` lowers to ds_bpermute_b32 — an LDS
+// round trip plus an address VGPR per step, five steps per reduction, ~30 reductions per env step.  The DPP forms below stay in the VALU:
+// quad_perm x2 and row_half_mirror / row_mirror fold the 16 lanes of a DPP row into every lane of it (the compiler fuses each move into
+// v_add_f32_dpp / v_max_f32_dpp), and one v_permlane16_swap_b32 (gfx950) exchanges the odd rows of one copy with the even rows of the
+// other, so rows {0,1} and {2,3} — the two envs of the wave — each end up holding their 32-lane result: 7 instructions, no LDS.
+// Inactive lanes read as 0 (bound_ctrl), a row never mixes envs, and the swap pairs row 0 with 1 and row 2 with 3 only.
+#if PBHC_G == 32
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<0xB1>(v);        // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E>(v);        // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x141>(v);       // row_half_mirror
+  v += dpp_mov<0x140>(v);       // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float group_max(float v) {      // operands are >= 0 wherever this is used, so the 0 of an inactive lane is neutral
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+}
+#else
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int m = PBHC_G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, PBHC_G);
@@ -133,6 +160,12 @@ __device__ __forceinline__ float group_max(float v) {
   for (int m = PBHC_G / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, PBHC_G));
   return v;
 }
+#endif
+// element `i` of a tensor at a UNIFORM base pointer with the byte offset formed in 32 bits: the compiler emits the SGPR-base form of
+// global_load / global_store (one 32-bit offset VGPR per access instead of a 64-bit address built in the VALU).  Callers keep
+// (elements x sizeof) below 2^32 (checked on the host at pbhc_env_create / pbhc_env_step).
+template <class T> __device__ __forceinline__ T& at(T* p, unsigned int i) { return *(T*)((char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
+template <class T> __device__ __forceinline__ const T& at(const T* p, unsigned int i) { return *(const T*)((const char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 __device__ __forceinline__ f4 ld4(const float* p) { return mk4(p[0], p[1], p[2], p[3]); }
 __device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
@@ -217,7 +250,7 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
         const float* ka = skc + a * SKC_W;
         f3 axis = ld3(ka + 7);
         f3 pn = add3(p, quat_rotate(r, ld3(ka)));
-        f4 rn = quat_unit(quat_mul(r, ld4(relq + 4 * a)));
+        f4 rn = quat_unit_fast(quat_mul(r, ld4(relq + 4 * a)));
         f3 wn = add3(w, mul3(quat_rotate(rn, axis), qd[a - 1]));
         v = add3(v, cross3(w, sub3(pn, p)));
         p = pn; r = rn; w = wn;
@@ -321,12 +354,16 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   float *red = S + lo.red, *feat = S + lo.feat;
   // replay frame of this step: named by the host, or read from the device-side cursor
   const size_t fk = (size_t)(io.frame_index >= 0 ? io.frame_index : io.frame_cursor[0] % io.num_frames) * (size_t)N;
+  // Addressing: every per-env tensor is indexed as <uniform 64-bit base> + <32-bit unsigned lane offset>, which the compiler emits as the
+  // SGPR-base form of global_load / global_store (one offset VGPR, no 64-bit VALU address arithmetic; pbhc_env_create checks that
+  // num_envs x row pitch stays below 2^30 elements).
+  typedef unsigned int u32;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
   float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
   uint32_t* mapl = (uint32_t*)(blockpart + PBHC_EPB * PBHC_NP);   // [map_lds_words] compact observation maps, shared by the workgroup
   const float dt = c.dt;
-  const size_t eD = (size_t)env * D;
+  const u32 eD = (u32)env * (u32)D;
   STAMP(0);
   float skreg[SKC_REGS];
   stage_skeleton_load(skc_img, Bx * SKC_W, skreg);
@@ -372,53 +409,54 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   // s_waitcnt when the allocator recycles the register of a load still in flight).  Out-of-range lanes read a neighbour's value and
   // never use it; a tail workgroup's missing envs read env N-1.
   const int envc = valid ? env : N - 1;
-  const size_t eDc = (size_t)envc * D;
+  const u32 eDc = (u32)envc * (u32)D;
   const int d = lane;                         // D <= 32: one dof per lane
   const int dc = min(lane, D - 1);
   float sumrow = 0.0f;                        // episode_sums[env][lane]; a term's own column is fetched with a shuffle in phase F
   // (1) what the FK chain needs
-  const float fq = io.frame_dof_pos[fk * D + eDc + dc], fqd = io.frame_dof_vel[fk * D + eDc + dc];
-  const float froot = io.frame_root[(fk + envc) * 13 + min(lane, 12)];
+  const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
+  const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
   // (2) env scalars -> reference-frame address
   ep1 = io.episode_length_buf[envc] + 1;
   start = io.motion_start_times[envc];
   mlen_env = io.motion_len[envc];
   mid = (int)io.motion_ids[envc];
-  origin = ld3(io.env_origins + (size_t)envc * 3);
+  origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u));
   // (3) everything else of this step, into registers
   float hreg[PBHC_HREG];
   {
-    const float* __restrict__ hsrc = io.hist + (size_t)envc * (io.hist_pitch ? io.hist_pitch : c.hist_dim);
+    const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
     const int hlast = c.hist_dim - 1;
 #pragma unroll
-    for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = hsrc[min(lane + u * PBHC_G, hlast)];
+    for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
   }
   float creg[128 / PBHC_G];
   {
-    const float* __restrict__ csrc = io.frame_contact + (fk + envc) * (size_t)(B * 3);
+    const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
+    const u32 cbase = (u32)envc * (u32)(B * 3);
 #pragma unroll
-    for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = csrc[min(lane + u * PBHC_G, B * 3 - 1)];
+    for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
   }
   float qold[PBHC_MAX_QUEUE];
-  float* qu = io.action_queue + (size_t)envc * Q * D + dc;
+  const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
 #pragma unroll
-  for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = qu[(size_t)min(k, Q - 1) * D];
-  const float a_in = io.actions_in[eDc + dc];
-  const float qp = io.dof_state[(eDc + dc) * 2], qv = io.dof_state[(eDc + dc) * 2 + 1];
-  const float kp = io.kp_scale[eDc + dc], kd = io.kd_scale[eDc + dc], rfs = io.rfi_lim_scale[eDc + dc], ras = io.rao_scale[eDc + dc];
-  const float u_inj = (io.u_rfi ? io.u_rfi : io.actions_in)[eDc + dc];
-  pf_last_act = io.last_actions[eDc + dc]; pf_last_qd = io.last_dof_vel[eDc + dc];
+  for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
+  const float a_in = at(io.actions_in, eDc + dc);
+  const float qp = at(io.dof_state, (eDc + dc) * 2), qv = at(io.dof_state, (eDc + dc) * 2 + 1);
+  const float kp = at(io.kp_scale, eDc + dc), kd = at(io.kd_scale, eDc + dc), rfs = at(io.rfi_lim_scale, eDc + dc), ras = at(io.rao_scale, eDc + dc);
+  const float u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
+  pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
   const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
   const float bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
   const int nlm = max(c.dr_link_mass_dim, 1);
-  const float lmreg = (c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com)[(size_t)envc * nlm + min(lane, nlm - 1)];
-  const float combias = io.dr_base_com[(size_t)envc * 3 + min(lane, 2)];
+  const float lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
+  const float combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
   const float fric = io.dr_friction[envc];
-  const float fat = io.feet_air_time[(size_t)envc * NF + min(lane, NF - 1)], lastc = io.last_contacts[(size_t)envc * NF + min(lane, NF - 1)];
+  const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
   {
     const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
     pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_]; pf_tsrc = c.term_src[tl_];
-    sumrow = io.episode_sums[(size_t)envc * c.num_sum_cols + min(lane, c.num_sum_cols - 1)];
+    sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));
     pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
   }
   float u_rfi = 0.5f;
@@ -465,7 +503,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
         for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
           if (k < Q) {
             float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
-            qu[(size_t)k * D] = nv;
+            at(io.action_queue, qoff + (u32)(k * D)) = nv;
             if (k == didx) delayed = nv;
           }
       }
@@ -593,7 +631,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       f3 rpos = ld3(rp + 3 * b);
       f3 dp = sub3(rpos, ld3(bp + 3 * b));
       float n2 = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
-      float msq = n2 / 3.0f;
+      float msq = n2 * (1.0f / 3.0f);
       float nrm = sqrtf(n2);
       int fl = c.body_flags[b];
       if (fl & 1) { s_up += msq; s_upn += nrm; }
@@ -603,14 +641,14 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       s_maxn = fmaxf(s_maxn, nrm);
       f4 dq = ld4(rq + 4 * b), cq = ld4(bq + 4 * b);
       f3 dv = sub3(ld3(rv + 3 * b), ld3(bv + 3 * b));
-      const float dv2 = (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) / 3.0f;
+      const float dv2 = (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) * (1.0f / 3.0f);
       s_vel += dv2;
       f3 dw3 = sub3(ld3(rw + 3 * b), ld3(bw + 3 * b));
-      const float dw2 = (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) / 3.0f;
+      const float dw2 = (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) * (1.0f / 3.0f);
       s_ang += dw2;
       if (!MODE) {
         float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (motion_tracking.py:651)
-        s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) / 4.0f;
+        s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) * 0.25f;
       } else {
         // true quaternion difference + its angle (general_tracking.py:643-647,1144,1203); anchor-relative target :750-767
         const f3 bpos = ld3(bp + 3 * b);
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
         const float l2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z, lnrm = sqrtf(l2);
         const float lang = quat_angle(quat_mul(quat_mul(dori, dq), quat_conj(cq)));
         if (fl & 16) {
-          s_key += msq; s_keyn += nrm; s_lkey += l2 / 3.0f; s_lkeyn += lnrm;
+          s_key += msq; s_keyn += nrm; s_lkey += l2 * (1.0f / 3.0f); s_lkeyn += lnrm;
           s_lkrot += lang * lang; s_kvel += dv2; s_kang += dw2;
         }
         if (fl & 1) s_lupn += lnrm;
@@ -641,6 +679,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       st3(feat + o_lv + 3 * b, quat_rotate(hinv, rvel));
     }
     const float soft_pos = pf_soft_pos, soft_vel = pf_soft_vel, soft_tau = pf_soft_tau;
+    const float inv_dt = 1.0f / dt;
     const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
     for (int d = lane; d < D; d += PBHC_G) {
       float dj = rdof[d] - q[d], djv = rdofv[d] - qd[d];
@@ -651,7 +690,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       float la = pf_last_act - act[d];
       s_ar += la * la;
       s_qd2 += qd[d] * qd[d];
-      float acc = (pf_last_qd - qd[d]) / dt;
+      float acc = (pf_last_qd - qd[d]) * inv_dt;
       s_qacc2 += acc * acc;
       float lo_l, hi_l;
       if (c.soft_pos_curriculum) {
@@ -805,7 +844,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       }
       myrew = raw * pf_tscale;
       if (pf_tpen) myrew = myrew * pen_scale;
-      io.episode_sums[(size_t)env * c.num_sum_cols + pf_tcol] = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
+      at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)pf_tcol) = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
     }
     if (c.use_vec_reward) {
       if (lane < c.num_rew_cols) {
@@ -814,9 +853,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
         if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
           float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
           v += tr;
-          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] = pf_termsum + tr;
+          at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) = pf_termsum + tr;
         }
-        io.rew_buf[(size_t)env * c.num_rew_cols + lane] = v;
+        at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane) = v;
         rew_total = v;
       }
       rew_total = group_sum(rew_total);
@@ -827,7 +866,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
         if (c.has_termination) {
           float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
           v += tr;
-          io.episode_sums[(size_t)env * c.num_sum_cols + c.termination_sum_col] += tr;
+          at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) += tr;
         }
         io.rew_buf[env] = v;
       }
@@ -901,16 +940,16 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   // optional outputs of the pre-reset state
   if (valid) {
     if (io.ref_body_pos_extend)
-      for (int i = lane; i < Bx * 3; i += PBHC_G) io.ref_body_pos_extend[(size_t)env * Bx * 3 + i] = rp[i];
+      for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
     if (io.ref_body_rot_extend)
-      for (int i = lane; i < Bx * 4; i += PBHC_G) io.ref_body_rot_extend[(size_t)env * Bx * 4 + i] = rq[i];
+      for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
     if (io.rigid_body_state)
       for (int b = lane; b < B; b += PBHC_G) {
-        float* o = io.rigid_body_state + ((size_t)env * B + b) * 13;
+        float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
         st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
       }
     if (io.contact_forces)
-      for (int i = lane; i < B * 3; i += PBHC_G) io.contact_forces[(size_t)env * B * 3 + i] = cf[i];
+      for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
   }
 
   STAMP(6);
@@ -926,23 +965,23 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
       pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, d, ur);
       if (c.randomize_pd_gain) {
-        io.kp_scale[eD + d] = io.ovr_kp ? io.ovr_kp[eD + d] : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
-        io.kd_scale[eD + d] = io.ovr_kd ? io.ovr_kd[eD + d] : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
+        at(io.kp_scale, eD + d) = io.ovr_kp ? at(io.ovr_kp, eD + d) : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
+        at(io.kd_scale, eD + d) = io.ovr_kd ? at(io.ovr_kd, eD + d) : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
       }
       if (c.randomize_rfi_lim)
-        io.rfi_lim_scale[eD + d] = io.ovr_rfi_lim ? io.ovr_rfi_lim[eD + d] : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
+        at(io.rfi_lim_scale, eD + d) = io.ovr_rfi_lim ? at(io.ovr_rfi_lim, eD + d) : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
       if (c.use_rao)
-        io.rao_scale[eD + d] = io.ovr_rao ? io.ovr_rao[eD + d] : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
+        at(io.rao_scale, eD + d) = io.ovr_rao ? at(io.ovr_rao, eD + d) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
       if (c.randomize_ctrl_delay)
-        for (int k = 0; k < Q; ++k) io.action_queue[((size_t)env * Q + k) * D + d] *= 0.0f;
+        for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)d) *= 0.0f;
     }
     for (int i = lane; i < c.hist_dim; i += PBHC_G) {
       feat[hoff + i] *= 0.0f;
     }
-    float* sum = io.episode_sums + (size_t)env * c.num_sum_cols;
+    const u32 sbase = (u32)env * (u32)c.num_sum_cols;
     for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
-      if (io.episode_rew_out) io.episode_rew_out[(size_t)env * c.num_sum_cols + i] = sum[i] / c.max_episode_length_s;
-      sum[i] = 0.0f;
+      if (io.episode_rew_out) at(io.episode_rew_out, sbase + (u32)i) = at(io.episode_sums, sbase + (u32)i) / c.max_episode_length_s;
+      at(io.episode_sums, sbase + (u32)i) = 0.0f;
     }
     if (lane == 0) {
       misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
@@ -998,8 +1037,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       feat[o_q + d] = q[d] - c.default_dof_pos[d];
       feat[o_qd + d] = qd[d];
       feat[o_a + d] = act[d];
-      feat[o_kp + d] = io.kp_scale[eD + d];
-      feat[o_kd + d] = io.kd_scale[eD + d];
+      feat[o_kp + d] = at(io.kp_scale, eD + d);
+      feat[o_kd + d] = at(io.kd_scale, eD + d);
     }
     if (lane == 0) {
       feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
@@ -1027,8 +1066,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
         const int nn = (int)mg[32];
         const uint32_t* noisy = mg + 33;
         const uint16_t* m16 = (const uint16_t*)(noisy + nn);
-        float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
         const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
+        float* __restrict__ const outg = io.obs[g];                 // uniform base; `ob` + element = 32-bit offset of this env's row
+        const u32 ob = (u32)env * (u32)pitch_g;
         if (((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) == 0)) {
           // rows start 8-byte aligned: a lane takes PAIRS of elements — one 32-bit LDS word holds both map entries, one 8-byte store both values
           const uint32_t* m32 = (const uint32_t*)m16;
@@ -1060,9 +1100,9 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
               if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
               if (pad_ok) {
                 const int jj = (j + 1 < dim) ? j : ((j < dim) ? j : pitch_g - 2);      // a trailing odd element writes its pair's second half into the padding
-                *reinterpret_cast<float2*>(out + jj) = make_float2(va, vb);
-              } else if (j + 1 < dim) *reinterpret_cast<float2*>(out + j) = make_float2(va, vb);
-              else if (j < dim) out[j] = va;
+                *reinterpret_cast<float2*>(&at(outg, ob + (u32)jj)) = make_float2(va, vb);
+              } else if (j + 1 < dim) *reinterpret_cast<float2*>(&at(outg, ob + (u32)j)) = make_float2(va, vb);
+              else if (j < dim) at(outg, ob + (u32)j) = va;
             }
 #ifdef PBHC_STAMPS
             if (g == 1 && p0 == lane) STAMP(22);
@@ -1081,7 +1121,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
             const int j = j0 + u * PBHC_G;
             float v = x[u] * sc[u];
             if (clip) v = clampf(v, -clipobs, clipobs);
-            if (j < dim) out[j] = v;
+            if (j < dim) at(outg, ob + (u32)j) = v;
           }
         }
         STAMP(12 + 2 * g);
@@ -1096,7 +1136,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
               const int seg = w >> 12;
               float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
               if (clip) v = clampf(v, -clipobs, clipobs);
-              out[e & 0xFFFFu] = v;
+              at(outg, ob + (e & 0xFFFFu)) = v;
             }
         }
         STAMP(13 + 2 * g);
@@ -1134,22 +1174,23 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
     STAMP(9);
     // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
     for (int d = lane; d < D; d += PBHC_G) {
-      io.actions[eD + d] = act[d];
-      io.last_actions[eD + d] = act[d];
-      io.actions_after_delay[eD + d] = actd[d];
-      io.torques[eD + d] = tau[d];
-      io.dof_state[(eD + d) * 2] = q[d];
-      io.dof_state[(eD + d) * 2 + 1] = qd[d];
-      io.last_dof_pos[eD + d] = q[d];
-      io.last_dof_vel[eD + d] = qd[d];
+      at(io.actions, eD + d) = act[d];
+      at(io.last_actions, eD + d) = act[d];
+      at(io.actions_after_delay, eD + d) = actd[d];
+      at(io.torques, eD + d) = tau[d];
+      at(io.dof_state, (eD + d) * 2) = q[d];
+      at(io.dof_state, (eD + d) * 2 + 1) = qd[d];
+      at(io.last_dof_pos, eD + d) = q[d];
+      at(io.last_dof_vel, eD + d) = qd[d];
     }
-    if (lane < 13) io.root_states[(size_t)env * 13 + lane] = root[lane];
+    if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];
     if (lane < NF) {
-      io.feet_air_time[(size_t)env * NF + lane] = misc[M_FAT0 + lane];
-      io.contacts[(size_t)env * NF + lane] = misc[M_CONTACT0 + lane];
-      io.contacts_filt[(size_t)env * NF + lane] = misc[M_CFILT0 + lane];
-      io.last_contacts[(size_t)env * NF + lane] = misc[M_CONTACT0 + lane];
-      io.last_contacts_filt[(size_t)env * NF + lane] = misc[M_CFILT0 + lane];
+      const u32 fo = (u32)env * (u32)NF + (u32)lane;
+      at(io.feet_air_time, fo) = misc[M_FAT0 + lane];
+      at(io.contacts, fo) = misc[M_CONTACT0 + lane];
+      at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];
+      at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];
+      at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];
     }
     if (lane == 0) {
       io.episode_length_buf[env] = (long long)misc[M_EPLEN];
@@ -1184,7 +1225,7 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   if (threadIdx.x < PBHC_NP) {
     float v = 0.0f;
     for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];
-    partials[(size_t)blockIdx.x * PBHC_NP + threadIdx.x] = v;
+    partials[(u32)blockIdx.x * (u32)PBHC_NP + threadIdx.x] = v;
   }
   STAMP(11);
   WG_STAMP(1);
@@ -1654,6 +1695,8 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   ARG_CHECK(cfg->queue_len >= 1 && cfg->queue_len <= PBHC_MAX_QUEUE);
   ARG_CHECK(tbl->row == 2 * D + 2 + 13 * Bx && tbl->frames && tbl->num_motions >= 1);
   ARG_CHECK(cfg->feat_dim > 0 && cfg->feat_dim < 16384);
+  // the step kernel addresses every per-env tensor with 32-bit element offsets from its base pointer
+  ARG_CHECK((uint64_t)cfg->num_envs * (uint64_t)(cfg->skel.num_bodies * 13 > cfg->hist_dim + 64 ? cfg->skel.num_bodies * 13 : cfg->hist_dim + 64) < (1ull << 30));
   for (int g = 0; g < cfg->num_groups; ++g) ARG_CHECK(cfg->groups[g].dim > 0 && cfg->groups[g].src && cfg->groups[g].scale && cfg->groups[g].noise);
   for (int i = 0; i < PBHC_F_NUM; ++i) ARG_CHECK(cfg->feat_off[i] >= 0 && cfg->feat_off[i] < cfg->feat_dim);
   PbhcEnv* e = new (std::nothrow) PbhcEnv();
@@ -1752,7 +1795,10 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(io->motion_start_times && io->motion_len && io->end_time_ratio_buf && io->episode_sums && io->hist);
   ARG_CHECK(io->episode_length_buf && io->last_episode_length_buf && io->reset_buf && io->action_delay_idx && io->motion_ids && io->time_out_buf);
   ARG_CHECK(io->env_origins && io->dr_base_com && io->dr_link_mass && io->dr_friction && io->rew_buf);
-  for (int g = 0; g < e->cfg.num_groups; ++g) ARG_CHECK(io->obs[g] != nullptr && (io->obs_pitch[g] == 0 || io->obs_pitch[g] >= e->cfg.groups[g].pitch));
+  for (int g = 0; g < e->cfg.num_groups; ++g) {
+    ARG_CHECK(io->obs[g] != nullptr && (io->obs_pitch[g] == 0 || io->obs_pitch[g] >= e->cfg.groups[g].pitch));
+    ARG_CHECK((uint64_t)e->cfg.num_envs * (uint64_t)(io->obs_pitch[g] ? io->obs_pitch[g] : e->cfg.groups[g].pitch) < (1ull << 30));   // 32-bit row offsets in the kernel
+  }
   ARG_CHECK(io->hist_pitch == 0 || io->hist_pitch >= e->cfg.hist_dim);
   hipStream_t st = (hipStream_t)stream;
   const int slot = e->prof_count % PBHC_PROFILE_RING;

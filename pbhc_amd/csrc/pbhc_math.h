@@ -63,6 +63,14 @@ __device__ __forceinline__ f4 quat_unit(f4 q) {
   n = fmaxf(n, 1e-9f);
   return mk4(q.x / n, q.y / n, q.z / n, q.w / n);
 }
+// The same normalisation with ONE hardware reciprocal (v_rcp_f32, 1 ulp) instead of four correctly rounded divisions (~10 instructions
+// each): for the sim-stub's rigid-body chain — Isaac Gym's job in the reference, so there is no reference op order to mirror — where
+// quat_unit runs once per joint of every body's chain.  Differs from quat_unit by <= 2 ulp per component.
+__device__ __forceinline__ f4 quat_unit_fast(f4 q) {
+  float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
+  const float r = __builtin_amdgcn_rcpf(n);
+  return mk4(q.x * r, q.y * r, q.z * r, q.w * r);
+}
 __device__ __forceinline__ f3 normalize3(f3 v) {
   float n = fmaxf(norm3(v), 1e-9f);
   return mk3(v.x / n, v.y / n, v.z / n);
