@@ -36,12 +36,14 @@ thread_local char g_pbhc_err[512] = "";
 // Diagnostic build only (-DPBHC_STAMPS, libpbhc_hip_stamps.so): shader-clock stamps of workgroup 0 at the phase
 // boundaries of k_env_step, written to a buffer nothing else reads.  The product build contains none of this.
 #ifdef PBHC_STAMPS
-__device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_stamps[64];                  // [0,32): role A (thread 0 of workgroup 0), [32,64): role B (thread 128)
 __device__ unsigned long long g_wg_times[2 * 4096];          // [workgroup][entry, exit] on the constant 100 MHz clock (comparable across CUs)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#define STAMPB(i) do { if (threadIdx.x == 128 && blockIdx.x == 0) g_stamps[32 + (i)] = clock64(); } while (0)
 #define WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg_times[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPB(i) do { } while (0)
 #define WG_STAMP(k) do { } while (0)
 #endif
 #define HIP_CHECK(x)                                                                          \
@@ -115,13 +117,19 @@ enum {
   M_TIME = 4, M_PHASE, M_MLEN, M_START, M_RESET, M_TIMEOUT, M_EPLEN, M_CONTACT0, M_CONTACT1, M_CFILT0, M_CFILT1,
   M_RCONTACT0, M_RCONTACT1, M_GRAV, M_FAR, M_END, M_TOUT_LEN, M_LASTEP, M_NEWSTART, M_DELAY, M_FAT0, M_FAT1,
   M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ,
-  M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI                      // general tracking: termination causes, anchor z / gravity-z differences
+  M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI,                     // general tracking: termination causes, anchor z / gravity-z differences
+  M_CLIPCNT                                                     // clipped actions of this step (role B -> reduction row)
 };
+static_assert(M_CLIPCNT < 48, "MISC region");
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
 // flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
 // data through LDS only; same-address global accesses stay inside one wave, where program order holds.
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// Hand-off through LDS between lanes of ONE wave (the step kernel keeps an env's lanes inside a wave): the hardware executes a wave's DS
+// instructions in issue order, so no instruction is needed — but the COMPILER must not move LDS accesses across the hand-off (without this
+// it forwards `if (lane == 0) x[i] = v;  ... = x[i]` per thread: the other lanes' load is hoisted above the store).
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
 
 // Reductions over the 32 lanes of an env (half a wave64), every lane receiving the result.  `__shfl_xor` lowers to ds_bpermute_b32 — an LDS
 // round trip plus an address VGPR per step, five steps per reduction, ~30 reductions per env step.  The DPP forms below stay in the VALU:
@@ -268,6 +276,62 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
   LDS_BARRIER();
 }
 
+// The same for ONE wave (the step kernel, where the 32 lanes of an env belong to one wave): no workgroup barrier.  A wave's DS instructions
+// execute in issue order, so the relative joint quaternions written in step 1 are visible to every lane's chain walk, and they can live in
+// `bq` itself: the world quaternions are stored only after EVERY walk of the wave has read its last relative one (up to two bodies per lane,
+// results held in registers until then).
+__device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, int lane, bool valid, const float* root, const float* q, const float* qd,
+                                             float* bp, float* bq, float* bv, float* bw) {
+  static_assert(PBHC_MAX_BODIES <= 2 * PBHC_G, "two bodies per lane");
+  float* relq = bq;
+  if (valid)
+    for (int b = 1 + lane; b < B; b += PBHC_G) {
+      const float* k = skc + b * SKC_W;
+      f3 axis = ld3(k + 7);
+      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_axis(q[b - 1], axis)));
+    }
+  WAVE_LDS_FENCE();
+  if (!valid) return;
+  f3 P[2], V[2], W[2];
+  f4 R[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int b = lane + it * PBHC_G;
+    P[it] = mk3(0, 0, 0); V[it] = P[it]; W[it] = P[it]; R[it] = mk4(0, 0, 0, 1);
+    if (b < Bx) {
+      const float* kb = skc + b * SKC_W;
+      const int n = __float_as_int(kb[10]);
+      f3 p = ld3(root), v = ld3(root + 7), w = ld3(root + 10);
+      f4 r = ld4(root + 3);
+      for (int i = 0; i < n; ++i) {
+        const int a = __float_as_int(kb[11 + i]);
+        const float* ka = skc + a * SKC_W;
+        f3 axis = ld3(ka + 7);
+        f3 pn = add3(p, quat_rotate(r, ld3(ka)));
+        f4 rn = quat_unit_fast(quat_mul(r, ld4(relq + 4 * a)));
+        f3 wn = add3(w, mul3(quat_rotate(rn, axis), qd[a - 1]));
+        v = add3(v, cross3(w, sub3(pn, p)));
+        p = pn; r = rn; w = wn;
+      }
+      if (b >= B) {
+        f3 off = ld3(kb);
+        f4 eq = ld4(kb + 3);
+        f3 pe = add3(quat_rotate(eq, quat_rotate(r, off)), p);
+        v = add3(v, cross3(w, off));
+        r = quat_mul(r, eq);
+        p = pe;
+      }
+      P[it] = p; V[it] = v; W[it] = w; R[it] = r;
+    }
+  }
+  WAVE_LDS_FENCE();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int b = lane + it * PBHC_G;
+    if (b < Bx) { st3(bp + 3 * b, P[it]); st4(bq + 4 * b, R[it]); st3(bv + 3 * b, V[it]); st3(bw + 3 * b, W[it]); }
+  }
+}
+
 // ---- frame blend (motion_lib_base.py:503-513) -------------------------------------------------
 __device__ __forceinline__ void frame_blend(float t, float len, int nf, float dt, int* f0, int* f1, float* blend) {
   float phase = clampf(t / len, 0.0f, 1.0f);
@@ -317,21 +381,77 @@ __device__ __forceinline__ void motion_lookup_meta(const PbhcMotionTable& tbl, i
 // =================================================================================================
 //  k_env_step: LeggedRobotBase.step (legged_robot_base.py:239-338) for LeggedRobotMotionTracking
 // =================================================================================================
+// One launch, 256-thread workgroups = 4 waves for PBHC_EPB = 4 envs, 32 lanes (half a wave64) per env and ROLE:
+//   role A "dynamics"    (waves 0,1; envs {0,1} / {2,3}): replay frame -> rigid-body FK -> body differences + reductions -> termination ->
+//                        rewards -> reset of terminated envs -> post-reset features -> state write-back.  This is the dependent chain
+//                        that sets the kernel's duration.
+//   role B "reference"   (waves 2,3; the same envs): everything that does not depend on the FK of the new frame — pre-physics step +
+//                        torques, per-env scalars (heading, base velocities, gravity, contacts), reference-frame lookup (lerp / slerp),
+//                        future reference targets (general tracking), the joint-space halves of the reductions, the optional state
+//                        outputs, and the observation elements whose sources are ready before the chain ends (history: ~80 % of them).
+// The round-1 kernel ran both roles back to back in ONE wave per env pair (2 waves per SIMD on the chip, ~65 k cycles per wave, of
+// which the observation write-out and the load phase were 45 %); split, the chain is ~40 % shorter and a SIMD holds 4 waves.
+// All LDS traffic of an env stays inside ITS two waves: within a wave the hardware executes DS instructions in order, so phases of
+// one role need no barrier at all; the five workgroup barriers below are the points where the roles exchange data.
 extern __shared__ float smem[];
+
+#define PBHC_TPB (2 * PBHC_G * PBHC_EPB)                   // threads per workgroup of k_env_step: two roles x 32 lanes x 4 envs
+#define PBHC_HREG (384 / PBHC_G)                           // history words per lane held in registers (hist_dim <= 384)
+#define PBHC_MAP_HDR 34                                    // compact map block: [16 scales][16 noises][nn][n_runs0 | n_runs1 << 8 | n_runs2 << 16][runs][noisy][pairs]
+
+// Observation elements of group block `mg` whose pair runs are [r0, r1): out[j] = clip(feat[src[j]] * scale[seg[j]]) for the element pairs of
+// each run (a run = consecutive pairs of one readiness class, built on the host).  `nl` lanes (32 or 64) of this env cooperate, `l` is this
+// lane's index among them.  Lanes past the end of a run recompute its last pair and store the same value to the same address (branch-free).
+template <int BATCH>
+__device__ __forceinline__ void obs_write_runs(const uint32_t* mg, int r0, int r1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
+                                               int dim, int pitch_g, int clip, float clipobs) {
+  const float* segs = (const float*)mg;
+  const int nn = (int)mg[32];
+  const uint32_t rc = mg[33];
+  const int nruns = (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu) + ((rc >> 16) & 0xFFu));
+  const uint32_t* runs = mg + PBHC_MAP_HDR;
+  const uint32_t* m32 = runs + nruns + nn;
+  const bool pad_ok = pitch_g >= dim + 1;                  // a trailing odd element stores its pair's second half into the row padding
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t rw = runs[r];
+    const int ps = (int)(rw & 0xFFFFu), pe = ps + (int)(rw >> 16) - 1;
+    for (int p0 = ps + l; p0 <= pe; p0 += BATCH * nl) {
+      uint32_t w[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) w[u] = m32[min(p0 + u * nl, pe)];
+      float xa[BATCH], xb[BATCH], sa[BATCH], sb[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const uint32_t lo = w[u] & 0xFFFFu, hi = w[u] >> 16;
+        xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
+        xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int j = 2 * min(p0 + u * nl, pe);
+        float va = xa[u] * sa[u], vb = xb[u] * sb[u];
+        if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
+        if (j + 1 < dim || pad_ok) *reinterpret_cast<float2*>(&at(outg, ob + (unsigned int)j)) = make_float2(va, vb);
+        else at(outg, ob + (unsigned int)j) = va;
+      }
+    }
+  }
+}
 
 // MODE 0: LeggedRobotMotionTracking (motion_tracking.py), MODE 1: LeggedRobotGeneralTracking (general_tracking.py)
 template <int MODE>
+// waves per SIMD the register allocation must allow: the v1 kernel's LDS footprint admits 4 workgroups = 16 waves per CU (<= 128 VGPRs);
+// general tracking holds twice the LDS per env (2 workgroups per CU)
 #ifndef PBHC_MIN_WAVES
-#define PBHC_MIN_WAVES 1
+#define PBHC_MIN_WAVES (MODE ? 2 : 4)
 #endif
-__global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
+__global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
   // whose scalars fold into the instruction stream; pointers, seed, env count and reference yaw always come from `rt`.
   // The config is read through the CONSTANT address space: the kernel never writes it, and saying so lets the compiler keep its
-  // scalars in SGPRs across the kernel's global stores (through a plain global pointer every `c.x` after a store is reloaded and
-  // waited for with s_waitcnt lgkmcnt(0), which also drains the LDS queue: ~8 reloads per batch of 8 stores in the observation phase).
+  // scalars in SGPRs across the kernel's global stores.
   WG_STAMP(0);
   typedef const PbhcEnvConfig __attribute__((address_space(4))) ConstCfg;
   ConstCfg& rt = *(ConstCfg*)cfgp;
@@ -342,7 +462,10 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
 #endif
   const auto& sk = c.skel;
   const int N = rt.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
-  const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G;
+  const int lane = threadIdx.x & (PBHC_G - 1);
+  const int wave = threadIdx.x >> 6;
+  const bool roleB = wave >= 2;                                            // wave-uniform
+  const int le = ((wave & 1) << 1) | ((threadIdx.x >> 5) & 1);             // env slot of this half-wave in the workgroup
   const int env = blockIdx.x * PBHC_EPB + le;
   const bool valid = env < N;
   float* S = smem + (size_t)le * lds_stride;
@@ -354,9 +477,8 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   float *red = S + lo.red, *feat = S + lo.feat;
   // replay frame of this step: named by the host, or read from the device-side cursor
   const size_t fk = (size_t)(io.frame_index >= 0 ? io.frame_index : io.frame_cursor[0] % io.num_frames) * (size_t)N;
-  // Addressing: every per-env tensor is indexed as <uniform 64-bit base> + <32-bit unsigned lane offset>, which the compiler emits as the
-  // SGPR-base form of global_load / global_store (one offset VGPR, no 64-bit VALU address arithmetic; pbhc_env_create checks that
-  // num_envs x row pitch stays below 2^30 elements).
+  // Addressing: every per-env tensor is indexed as <uniform 64-bit base> + <32-bit unsigned lane offset> (`at`), which the compiler emits
+  // as the SGPR-base form of global_load / global_store (pbhc_env_create / pbhc_env_step check that num_envs x row pitch < 2^30 elements).
   typedef unsigned int u32;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
@@ -364,118 +486,138 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
   uint32_t* mapl = (uint32_t*)(blockpart + PBHC_EPB * PBHC_NP);   // [map_lds_words] compact observation maps, shared by the workgroup
   const float dt = c.dt;
   const u32 eD = (u32)env * (u32)D;
-  STAMP(0);
-  float skreg[SKC_REGS];
-  stage_skeleton_load(skc_img, Bx * SKC_W, skreg);
-  // compact observation maps: loads ISSUED here (registers), written to LDS at the end of the prologue (consumed in phase I)
-#define PBHC_MAPREG (MODE ? 16 : 8)
-  uint32_t mreg[PBHC_MAPREG];
-  const int map_words = c.map_lds_words;
-  if (map_words > 0) {
-#pragma unroll
-    for (int u = 0; u < PBHC_MAPREG; ++u) {
-      const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB);
-      mreg[u] = i < map_words ? map_img[i] : 0u;
-    }
-  }
-
-  // ---------------- prologue + phase A: every global load that does not depend on this step's compute is ISSUED here,
-  // in the order it is needed (frame q / q-dot / root first: the FK chain waits only for them; the history, the per-dof
-  // state and the reference rows stay in flight behind the chain).  _pre_physics_step (motion_tracking.py:749-768) and the
-  // torques from the pre-step state (legged_robot_base.py:795-838) are computed when their operands land.
-  // All lanes of an env compute the reference-frame address redundantly (no LDS round trip).
-#define PBHC_HREG (384 / PBHC_G)                        // history words per lane held in registers (hist_dim <= 384)
-  long long ep1 = 0;
-  float start = 0.0f, mlen_env = 0.0f, tref = 0.0f, blend = 0.0f;
-  int mid = 0;
-  f3 origin = mk3(0.f, 0.f, 0.f);
-  f3 rp0 = mk3(0, 0, 0), rp1 = rp0, rv0 = rp0, rv1 = rp0, rw0 = rp0, rw1 = rp0;
-  f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
-  float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
-  float pf_last_act = 0, pf_last_qd = 0, pf_sum = 0, pf_tscale = 0, pf_sigma = 1.0f, pf_termsum = 0;
-  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0, pf_tsrc = -1;
-  const float pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE], pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
-  const float pf_soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], pf_soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], pf_soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
-  const float pf_noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
-  const float* r0 = nullptr;
-  const float* r1 = nullptr;
-  float m_len = tbl.single_len, m_dt = tbl.single_dt;          // this env's clip: length, frame time, frames, first table row
-  int m_nf = tbl.single_num_frames, m_row0 = 0;
-  float clipcnt = 0.0f;
+  const int envc = valid ? env : N - 1;                       // a tail workgroup's missing envs load env N-1 (and store nothing)
+  const u32 eDc = (u32)envc * (u32)D;
+  const int d = lane;                                         // D <= 32: one dof per lane
+  const int dc = min(lane, D - 1);
   const int hoff = c.feat_off[PBHC_F_HISTORY];
   const int Q = c.queue_len;
-  // Branch-free load section: every index is clamped into range instead of predicating the load, so that the whole section is one
-  // basic block and the loads issue back to back (a predicated load costs a branch, a zero-initialised phi and, in practice, an early
-  // s_waitcnt when the allocator recycles the register of a load still in flight).  Out-of-range lanes read a neighbour's value and
-  // never use it; a tail workgroup's missing envs read env N-1.
-  const int envc = valid ? env : N - 1;
-  const u32 eDc = (u32)envc * (u32)D;
-  const int d = lane;                         // D <= 32: one dof per lane
-  const int dc = min(lane, D - 1);
-  float sumrow = 0.0f;                        // episode_sums[env][lane]; a term's own column is fetched with a shuffle in phase F
-  // (1) what the FK chain needs
-  const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
-  const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
-  // (2) env scalars -> reference-frame address
-  ep1 = io.episode_length_buf[envc] + 1;
-  start = io.motion_start_times[envc];
-  mlen_env = io.motion_len[envc];
-  mid = (int)io.motion_ids[envc];
-  origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u));
-  // (3) everything else of this step, into registers
-  float hreg[PBHC_HREG];
+  const int map_words = c.map_lds_words;
+  const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
+  STAMP(0);
+
+  // ---------------- shared staging: skeleton constants + compact observation maps, loads issued first ----------------------------
+#define SKC_REGS2 ((SKC_WORDS + PBHC_TPB - 1) / PBHC_TPB)
+#define PBHC_MAPREG (MODE ? 8 : 4)
+  float skreg[SKC_REGS2];
   {
-    const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
-    const int hlast = c.hist_dim - 1;
+    const int n = Bx * SKC_W;
 #pragma unroll
-    for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+    for (int u = 0; u < SKC_REGS2; ++u) { const int i = threadIdx.x + u * PBHC_TPB; skreg[u] = skc_img[min(i, n - 1)]; }
   }
-  float creg[128 / PBHC_G];
-  {
-    const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
-    const u32 cbase = (u32)envc * (u32)(B * 3);
+  uint32_t mreg[PBHC_MAPREG];
+  if (map_words > 0) {
 #pragma unroll
-    for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
+    for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min((int)threadIdx.x + u * PBHC_TPB, map_words - 1)];
   }
-  float qold[PBHC_MAX_QUEUE];
-  const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
-#pragma unroll
-  for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
-  const float a_in = at(io.actions_in, eDc + dc);
-  const float qp = at(io.dof_state, (eDc + dc) * 2), qv = at(io.dof_state, (eDc + dc) * 2 + 1);
-  const float kp = at(io.kp_scale, eDc + dc), kd = at(io.kd_scale, eDc + dc), rfs = at(io.rfi_lim_scale, eDc + dc), ras = at(io.rao_scale, eDc + dc);
-  const float u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
-  pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
-  const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
-  const float bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
-  const int nlm = max(c.dr_link_mass_dim, 1);
-  const float lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
-  const float combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
-  const float fric = io.dr_friction[envc];
-  const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
-  {
-    const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
-    pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_]; pf_tsrc = c.term_src[tl_];
-    sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));
-    pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
+
+  // ---------------- per-env scalars both roles need (tiny, redundant loads) ------------------------------------------------------
+  const long long ep1 = io.episode_length_buf[envc] + 1;
+  const float start = io.motion_start_times[envc];
+  const int mid = (int)io.motion_ids[envc];
+  const float mlen_env = io.motion_len[envc];
+  const f3 origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u));
+  float m_len = tbl.single_len, m_dt = tbl.single_dt;          // this env's clip: length, frame time, frames, first table row
+  int m_nf = tbl.single_num_frames, m_row0 = 0;
+  if (tbl.num_motions != 1) {                                  // single clip: its meta travels in the kernel arguments
+    m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid];
   }
-  float u_rfi = 0.5f;
-  if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
-  if (valid) {
-    // ---- consume (1): frame state -> LDS for the FK chain
-    if (d < D) { q[d] = fq; qd[d] = fqd; }
-    if (lane < 13) root[lane] = froot;
-    // ---- consume (2): reference rows, issued now, consumed after the FK chain
-    tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
-    int f0, f1;
-    if (tbl.num_motions != 1) {                                 // single clip: its meta travels in the kernel arguments
-      m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid];
-    }
-    frame_blend(tref, m_len, m_nf, m_dt, &f0, &f1, &blend);
-    r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
-    r1 = tbl.frames + (size_t)(m_row0 + f1) * tbl.row;
-    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
+
+  // role-A registers that live across phases
+  float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, etr_old = 0.0f;
+  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0, pf_tsrc = -1;
+  long long adelay = 0;
+  // role-B registers that live across phases
+  float pf_last_act = 0.0f, pf_last_qd = 0.0f;
+  float tref = 0.0f;
+  // reductions of the two roles (role A: body sums, role B: joint-space sums); declared here, reduced after their loops
+  float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
+  float s_key = 0, s_keyn = 0, s_lkey = 0, s_lkeyn = 0, s_lkrot = 0, s_kvel = 0, s_kang = 0, s_lupn = 0, s_llon = 0, s_lvrn = 0, s_bodyz = 0;
+
+  // staging stores of the shared images + bar0.  Expanded inside EACH role's path, so that the wait for the image loads (the first in the
+  // wave's queue) is counted against that role's own later loads, which stay in flight across the barrier.
+#define STAGE_AND_BAR0()                                                                                               \
+  do {                                                                                                                 \
+    const int n_ = Bx * SKC_W;                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < SKC_REGS2; ++u) { const int i = threadIdx.x + u * PBHC_TPB; if (i < n_) skc[i] = skreg[u]; } \
+    if (map_words > 0) {                                                                                               \
+      _Pragma("unroll") for (int u = 0; u < PBHC_MAPREG; ++u) { const int i = threadIdx.x + u * PBHC_TPB; if (i < map_words) mapl[i] = mreg[u]; } \
+      for (int i = threadIdx.x + PBHC_MAPREG * PBHC_TPB; i < map_words; i += PBHC_TPB) mapl[i] = map_img[i];           \
+    }                                                                                                                  \
+    LDS_BARRIER();                                                                                                     \
+  } while (0)
+
+  if (!roleB) {
+    // =============== role A, interval 0: the replay frame -> LDS (what the FK chain waits for), then the loads of its later phases
+    const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
+    const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
+      const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
+      pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_]; pf_tsrc = c.term_src[tl_];
+      sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));   // a term's own column: shuffle in phase F
+      pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
+      pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE]; pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
+      kpA = at(io.kp_scale, eDc + dc); kdA = at(io.kd_scale, eDc + dc);                // phase H (a reset replaces them in registers)
+      adelay = io.action_delay_idx[envc];
+      etr_old = io.end_time_ratio_buf[envc];
+    }
+    STAGE_AND_BAR0();                                          // bar0: skeleton constants + maps staged
+    STAMP(1);
+    if (valid) {
+      if (d < D) { q[d] = fq; qd[d] = fqd; }
+      if (lane < 13) root[lane] = froot;
+    }
+    WAVE_LDS_FENCE();
+    // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
+    fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+    STAMP(2);
+  } else {
+    // =============== role B, interval 0: every other load of the step, issued back to back (indices clamped, not predicated: one basic
+    // block), then _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
+    float hreg[PBHC_HREG];
+    {
+      const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
+      const int hlast = c.hist_dim - 1;
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+    }
+    float creg[128 / PBHC_G];
+    {
+      const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
+      const u32 cbase = (u32)envc * (u32)(B * 3);
+#pragma unroll
+      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
+    }
+    const float broot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));     // B's own copy of the root state (phase C)
+    float qold[PBHC_MAX_QUEUE];
+    const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
+#pragma unroll
+    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
+    const float a_in = at(io.actions_in, eDc + dc);
+    const float qp = at(io.dof_state, (eDc + dc) * 2), qv = at(io.dof_state, (eDc + dc) * 2 + 1);
+    const float kp = at(io.kp_scale, eDc + dc), kd = at(io.kd_scale, eDc + dc), rfs = at(io.rfi_lim_scale, eDc + dc), ras = at(io.rao_scale, eDc + dc);
+    const float u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
+    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
+    const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
+    const float bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
+    const int nlm = max(c.dr_link_mass_dim, 1);
+    const float lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
+    const float combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
+    const float fric = io.dr_friction[envc];
+    const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
+    // reference rows: address from the env scalars, loads issued now, consumed in phase D
+    float blend = 0.0f;
+    const float* r0 = tbl.frames;
+    const float* r1 = tbl.frames;
+    f3 rp0 = mk3(0, 0, 0), rp1 = rp0, rv0 = rp0, rv1 = rp0, rw0 = rp0, rw1 = rp0;
+    f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
+    float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
+    tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
+    {
+      int f0, f1;
+      frame_blend(tref, m_len, m_nf, m_dt, &f0, &f1, &blend);
+      r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
+      r1 = tbl.frames + (size_t)(m_row0 + f1) * tbl.row;
       const int lb = min(lane, Bx - 1), lc = min(lane, 1);
       rp0 = ld3(r0 + o_pos + 3 * lb); rp1 = ld3(r1 + o_pos + 3 * lb);
       rq0 = ld4(r0 + o_rot + 4 * lb); rq1 = ld4(r1 + o_rot + 4 * lb);
@@ -484,648 +626,629 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       rd0 = r0[dc]; rd1 = r1[dc]; rdv0 = r0[D + dc]; rdv1 = r1[D + dc];
       rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
-
-    // ---- consume (3): LDS staging + torques
+    float u_rfi = 0.5f;
+    if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
+    STAGE_AND_BAR0();                                          // bar0: skeleton constants + maps staged
+    float clipcnt = 0.0f;
+    if (valid) {
 #pragma unroll
-    for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
-    if (c.hist_dim > PBHC_HREG * PBHC_G)
-      copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
+      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
+      if (c.hist_dim > PBHC_HREG * PBHC_G)
+        copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
 #pragma unroll
-    for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
-    if (d < D) {
-      const float tl = c.torque_limits[d];
-      const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
-      if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
-      act[d] = a;
-      float delayed = a;
-      if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
+      for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
+      if (lane < 13) red[lane] = broot;                       // scratch until bar1 (role A first writes `red` after it)
+      if (d < D) {
+        const float tl = c.torque_limits[d];
+        const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
+        if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
+        act[d] = a;
+        float delayed = a;
+        if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
 #pragma unroll
-        for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
-          if (k < Q) {
-            float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
-            at(io.action_queue, qoff + (u32)(k * D)) = nv;
-            if (k == didx) delayed = nv;
-          }
-      }
-      actd[d] = delayed;
-      float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
-      if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
-      if (c.use_rao) tq = tq + ras * tl;
-      if (c.clip_torques) tq = clampf(tq, -tl, tl);
-      tau[d] = tq;
-    }
-    if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
-    if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
-    if (lane == 0) {
-      feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
-      feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
-      if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
-    }
-    if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
-    if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
-  }
-  clipcnt = group_sum(clipcnt);
-  stage_skeleton_store(Bx, skc, skreg);
-  if (map_words > 0) {
-#pragma unroll
-    for (int u = 0; u < PBHC_MAPREG; ++u) {
-      const int i = threadIdx.x + u * (PBHC_G * PBHC_EPB);
-      if (i < map_words) mapl[i] = mreg[u];
-    }
-    for (int i = threadIdx.x + PBHC_MAPREG * (PBHC_G * PBHC_EPB); i < map_words; i += PBHC_G * PBHC_EPB) mapl[i] = map_img[i];
-  }
-  LDS_BARRIER();
-
-  STAMP(1);
-  // ---------------- phase B: rigid-body state of the new frame (sim-stub FK) -------------------
-  fk_walk(skc, B, Bx, lane, valid, root, q, qd, rq /* scratch: relq, overwritten by the reference lookup later */, bp, bq, bv, bw);
-
-  STAMP(2);
-  // ---------------- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference
-  // frame motion_tracking.py:554,588) ----------------------------------------------------------
-  if (valid) {
-    f4 rq4 = ld4(root + 3);
-    if (lane == 0) {
-      misc[M_EPLEN] = (float)ep1;
-      const float mlen = mlen_env;
-      misc[M_START] = start; misc[M_MLEN] = mlen;
-      const float t = tref;
-      misc[M_TIME] = t;
-      misc[M_PHASE] = t / mlen;
-      feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
-      f3 e = euler_xyz(rq4);
-      misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
-      feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
-      if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
-      st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
-    } else if (lane <= 3) {
-      // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
-      const f3 vin = lane == 1 ? ld3(root + 7) : (lane == 2 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
-      const f3 vo = quat_rotate_inverse(rq4, vin);
-      const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
-      st3(feat + off, vo);
-      if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
-    } else if (lane >= 4 && lane < 4 + NF) {
-      int f = lane - 4;
-      float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
-      float lastc = misc[M_LASTC0 + f];
-      misc[M_CONTACT0 + f] = cn;
-      misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
-    }
-  }
-  LDS_BARRIER();
-
-  STAMP(3);
-  // ---------------- phase D: reference frame (a6) ------------------------------------------------
-  // lerp / slerp of the two prefetched frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
-  if (valid) {
-    const float a = 1.0f - blend, bb = blend;
-    if (lane < D) { rdof[lane] = a * rd0 + bb * rd1; rdofv[lane] = a * rdv0 + bb * rdv1; }
-    if (lane < 2) {
-      misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
-      if (MODE) feat[c.feat_off[PBHC_F_REF_CONTACT_MASK] + lane] = a * rc0 + bb * rc1;
-    }
-    if (lane < Bx) {
-      st3(rp + 3 * lane, mk3(a * rp0.x + bb * rp1.x + origin.x, a * rp0.y + bb * rp1.y + origin.y, a * rp0.z + bb * rp1.z + origin.z));
-      st4(rq + 4 * lane, slerp(rq0, rq1, bb));
-      st3(rv + 3 * lane, mk3(a * rv0.x + bb * rv1.x, a * rv0.y + bb * rv1.y, a * rv0.z + bb * rv1.z));
-      st3(rw + 3 * lane, mk3(a * rw0.x + bb * rw1.x, a * rw0.y + bb * rw1.y, a * rw0.z + bb * rw1.z));
-    }
-    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
-    for (int i = lane + PBHC_G; i < Bx; i += PBHC_G) {            // bodies beyond the 32 lanes (29-DoF robots)
-      f3 p0 = ld3(r0 + o_pos + 3 * i), p1 = ld3(r1 + o_pos + 3 * i);
-      st3(rp + 3 * i, mk3(a * p0.x + bb * p1.x + origin.x, a * p0.y + bb * p1.y + origin.y, a * p0.z + bb * p1.z + origin.z));
-      st4(rq + 4 * i, slerp(ld4(r0 + o_rot + 4 * i), ld4(r1 + o_rot + 4 * i), bb));
-      f3 v0 = ld3(r0 + o_vel + 3 * i), v1 = ld3(r1 + o_vel + 3 * i);
-      st3(rv + 3 * i, mk3(a * v0.x + bb * v1.x, a * v0.y + bb * v1.y, a * v0.z + bb * v1.z));
-      f3 w0 = ld3(r0 + o_ang + 3 * i), w1 = ld3(r1 + o_ang + 3 * i);
-      st3(rw + 3 * i, mk3(a * w0.x + bb * w1.x, a * w0.y + bb * w1.y, a * w0.z + bb * w1.z));
-    }
-  }
-  LDS_BARRIER();
-
-  STAMP(4);
-  // ---------------- phase E: tracking differences + lane-parallel partial sums -------------------
-  // (motion_tracking.py:645-731 and the reductions of the _reward_* terms)
-  float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
-  float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
-  float s_key = 0, s_keyn = 0, s_lkey = 0, s_lkeyn = 0, s_lkrot = 0, s_kvel = 0, s_kang = 0, s_lupn = 0, s_llon = 0, s_lvrn = 0, s_bodyz = 0;
-  if (valid) {
-    f4 hinv = ld4(misc + M_HINV);
-    f3 rootp = ld3(root);
-    // general tracking: anchor ("beyondmimic") frame, general_tracking.py:738-767 — every lane derives it redundantly (no LDS
-    // round trip).  delta_pos aliases robot_anchor_pos in the reference (:748-749): (robot x, robot y, REF z) is used by both.
-    f4 a_rq = mk4(0, 0, 0, 1), a_bq = a_rq, dori = a_rq, ainv = a_rq;
-    f3 a_rp = mk3(0, 0, 0), a_bp = a_rp, dpos = a_rp;
-    if (MODE) {
-      const int an = c.anchor_index;
-      a_rq = ld4(rq + 4 * an); a_bq = ld4(bq + 4 * an); a_rp = ld3(rp + 3 * an); a_bp = ld3(bp + 3 * an);
-      dori = yaw_quat(quat_mul(a_bq, quat_conj(a_rq)));
-      dpos = mk3(a_bp.x, a_bp.y, a_rp.z);
-      ainv = quat_conj(a_bq);
-    }
-    const int o_lbp = c.feat_off[PBHC_F_LOCAL_BODY_POS], o_lbr = c.feat_off[PBHC_F_LOCAL_BODY_ROT];
-    const int o_dif = c.feat_off[PBHC_F_DIF_LOCAL_RIGID_BODY_POS], o_loc = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_POS];
-    const int o_vr = c.feat_off[PBHC_F_VR_3POINT_POS], o_lv = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_VEL], o_gv = c.feat_off[PBHC_F_GLOBAL_REF_RIGID_BODY_VEL];
-    for (int b = lane; b < Bx; b += PBHC_G) {
-      f3 rpos = ld3(rp + 3 * b);
-      f3 dp = sub3(rpos, ld3(bp + 3 * b));
-      float n2 = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
-      float msq = n2 * (1.0f / 3.0f);
-      float nrm = sqrtf(n2);
-      int fl = c.body_flags[b];
-      if (fl & 1) { s_up += msq; s_upn += nrm; }
-      if (fl & 2) { s_lo += msq; s_lon += nrm; }
-      if (fl & 4) { s_vr += msq; s_vrn += nrm; }
-      if (fl & 8) s_feet += msq;
-      s_maxn = fmaxf(s_maxn, nrm);
-      f4 dq = ld4(rq + 4 * b), cq = ld4(bq + 4 * b);
-      f3 dv = sub3(ld3(rv + 3 * b), ld3(bv + 3 * b));
-      const float dv2 = (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) * (1.0f / 3.0f);
-      s_vel += dv2;
-      f3 dw3 = sub3(ld3(rw + 3 * b), ld3(bw + 3 * b));
-      const float dw2 = (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) * (1.0f / 3.0f);
-      s_ang += dw2;
-      if (!MODE) {
-        float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (motion_tracking.py:651)
-        s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) * 0.25f;
-      } else {
-        // true quaternion difference + its angle (general_tracking.py:643-647,1144,1203); anchor-relative target :750-767
-        const f3 bpos = ld3(bp + 3 * b);
-        const float ang = quat_angle(quat_mul(dq, quat_conj(cq)));
-        s_rot += ang * ang;
-        if (b == c.anchor_index) { red[R_AROT] = ang * ang; red[R_APOS] = msq; }
-        const f3 dl = sub3(add3(dpos, quat_apply(dori, sub3(rpos, a_rp))), bpos);
-        const float l2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z, lnrm = sqrtf(l2);
-        const float lang = quat_angle(quat_mul(quat_mul(dori, dq), quat_conj(cq)));
-        if (fl & 16) {
-          s_key += msq; s_keyn += nrm; s_lkey += l2 * (1.0f / 3.0f); s_lkeyn += lnrm;
-          s_lkrot += lang * lang; s_kvel += dv2; s_kang += dw2;
+          for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
+            if (k < Q) {
+              float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
+              at(io.action_queue, qoff + (u32)(k * D)) = nv;
+              if (k == didx) delayed = nv;
+            }
         }
-        if (fl & 1) s_lupn += lnrm;
-        if (fl & 2) s_llon += lnrm;
-        if (fl & 4) s_lvrn += lnrm;
-        if ((fl & 32) && fabsf(dl.z) > c.body_z_threshold) s_bodyz = 1.0f;
-        st3(feat + o_lbp + 3 * b, quat_apply(ainv, sub3(bpos, dpos)));           // :779-782
-        quat_to_mat6(quat_mul(ainv, cq), feat + o_lbr + 6 * b);                 // :771-778
+        actd[d] = delayed;
+        float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
+        if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
+        if (c.use_rao) tq = tq + ras * tl;
+        if (c.clip_torques) tq = clampf(tq, -tl, tl);
+        tau[d] = tq;
       }
-      st3(feat + o_dif + 3 * b, quat_rotate(hinv, dp));
-      f3 gl = sub3(rpos, rootp);
-      f3 loc = quat_rotate(hinv, gl);
-      st3(feat + o_loc + 3 * b, loc);
-      if (c.track_slot[b] >= 0) st3(feat + o_vr + 3 * c.track_slot[b], loc);
-      f3 rvel = ld3(rv + 3 * b);
-      st3(feat + o_gv + 3 * b, rvel);
-      st3(feat + o_lv + 3 * b, quat_rotate(hinv, rvel));
+      if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
+      if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
+      if (lane == 0) {
+        feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
+        feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
+        if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
+      }
+      if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
+      if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
     }
-    const float soft_pos = pf_soft_pos, soft_vel = pf_soft_vel, soft_tau = pf_soft_tau;
-    const float inv_dt = 1.0f / dt;
-    const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
-    for (int d = lane; d < D; d += PBHC_G) {
-      float dj = rdof[d] - q[d], djv = rdofv[d] - qd[d];
-      feat[o_dja + d] = dj; feat[o_djv + d] = djv;
-      s_maxjp = fmaxf(s_maxjp, fabsf(dj));
-      s_jp2 += dj * dj; s_jv2 += djv * djv;
-      s_tau2 += tau[d] * tau[d];
-      float la = pf_last_act - act[d];
-      s_ar += la * la;
-      s_qd2 += qd[d] * qd[d];
-      float acc = (pf_last_qd - qd[d]) * inv_dt;
-      s_qacc2 += acc * acc;
-      float lo_l, hi_l;
-      if (c.soft_pos_curriculum) {
-        float m = (c.hard_dof_pos_limits[d][0] + c.hard_dof_pos_limits[d][1]) / 2.0f;
-        float r = c.hard_dof_pos_limits[d][1] - c.hard_dof_pos_limits[d][0];
-        lo_l = m - 0.5f * r * soft_pos; hi_l = m + 0.5f * r * soft_pos;
-      } else { lo_l = c.soft_dof_pos_limits[d][0]; hi_l = c.soft_dof_pos_limits[d][1]; }
-      s_lpos += -fminf(q[d] - lo_l, 0.0f) + fmaxf(q[d] - hi_l, 0.0f);
-      float vlim = c.dof_vel_limits[d] * (c.soft_vel_curriculum ? soft_vel : c.soft_dof_vel_limit);
-      s_lvel += clampf(fabsf(qd[d]) - vlim, 0.0f, 1.0f);
-      if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[d]) - c.torque_limits[d] * soft_tau, 0.0f, 1.0f);
-      else s_ltau += fmaxf(fabsf(tau[d]) - c.torque_limits[d] * c.soft_torque_limit, 0.0f);
+    clipcnt = group_sum(clipcnt);
+    if (valid && lane == 0) misc[M_CLIPCNT] = clipcnt;
+    WAVE_LDS_FENCE();
+    // =============== role B, interval 1: per-env scalars, reference frame, future targets ==========================================
+    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588),
+    // while the reference rows are in flight
+    if (valid) {
+      const float* broot = red;                                // this role's copy of the frame's root state (see interval 0)
+      f4 rq4 = ld4(broot + 3);
+      if (lane == 0) {
+        const float mlen = mlen_env;
+        misc[M_EPLEN] = (float)ep1;
+        misc[M_START] = start; misc[M_MLEN] = mlen;
+        const float t = tref;
+        misc[M_TIME] = t;
+        misc[M_PHASE] = t / mlen;
+        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
+        f3 e = euler_xyz(rq4);
+        misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
+        feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
+        if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
+        st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
+      } else if (lane <= 3) {
+        // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
+        const f3 vin = lane == 1 ? ld3(broot + 7) : (lane == 2 ? ld3(broot + 10) : mk3(0.0f, 0.0f, -1.0f));
+        const f3 vo = quat_rotate_inverse(rq4, vin);
+        const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+        st3(feat + off, vo);
+        if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+      } else if (lane >= 4 && lane < 4 + NF) {
+        int f = lane - 4;
+        float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
+        float lastc = misc[M_LASTC0 + f];
+        misc[M_CONTACT0 + f] = cn;
+        misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
+      }
     }
-    for (int i = lane; i < c.num_penalised; i += PBHC_G)
-      if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
-    if (MODE && lane == 0) {
-      // root differences (general_tracking.py:655-666) and the anchor observations / termination signals (:784-803)
-      const f4 rootq = ld4(root + 3);
-      const f3 drv = sub3(quat_rotate_inverse(ld4(rq), ld3(rv)), quat_rotate_inverse(rootq, ld3(root + 7)));
-      st3(feat + c.feat_off[PBHC_F_DIF_ROOT_VELOCITY], drv);
-      red[R_RVEL] = (drv.x * drv.x + drv.y * drv.y + drv.z * drv.z) / 3.0f;
-      const f4 drr = quat_mul(ld4(rq), quat_conj(rootq));
-      st4(feat + c.feat_off[PBHC_F_DIF_ROOT_ROT], drr);
-      const float drh = rp[2] - root[2];
-      feat[c.feat_off[PBHC_F_DIF_ROOT_HEIGHT]] = drh;
-      const float ra = quat_angle(drr);
-      red[R_RPOSE] = ra * ra + drh * drh;
-      quat_to_mat6(quat_mul(ainv, a_rq), feat + c.feat_off[PBHC_F_ANCHOR_REF_ROT]);
-      st3(feat + c.feat_off[PBHC_F_ANCHOR_REF_POS], quat_apply(ainv, sub3(a_rp, a_bp)));
-      const f3 gv = mk3(0.0f, 0.0f, -1.0f);
-      misc[M_ADZ] = a_rp.z - a_bp.z;
-      misc[M_AORI] = quat_rotate_inverse(a_rq, gv).z - quat_rotate_inverse(a_bq, gv).z;
+    STAMPB(1);
+    // ---- phase D: reference frame: lerp / slerp of the two frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
+    if (valid) {
+      const float a = 1.0f - blend, bb = blend;
+      if (lane < D) { rdof[lane] = a * rd0 + bb * rd1; rdofv[lane] = a * rdv0 + bb * rdv1; }
+      if (lane < 2) {
+        misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
+        if (MODE) feat[c.feat_off[PBHC_F_REF_CONTACT_MASK] + lane] = a * rc0 + bb * rc1;
+      }
+      if (lane < Bx) {
+        st3(rp + 3 * lane, mk3(a * rp0.x + bb * rp1.x + origin.x, a * rp0.y + bb * rp1.y + origin.y, a * rp0.z + bb * rp1.z + origin.z));
+        st4(rq + 4 * lane, slerp(rq0, rq1, bb));
+        st3(rv + 3 * lane, mk3(a * rv0.x + bb * rv1.x, a * rv0.y + bb * rv1.y, a * rv0.z + bb * rv1.z));
+        st3(rw + 3 * lane, mk3(a * rw0.x + bb * rw1.x, a * rw0.y + bb * rw1.y, a * rw0.z + bb * rw1.z));
+      }
+      for (int i = lane + PBHC_G; i < Bx; i += PBHC_G) {            // bodies beyond the 32 lanes (29-DoF robots)
+        f3 p0 = ld3(r0 + o_pos + 3 * i), p1 = ld3(r1 + o_pos + 3 * i);
+        st3(rp + 3 * i, mk3(a * p0.x + bb * p1.x + origin.x, a * p0.y + bb * p1.y + origin.y, a * p0.z + bb * p1.z + origin.z));
+        st4(rq + 4 * i, slerp(ld4(r0 + o_rot + 4 * i), ld4(r1 + o_rot + 4 * i), bb));
+        f3 v0 = ld3(r0 + o_vel + 3 * i), v1 = ld3(r1 + o_vel + 3 * i);
+        st3(rv + 3 * i, mk3(a * v0.x + bb * v1.x, a * v0.y + bb * v1.y, a * v0.z + bb * v1.z));
+        f3 w0 = ld3(r0 + o_ang + 3 * i), w1 = ld3(r1 + o_ang + 3 * i);
+        st3(rw + 3 * i, mk3(a * w0.x + bb * w1.x, a * w0.y + bb * w1.y, a * w0.z + bb * w1.z));
+      }
     }
+    STAMPB(2);
+    // ---- general tracking: future reference targets (general_tracking.py:500-565) ----------------------------------------------
+    // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
+    // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
+    // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.  Wave-local (no barrier between the passes).
+    if (MODE && c.future_num_steps > 0) {
+      const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
+      float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
+      const int row0 = m_row0, nf_c = m_nf;
+      const float len_c = m_len, dt_c = m_dt;
+      const float tb = (float)ep1 * dt + start;
+      if (valid)
+        for (int st = lane; st < NS; st += PBHC_G) {
+          const float t = (float)c.future_steps[st] * dt + tb;
+          int f0, f1; float bl;
+          frame_blend(t, len_c, nf_c, dt_c, &f0, &f1, &bl);
+          const float* q0 = tbl.frames + (size_t)(row0 + f0) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + f1) * tbl.row;
+          const float al = 1.0f - bl;
+          const f4 rr = slerp(ld4(q0 + o_rot), ld4(q1 + o_rot), bl);
+          const f3 v0 = ld3(q0 + o_vel), v1 = ld3(q1 + o_vel), w0 = ld3(q0 + o_ang), w1 = ld3(q1 + o_ang);
+          const f3 e = euler_xyz(rr);
+          feat[c.feat_off[PBHC_F_FUT_ROOT_HEIGHT] + st] = al * q0[o_pos + 2] + bl * q1[o_pos + 2] + origin.z;
+          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st] = e.x;
+          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st + 1] = e.y;
+          st3(feat + c.feat_off[PBHC_F_FUT_BASE_LIN_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * v0.x + bl * v1.x, al * v0.y + bl * v1.y, al * v0.z + bl * v1.z)));
+          st3(feat + c.feat_off[PBHC_F_FUT_BASE_ANG_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * w0.x + bl * w1.x, al * w0.y + bl * w1.y, al * w0.z + bl * w1.z)));
+          const f4 aq = an == 0 ? rr : slerp(ld4(q0 + o_rot + 4 * an), ld4(q1 + o_rot + 4 * an), bl);
+          const f3 p0 = ld3(q0 + o_pos + 3 * an), p1 = ld3(q1 + o_pos + 3 * an);
+          float* fs = fut + 10 * st;
+          fs[0] = __int_as_float(f0); fs[1] = __int_as_float(f1); fs[2] = bl;
+          st4(fs + 3, quat_conj(aq));
+          st3(fs + 7, mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z));
+        }
+      WAVE_LDS_FENCE();
+      if (valid) {
+        const int o_fd = c.feat_off[PBHC_F_FUT_DOF_POS], o_fk = c.feat_off[PBHC_F_FUT_LOCAL_KEY_POS];
+        int st = 0, dd = lane;                                       // (step, dof) without divisions: D may be < 32
+        while (dd >= D) { dd -= D; ++st; }
+        for (; st < NS;) {
+          const float* fs = fut + 10 * st;
+          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+          feat[o_fd + st * D + dd] = (1.0f - fs[2]) * q0[dd] + fs[2] * q1[dd];
+          dd += PBHC_G;
+          while (dd >= D) { dd -= D; ++st; }
+        }
+        for (int i = lane; i < NS * Kn; i += PBHC_G) {
+          const int st2 = i / Kn, k = i - st2 * Kn, body = c.key[k];
+          const float* fs = fut + 10 * st2;
+          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+          const float bl = fs[2], al = 1.0f - bl;
+          const f3 p0 = ld3(q0 + o_pos + 3 * body), p1 = ld3(q1 + o_pos + 3 * body);
+          const f3 pw = mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z);
+          st3(feat + o_fk + 3 * i, quat_apply(ld4(fs + 3), sub3(pw, ld3(fs + 7))));
+        }
+      }
+    }
+    STAMPB(3);
   }
-#define GSUM(v) v = group_sum(v)
-  GSUM(s_up); GSUM(s_lo); GSUM(s_vr); GSUM(s_feet); GSUM(s_rot); GSUM(s_vel); GSUM(s_ang); GSUM(s_upn); GSUM(s_lon); GSUM(s_vrn);
-  GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
-  s_maxn = group_max(s_maxn); s_maxjp = group_max(s_maxjp);
-  if (MODE) {
-    GSUM(s_key); GSUM(s_keyn); GSUM(s_lkey); GSUM(s_lkeyn); GSUM(s_lkrot); GSUM(s_kvel); GSUM(s_kang); GSUM(s_lupn); GSUM(s_llon); GSUM(s_lvrn);
-    s_bodyz = group_max(s_bodyz);
-  }
-  if (valid && lane == 0) {
-    if (MODE) {
-      const float nk = (float)c.num_key;
-      red[R_KEY] = s_key / nk; red[R_KEYN] = s_keyn / nk; red[R_LKEY] = s_lkey / nk; red[R_LKEYN] = s_lkeyn / nk; red[R_LKROT] = s_lkrot / nk;
-      red[R_KVEL] = s_kvel / nk; red[R_KANG] = s_kang / nk;
-      red[R_LUPN] = s_lupn / (float)c.num_upper; red[R_LLON] = s_llon / (float)c.num_lower; red[R_LVRN] = s_lvrn / (float)c.num_track;
-    }
-    red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
-    red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
-    red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
-    red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
-    if (!MODE) for (int k = PBHC_S_KEY_BODY_POS; k < PBHC_NUM_SIGMA; ++k) red[R_ERR0 + k] = 0.0f;
-    red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = clipcnt;
-    // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
-    float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
-    if (c.terminate_by_gravity) grav = sqrtf(misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]) > c.termination_gravity ? 1.0f : 0.0f;
-    if (c.terminate_when_motion_far) far = s_maxn > pf_far_thr ? 1.0f : 0.0f;
-    tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
-    if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
-    float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
-    float refz = 0.0f, refori = 0.0f, bodyz = 0.0f;
-    if (MODE) {                                   // general_tracking.py:241-254
-      if (c.terminate_by_ref_pos_z) refz = fabsf(misc[M_ADZ]) > c.ref_pos_z_threshold ? 1.0f : 0.0f;
-      if (c.terminate_by_ref_ori) refori = fabsf(misc[M_AORI]) > c.ref_ori_threshold ? 1.0f : 0.0f;
-      if (c.terminate_by_body_z) bodyz = s_bodyz;
-      misc[M_REFZ] = refz; misc[M_REFORI] = refori; misc[M_BODYZ] = bodyz;
-    }
-    misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
-    misc[M_TIMEOUT] = tout;
-    misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f) ? 1.0f : 0.0f;
-  }
-  LDS_BARRIER();
+  LDS_BARRIER();                                               // bar1: A's body state and B's reference frame / scalars are in LDS
+  STAMP(3);
 
-  STAMP(5);
-  // ---------------- phase F: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ----
-  // (a) lane k < 10: e_k = exp(-err_k / sigma_k); lanes 10.. : per-foot norms.  (b) lane i <-> term i: cheap selects.
-  if (valid) {
-    if (lane < PBHC_NUM_SIGMA) {
-      const float e = red[R_ERR0 + lane];
-      red[R_EXP0 + lane] = expf(-e / pf_sigma);
-    } else if (lane < PBHC_NUM_SIGMA + NF) {
-      const int f = lane - PBHC_NUM_SIGMA;
-      const float* fc = cf + 3 * c.feet[f];
-      const float* fv = bv + 3 * c.feet[f];
-      red[R_FOOT0 + 4 * f + 0] = norm3(ld3(fc));
-      red[R_FOOT0 + 4 * f + 1] = sqrtf(fc[0] * fc[0] + fc[1] * fc[1]);
-      red[R_FOOT0 + 4 * f + 2] = fc[2];
-      red[R_FOOT0 + 4 * f + 3] = norm3(ld3(fv));
-      red[R_FOOT0 + 8 + f] = sqrtf(fv[0] * fv[0] + fv[1] * fv[1]);
+  if (!roleB) {
+    // =============== role A, interval 2a: tracking differences over the bodies + lane-parallel partial sums ======================
+    // (motion_tracking.py:645-731 and the body-space reductions of the _reward_* terms)
+    if (valid) {
+      f4 hinv = ld4(misc + M_HINV);
+      f3 rootp = ld3(root);
+      // general tracking: anchor ("beyondmimic") frame, general_tracking.py:738-767 — every lane derives it redundantly (no LDS
+      // round trip).  delta_pos aliases robot_anchor_pos in the reference (:748-749): (robot x, robot y, REF z) is used by both.
+      f4 a_rq = mk4(0, 0, 0, 1), a_bq = a_rq, dori = a_rq, ainv = a_rq;
+      f3 a_rp = mk3(0, 0, 0), a_bp = a_rp, dpos = a_rp;
+      if (MODE) {
+        const int an = c.anchor_index;
+        a_rq = ld4(rq + 4 * an); a_bq = ld4(bq + 4 * an); a_rp = ld3(rp + 3 * an); a_bp = ld3(bp + 3 * an);
+        dori = yaw_quat(quat_mul(a_bq, quat_conj(a_rq)));
+        dpos = mk3(a_bp.x, a_bp.y, a_rp.z);
+        ainv = quat_conj(a_bq);
+      }
+      const int o_lbp = c.feat_off[PBHC_F_LOCAL_BODY_POS], o_lbr = c.feat_off[PBHC_F_LOCAL_BODY_ROT];
+      const int o_dif = c.feat_off[PBHC_F_DIF_LOCAL_RIGID_BODY_POS], o_loc = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_POS];
+      const int o_vr = c.feat_off[PBHC_F_VR_3POINT_POS], o_lv = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_VEL], o_gv = c.feat_off[PBHC_F_GLOBAL_REF_RIGID_BODY_VEL];
+      for (int b = lane; b < Bx; b += PBHC_G) {
+        f3 rpos = ld3(rp + 3 * b);
+        f3 dp = sub3(rpos, ld3(bp + 3 * b));
+        float n2 = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
+        float msq = n2 * (1.0f / 3.0f);
+        float nrm = sqrtf(n2);
+        int fl = c.body_flags[b];
+        if (fl & 1) { s_up += msq; s_upn += nrm; }
+        if (fl & 2) { s_lo += msq; s_lon += nrm; }
+        if (fl & 4) { s_vr += msq; s_vrn += nrm; }
+        if (fl & 8) s_feet += msq;
+        s_maxn = fmaxf(s_maxn, nrm);
+        f4 dq = ld4(rq + 4 * b), cq = ld4(bq + 4 * b);
+        f3 dv = sub3(ld3(rv + 3 * b), ld3(bv + 3 * b));
+        const float dv2 = (dv.x * dv.x + dv.y * dv.y + dv.z * dv.z) * (1.0f / 3.0f);
+        s_vel += dv2;
+        f3 dw3 = sub3(ld3(rw + 3 * b), ld3(bw + 3 * b));
+        const float dw2 = (dw3.x * dw3.x + dw3.y * dw3.y + dw3.z * dw3.z) * (1.0f / 3.0f);
+        s_ang += dw2;
+        if (!MODE) {
+          float dx = dq.x - cq.x, dy = dq.y - cq.y, dz = dq.z - cq.z, dw = dq.w - cq.w;   // quaternion SUBTRACTION, sic (motion_tracking.py:651)
+          s_rot += (dx * dx + dy * dy + dz * dz + dw * dw) * 0.25f;
+        } else {
+          // true quaternion difference + its angle (general_tracking.py:643-647,1144,1203); anchor-relative target :750-767
+          const f3 bpos = ld3(bp + 3 * b);
+          const float ang = quat_angle(quat_mul(dq, quat_conj(cq)));
+          s_rot += ang * ang;
+          if (b == c.anchor_index) { red[R_AROT] = ang * ang; red[R_APOS] = msq; }
+          const f3 dl = sub3(add3(dpos, quat_apply(dori, sub3(rpos, a_rp))), bpos);
+          const float l2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z, lnrm = sqrtf(l2);
+          const float lang = quat_angle(quat_mul(quat_mul(dori, dq), quat_conj(cq)));
+          if (fl & 16) {
+            s_key += msq; s_keyn += nrm; s_lkey += l2 * (1.0f / 3.0f); s_lkeyn += lnrm;
+            s_lkrot += lang * lang; s_kvel += dv2; s_kang += dw2;
+          }
+          if (fl & 1) s_lupn += lnrm;
+          if (fl & 2) s_llon += lnrm;
+          if (fl & 4) s_lvrn += lnrm;
+          if ((fl & 32) && fabsf(dl.z) > c.body_z_threshold) s_bodyz = 1.0f;
+          st3(feat + o_lbp + 3 * b, quat_apply(ainv, sub3(bpos, dpos)));           // :779-782
+          quat_to_mat6(quat_mul(ainv, cq), feat + o_lbr + 6 * b);                 // :771-778
+        }
+        st3(feat + o_dif + 3 * b, quat_rotate(hinv, dp));
+        f3 gl = sub3(rpos, rootp);
+        f3 loc = quat_rotate(hinv, gl);
+        st3(feat + o_loc + 3 * b, loc);
+        if (c.track_slot[b] >= 0) st3(feat + o_vr + 3 * c.track_slot[b], loc);
+        f3 rvel = ld3(rv + 3 * b);
+        st3(feat + o_gv + 3 * b, rvel);
+        st3(feat + o_lv + 3 * b, quat_rotate(hinv, rvel));
+      }
+      if (MODE && lane == 0) {
+        // root differences (general_tracking.py:655-666) and the anchor observations / termination signals (:784-803)
+        const f4 rootq = ld4(root + 3);
+        const f3 drv = sub3(quat_rotate_inverse(ld4(rq), ld3(rv)), quat_rotate_inverse(rootq, ld3(root + 7)));
+        st3(feat + c.feat_off[PBHC_F_DIF_ROOT_VELOCITY], drv);
+        red[R_RVEL] = (drv.x * drv.x + drv.y * drv.y + drv.z * drv.z) / 3.0f;
+        const f4 drr = quat_mul(ld4(rq), quat_conj(rootq));
+        st4(feat + c.feat_off[PBHC_F_DIF_ROOT_ROT], drr);
+        const float drh = rp[2] - root[2];
+        feat[c.feat_off[PBHC_F_DIF_ROOT_HEIGHT]] = drh;
+        const float ra = quat_angle(drr);
+        red[R_RPOSE] = ra * ra + drh * drh;
+        quat_to_mat6(quat_mul(ainv, a_rq), feat + c.feat_off[PBHC_F_ANCHOR_REF_ROT]);
+        st3(feat + c.feat_off[PBHC_F_ANCHOR_REF_POS], quat_apply(ainv, sub3(a_rp, a_bp)));
+        const f3 gv = mk3(0.0f, 0.0f, -1.0f);
+        misc[M_ADZ] = a_rp.z - a_bp.z;
+        misc[M_AORI] = quat_rotate_inverse(a_rq, gv).z - quat_rotate_inverse(a_bq, gv).z;
+      }
     }
+#define GSUM(v) v = group_sum(v)
+    GSUM(s_up); GSUM(s_lo); GSUM(s_vr); GSUM(s_feet); GSUM(s_rot); GSUM(s_vel); GSUM(s_ang); GSUM(s_upn); GSUM(s_lon); GSUM(s_vrn);
+    s_maxn = group_max(s_maxn);
+    if (MODE) {
+      GSUM(s_key); GSUM(s_keyn); GSUM(s_lkey); GSUM(s_lkeyn); GSUM(s_lkrot); GSUM(s_kvel); GSUM(s_kang); GSUM(s_lupn); GSUM(s_llon); GSUM(s_lvrn);
+      s_bodyz = group_max(s_bodyz);
+    }
+    if (valid && lane == 0) {
+      if (MODE) {
+        const float nk = (float)c.num_key;
+        red[R_KEY] = s_key / nk; red[R_KEYN] = s_keyn / nk; red[R_LKEY] = s_lkey / nk; red[R_LKEYN] = s_lkeyn / nk; red[R_LKROT] = s_lkrot / nk;
+        red[R_KVEL] = s_kvel / nk; red[R_KANG] = s_kang / nk;
+        red[R_LUPN] = s_lupn / (float)c.num_upper; red[R_LLON] = s_llon / (float)c.num_lower; red[R_LVRN] = s_lvrn / (float)c.num_track;
+      }
+      red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
+      red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
+      red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
+      if (!MODE) for (int k = PBHC_S_KEY_BODY_POS; k < PBHC_NUM_SIGMA; ++k) red[R_ERR0 + k] = 0.0f;
+      // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
+      float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
+      if (c.terminate_by_gravity) grav = sqrtf(misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]) > c.termination_gravity ? 1.0f : 0.0f;
+      if (c.terminate_when_motion_far) far = s_maxn > pf_far_thr ? 1.0f : 0.0f;
+      tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
+      if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
+      float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
+      float refz = 0.0f, refori = 0.0f, bodyz = 0.0f;
+      if (MODE) {                                   // general_tracking.py:241-254
+        if (c.terminate_by_ref_pos_z) refz = fabsf(misc[M_ADZ]) > c.ref_pos_z_threshold ? 1.0f : 0.0f;
+        if (c.terminate_by_ref_ori) refori = fabsf(misc[M_AORI]) > c.ref_ori_threshold ? 1.0f : 0.0f;
+        if (c.terminate_by_body_z) bodyz = s_bodyz;
+        misc[M_REFZ] = refz; misc[M_REFORI] = refori; misc[M_BODYZ] = bodyz;
+      }
+      misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
+      misc[M_TIMEOUT] = tout;
+      misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f) ? 1.0f : 0.0f;
+    }
+    STAMP(4);
+  } else {
+    // =============== role B, interval 2a: outputs of the pre-reset reference, joint-space differences + reductions, foot norms ====
+    float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
+    if (valid) {
+      if (io.ref_body_pos_extend)
+        for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
+      if (io.ref_body_rot_extend)
+        for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
+      const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
+      const float inv_dt = 1.0f / dt;
+      const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
+      for (int dd = lane; dd < D; dd += PBHC_G) {
+        float dj = rdof[dd] - q[dd], djv = rdofv[dd] - qd[dd];
+        feat[o_dja + dd] = dj; feat[o_djv + dd] = djv;
+        s_maxjp = fmaxf(s_maxjp, fabsf(dj));
+        s_jp2 += dj * dj; s_jv2 += djv * djv;
+        s_tau2 += tau[dd] * tau[dd];
+        float la = pf_last_act - act[dd];
+        s_ar += la * la;
+        s_qd2 += qd[dd] * qd[dd];
+        float acc = (pf_last_qd - qd[dd]) * inv_dt;
+        s_qacc2 += acc * acc;
+        float lo_l, hi_l;
+        if (c.soft_pos_curriculum) {
+          float m = (c.hard_dof_pos_limits[dd][0] + c.hard_dof_pos_limits[dd][1]) / 2.0f;
+          float r = c.hard_dof_pos_limits[dd][1] - c.hard_dof_pos_limits[dd][0];
+          lo_l = m - 0.5f * r * soft_pos; hi_l = m + 0.5f * r * soft_pos;
+        } else { lo_l = c.soft_dof_pos_limits[dd][0]; hi_l = c.soft_dof_pos_limits[dd][1]; }
+        s_lpos += -fminf(q[dd] - lo_l, 0.0f) + fmaxf(q[dd] - hi_l, 0.0f);
+        float vlim = c.dof_vel_limits[dd] * (c.soft_vel_curriculum ? soft_vel : c.soft_dof_vel_limit);
+        s_lvel += clampf(fabsf(qd[dd]) - vlim, 0.0f, 1.0f);
+        if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[dd]) - c.torque_limits[dd] * soft_tau, 0.0f, 1.0f);
+        else s_ltau += fmaxf(fabsf(tau[dd]) - c.torque_limits[dd] * c.soft_torque_limit, 0.0f);
+      }
+      for (int i = lane; i < c.num_penalised; i += PBHC_G)
+        if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
+      if (lane >= PBHC_G - NF) {                              // per-foot norms for the contact rewards (phase F of role A)
+        const int f = lane - (PBHC_G - NF);
+        const float* fc = cf + 3 * c.feet[f];
+        const float* fv = bv + 3 * c.feet[f];
+        red[R_FOOT0 + 4 * f + 0] = norm3(ld3(fc));
+        red[R_FOOT0 + 4 * f + 1] = sqrtf(fc[0] * fc[0] + fc[1] * fc[1]);
+        red[R_FOOT0 + 4 * f + 2] = fc[2];
+        red[R_FOOT0 + 4 * f + 3] = norm3(ld3(fv));
+        red[R_FOOT0 + 8 + f] = sqrtf(fv[0] * fv[0] + fv[1] * fv[1]);
+      }
+    }
+    GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
+    s_maxjp = group_max(s_maxjp);
+    if (valid && lane == 0) {
+      red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
+      red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = misc[M_CLIPCNT];
+    }
+    STAMPB(4);
   }
-  LDS_BARRIER();
+  LDS_BARRIER();                                               // bar2: both halves of the reduction row + termination flags are in LDS
+  STAMP(5);
+
   float err[PBHC_NUM_SIGMA];
 #pragma unroll
   for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
-  float rew_total = 0.0f;
-  pf_sum = __shfl(sumrow, pf_tcol, PBHC_G);
-  pf_termsum = __shfl(sumrow, c.termination_sum_col, PBHC_G);
-  if (valid) {
-    const float pen_scale = pf_pen_scale;
-    float myrew = 0.0f;
-    if (lane < c.num_terms) {
-      float raw = 0.0f;
-      const int id = pf_tid;
-      const float* ex = red + R_EXP0;
-      const float* ft = red + R_FOOT0;
-      // Most terms are one value of the reduction row: `term_src` (filled by pbhc_env_create, see term_source()) is its LDS slot.
-      // Only the terms that combine several values keep a case.
-      if (pf_tsrc >= 0) raw = red[pf_tsrc];
-      else switch (id) {
-        case PBHC_R_TELEOP_CONTACT_MASK: {
-          float e = 0.0f;
-          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
-          raw = 1.0f - e / (float)NF;
-        } break;
-        case PBHC_R_TELEOP_CONTACT_MASK_V2: {
-          float e = 0.0f;
-          for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
-          raw = 0.5f - e / (float)NF;
-        } break;
-        case PBHC_R_TELEOP_BODY_POSITION_EXTEND: raw = ex[PBHC_S_LOWER_BODY_POS] * c.body_pos_lower_weight + ex[PBHC_S_UPPER_BODY_POS] * c.body_pos_upper_weight; break;
-        case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
-        case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
-          for (int f = 0; f < NF; ++f) {
-            bool contact = ft[4 * f + 2] > 1.0f;
-            bool cfilt = contact || (misc[M_LASTC0 + f] != 0.0f);
-            float fat = misc[M_FAT0 + f];
-            float first = (fat > 0.0f && cfilt) ? 1.0f : 0.0f;
-            fat = fat + dt;
-            raw += (fat - c.desired_feet_air_time) * first;
-            misc[M_FAT0 + f] = cfilt ? fat * 0.0f : fat;
-          }
-        } break;
-        case PBHC_R_PENALTY_FEET_CONTACT_FORCES:
-          for (int f = 0; f < NF; ++f) raw += fmaxf(ft[4 * f] - c.max_contact_force, 0.0f);
-          break;
-        case PBHC_R_PENALTY_STUMBLE:
-          for (int f = 0; f < NF; ++f)
-            if (ft[4 * f + 1] > 5.0f * fabsf(ft[4 * f + 2])) raw = 1.0f;
-          break;
-        case PBHC_R_PENALTY_SLIPPAGE:
-          for (int f = 0; f < NF; ++f) raw += ft[4 * f + 3] * (ft[4 * f] > 1.0f ? 1.0f : 0.0f);
-          break;
-        case PBHC_R_FOOT_SLIP_PENALTY:
-          for (int f = 0; f < NF; ++f) raw += (ft[4 * f] > 1.0f ? 1.0f : 0.0f) * ft[8 + f];
-          break;
-        case PBHC_R_ALIVE: raw = 1.0f; break;
-        default: raw = 0.0f;
-      }
-      myrew = raw * pf_tscale;
-      if (pf_tpen) myrew = myrew * pen_scale;
-      at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)pf_tcol) = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
+  float rew_total = 0.0f, etr_val = 0.0f;
+  const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals
+  const int ngroups = c.num_groups;
+
+  if (!roleB) {
+    // =============== role A, interval 2b: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ========================
+    // (a) lane k < 10: e_k = exp(-err_k / sigma_k).  (b) lane i <-> term i: cheap selects.
+    if (valid && lane < PBHC_NUM_SIGMA) {
+      const float e = red[R_ERR0 + lane];
+      red[R_EXP0 + lane] = expf(-e / pf_sigma);
     }
-    if (c.use_vec_reward) {
-      if (lane < c.num_rew_cols) {
-        float v = lane < c.num_terms ? myrew : 0.0f;
-        if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
-        if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
-          float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
-          v += tr;
-          at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) = pf_termsum + tr;
+    WAVE_LDS_FENCE();
+    const float pf_sum = __shfl(sumrow, pf_tcol, PBHC_G);
+    const float pf_termsum = __shfl(sumrow, c.termination_sum_col, PBHC_G);
+    if (valid) {
+      const float pen_scale = pf_pen_scale;
+      float myrew = 0.0f;
+      if (lane < c.num_terms) {
+        float raw = 0.0f;
+        const int id = pf_tid;
+        const float* ex = red + R_EXP0;
+        const float* ft = red + R_FOOT0;
+        // Most terms are one value of the reduction row: `term_src` (filled by pbhc_env_create, see term_source()) is its LDS slot.
+        // Only the terms that combine several values keep a case.
+        if (pf_tsrc >= 0) raw = red[pf_tsrc];
+        else switch (id) {
+          case PBHC_R_TELEOP_CONTACT_MASK: {
+            float e = 0.0f;
+            for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
+            raw = 1.0f - e / (float)NF;
+          } break;
+          case PBHC_R_TELEOP_CONTACT_MASK_V2: {
+            float e = 0.0f;
+            for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
+            raw = 0.5f - e / (float)NF;
+          } break;
+          case PBHC_R_TELEOP_BODY_POSITION_EXTEND: raw = ex[PBHC_S_LOWER_BODY_POS] * c.body_pos_lower_weight + ex[PBHC_S_UPPER_BODY_POS] * c.body_pos_upper_weight; break;
+          case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
+          case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
+            for (int f = 0; f < NF; ++f) {
+              bool contact = ft[4 * f + 2] > 1.0f;
+              bool cfilt = contact || (misc[M_LASTC0 + f] != 0.0f);
+              float fat = misc[M_FAT0 + f];
+              float first = (fat > 0.0f && cfilt) ? 1.0f : 0.0f;
+              fat = fat + dt;
+              raw += (fat - c.desired_feet_air_time) * first;
+              misc[M_FAT0 + f] = cfilt ? fat * 0.0f : fat;
+            }
+          } break;
+          case PBHC_R_PENALTY_FEET_CONTACT_FORCES:
+            for (int f = 0; f < NF; ++f) raw += fmaxf(ft[4 * f] - c.max_contact_force, 0.0f);
+            break;
+          case PBHC_R_PENALTY_STUMBLE:
+            for (int f = 0; f < NF; ++f)
+              if (ft[4 * f + 1] > 5.0f * fabsf(ft[4 * f + 2])) raw = 1.0f;
+            break;
+          case PBHC_R_PENALTY_SLIPPAGE:
+            for (int f = 0; f < NF; ++f) raw += ft[4 * f + 3] * (ft[4 * f] > 1.0f ? 1.0f : 0.0f);
+            break;
+          case PBHC_R_FOOT_SLIP_PENALTY:
+            for (int f = 0; f < NF; ++f) raw += (ft[4 * f] > 1.0f ? 1.0f : 0.0f) * ft[8 + f];
+            break;
+          case PBHC_R_ALIVE: raw = 1.0f; break;
+          default: raw = 0.0f;
         }
-        at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane) = v;
+        myrew = raw * pf_tscale;
+        if (pf_tpen) myrew = myrew * pen_scale;
+        at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)pf_tcol) = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
+      }
+      if (c.use_vec_reward) {
+        if (lane < c.num_rew_cols) {
+          float v = lane < c.num_terms ? myrew : 0.0f;
+          if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
+          if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
+            float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
+            v += tr;
+            at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) = pf_termsum + tr;
+          }
+          at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane) = v;
+          rew_total = v;
+        }
+        rew_total = group_sum(rew_total);
+      } else {
+        float v = group_sum(lane < c.num_terms ? myrew : 0.0f);
+        if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
+        if (lane == 0) {
+          if (c.has_termination) {
+            float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
+            v += tr;
+            at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) += tr;
+          }
+          io.rew_buf[env] = v;
+        }
         rew_total = v;
       }
-      rew_total = group_sum(rew_total);
-    } else {
-      float v = group_sum(lane < c.num_terms ? myrew : 0.0f);
-      if (c.only_positive_rewards) v = fmaxf(v, 0.0f);
-      if (lane == 0) {
-        if (c.has_termination) {
-          float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
-          v += tr;
-          at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) += tr;
-        }
-        io.rew_buf[env] = v;
-      }
-      rew_total = v;
-    }
 #pragma unroll
-    for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = red[R_ERR0 + k];
-  }
-  LDS_BARRIER();   // episode_sums / feet_air_time (misc) settled before the reset path reads them
-
-  // ---------------- general tracking: future reference targets (general_tracking.py:500-565) ------
-  // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
-  // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
-  // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.
-  if (MODE && c.future_num_steps > 0) {
-    const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
-    float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
-    const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;
-    const int row0 = m_row0, nf_c = m_nf;
-    const float len_c = m_len, dt_c = m_dt;
-    const float tb = (float)ep1 * dt + start;
-    if (valid)
-      for (int st = lane; st < NS; st += PBHC_G) {
-        const float t = (float)c.future_steps[st] * dt + tb;
-        int f0, f1; float bl;
-        frame_blend(t, len_c, nf_c, dt_c, &f0, &f1, &bl);
-        const float* q0 = tbl.frames + (size_t)(row0 + f0) * tbl.row;
-        const float* q1 = tbl.frames + (size_t)(row0 + f1) * tbl.row;
-        const float al = 1.0f - bl;
-        const f4 rr = slerp(ld4(q0 + o_rot), ld4(q1 + o_rot), bl);
-        const f3 v0 = ld3(q0 + o_vel), v1 = ld3(q1 + o_vel), w0 = ld3(q0 + o_ang), w1 = ld3(q1 + o_ang);
-        const f3 e = euler_xyz(rr);
-        feat[c.feat_off[PBHC_F_FUT_ROOT_HEIGHT] + st] = al * q0[o_pos + 2] + bl * q1[o_pos + 2] + origin.z;
-        feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st] = e.x;
-        feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st + 1] = e.y;
-        st3(feat + c.feat_off[PBHC_F_FUT_BASE_LIN_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * v0.x + bl * v1.x, al * v0.y + bl * v1.y, al * v0.z + bl * v1.z)));
-        st3(feat + c.feat_off[PBHC_F_FUT_BASE_ANG_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * w0.x + bl * w1.x, al * w0.y + bl * w1.y, al * w0.z + bl * w1.z)));
-        const f4 aq = an == 0 ? rr : slerp(ld4(q0 + o_rot + 4 * an), ld4(q1 + o_rot + 4 * an), bl);
-        const f3 p0 = ld3(q0 + o_pos + 3 * an), p1 = ld3(q1 + o_pos + 3 * an);
-        float* fs = fut + 10 * st;
-        fs[0] = __int_as_float(f0); fs[1] = __int_as_float(f1); fs[2] = bl;
-        st4(fs + 3, quat_conj(aq));
-        st3(fs + 7, mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z));
+      for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = red[R_ERR0 + k];
+    }
+    // the episode_sums stores above and the reset path's loads / stores of the same row below are issued by the same lanes' wave in
+    // program order; the reset path waits for them explicitly
+    WAVE_LDS_FENCE();
+    STAMP(6);
+    // ---------------- phase G: reset_envs_idx for terminated envs (legged_robot_base.py:491-517,
+    // 599-686; motion_tracking.py:265-287,369-378,445-543) ------------------------------------------
+    const bool do_reset = valid && misc[M_RESET] != 0.0f;
+    if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)adelay; }
+    if (do_reset) {
+      __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0) expcnt(0) lgkmcnt(0): the wave's episode_sums stores of phase F have landed
+      for (int dd = lane; dd < D; dd += PBHC_G) {
+        act[dd] = 0.0f; actd[dd] = 0.0f;
+        float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
+        pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, dd, ur);
+        if (c.randomize_pd_gain) {
+          kpA = io.ovr_kp ? at(io.ovr_kp, eD + dd) : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
+          kdA = io.ovr_kd ? at(io.ovr_kd, eD + dd) : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
+          at(io.kp_scale, eD + dd) = kpA;
+          at(io.kd_scale, eD + dd) = kdA;
+        }
+        if (c.randomize_rfi_lim)
+          at(io.rfi_lim_scale, eD + dd) = io.ovr_rfi_lim ? at(io.ovr_rfi_lim, eD + dd) : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
+        if (c.use_rao)
+          at(io.rao_scale, eD + dd) = io.ovr_rao ? at(io.ovr_rao, eD + dd) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
+        if (c.randomize_ctrl_delay)
+          for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
       }
-    LDS_BARRIER();
+      for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
+      const u32 sbase = (u32)env * (u32)c.num_sum_cols;
+      for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
+        if (io.episode_rew_out) at(io.episode_rew_out, sbase + (u32)i) = at(io.episode_sums, sbase + (u32)i) / c.max_episode_length_s;
+        at(io.episode_sums, sbase + (u32)i) = 0.0f;
+      }
+      if (lane == 0) {
+        misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
+        misc[M_CONTACT0] = 0.0f; misc[M_CONTACT1] = 0.0f; misc[M_CFILT0] = 0.0f; misc[M_CFILT1] = 0.0f;
+        float old_start = misc[M_START];
+        float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
+        io.end_time_ratio_buf[env] = etr;
+        etr_val = etr;
+        float mlen = m_len;                                  // = tbl.motion_len[mid], in registers since the prologue
+        io.motion_len[env] = mlen;
+        float ue[4];                                     // start phase and control delay of the new episode from one Philox call
+        pbhc::rng_uniform4(rt.seed, env, step_ctr, 6, 0, ue);
+        float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
+        io.motion_start_times[env] = ns;
+        misc[M_NEWSTART] = ns;
+        if (c.randomize_ctrl_delay) {
+          long long nd = io.ovr_delay ? io.ovr_delay[env]
+                                      : (long long)c.ctrl_delay_range[0] + (long long)(ue[1] * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
+          io.action_delay_idx[env] = nd;
+          misc[M_DELAY] = (float)nd;
+        }
+        misc[M_EPLEN] = 0.0f;
+      }
+      WAVE_LDS_FENCE();
+      // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
+      // invalidated, motion_tracking.py:378,536-543,477-507)
+      float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
+      if (MODE) {
+        // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
+        // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
+        motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+        motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
+      } else {
+        motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+      }
+      WAVE_LDS_FENCE();
+      if (lane == 0) {
+        st3(root, ld3(rp));
+        st4(root + 3, quat_mul(mk4(0.f, 0.f, 0.f, 1.f), ld4(rq)));       // quat_mul(small_random_quaternions(max_angle=0), root_rot)
+        st3(root + 7, ld3(rv));
+        st3(root + 10, ld3(rw));
+      }
+    } else if (valid && lane == 0) {
+      etr_val = etr_old;
+    }
+    WAVE_LDS_FENCE();
+    STAMP(7);
+    // ---------------- phase H: post-reset features ------------------------------------------------------------------------------
     if (valid) {
-      const int o_fd = c.feat_off[PBHC_F_FUT_DOF_POS], o_fk = c.feat_off[PBHC_F_FUT_LOCAL_KEY_POS];
-      int st = 0, d = lane;                                        // (step, dof) without divisions: D may be < 32
-      while (d >= D) { d -= D; ++st; }
-      for (; st < NS;) {
-        const float* fs = fut + 10 * st;
-        const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
-        const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
-        feat[o_fd + st * D + d] = (1.0f - fs[2]) * q0[d] + fs[2] * q1[d];
-        d += PBHC_G;
-        while (d >= D) { d -= D; ++st; }
+      const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
+      const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
+      for (int dd = lane; dd < D; dd += PBHC_G) {
+        feat[o_q + dd] = q[dd] - c.default_dof_pos[dd];
+        feat[o_qd + dd] = qd[dd];
+        feat[o_a + dd] = act[dd];
+        feat[o_kp + dd] = kpA;                                   // D <= 32: lane dd owns dof dd in the prologue load and in the reset path alike
+        feat[o_kd + dd] = kdA;
       }
-      for (int i = lane; i < NS * Kn; i += PBHC_G) {
-        const int st2 = i / Kn, k = i - st2 * Kn, body = c.key[k];
-        const float* fs = fut + 10 * st2;
-        const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
-        const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
-        const float bl = fs[2], al = 1.0f - bl;
-        const f3 p0 = ld3(q0 + o_pos + 3 * body), p1 = ld3(q1 + o_pos + 3 * body);
-        const f3 pw = mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z);
-        st3(feat + o_fk + 3 * i, quat_apply(ld4(fs + 3), sub3(pw, ld3(fs + 7))));
+      if (lane == 0) {
+        feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
+        feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];              // a live view of the root state in the reference: reset envs show the reset height
       }
+      if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
     }
-    LDS_BARRIER();
+    STAMP(8);
+  } else {
+    // =============== role B, interval 2b: state outputs + the observation elements whose sources are final ========================
+    if (valid) {
+      if (io.rigid_body_state)
+        for (int b = lane; b < B; b += PBHC_G) {
+          float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
+          st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
+        }
+      if (io.contact_forces)
+        for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
+      // classes 0 (history, DR, per-env scalars, reference / future targets: this role's own products) and 1 (difference features of
+      // interval 2a) of every group; a terminated env's history elements are rewritten (as zeros) after bar3
+      if (map_words > 0)
+        for (int g = 0; g < ngroups; ++g) {
+          const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
+          if (((pitch_g & 1) != 0) || ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) != 0)) continue;      // unaligned rows: everything after bar3
+          const uint32_t* mg = mapl + c.groups[g].lds_off;
+          const uint32_t rc = mg[33];
+          obs_write_runs<8>(mg, 0, (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu)), lane, PBHC_G, feat, io.obs[g], (u32)env * (u32)pitch_g, c.groups[g].dim, pitch_g,
+                            c.groups[g].clip, clipobs);
+        }
+    }
+    STAMPB(5);
   }
-  // optional outputs of the pre-reset state
-  if (valid) {
-    if (io.ref_body_pos_extend)
-      for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
-    if (io.ref_body_rot_extend)
-      for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
-    if (io.rigid_body_state)
-      for (int b = lane; b < B; b += PBHC_G) {
-        float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
-        st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
-      }
-    if (io.contact_forces)
-      for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
-  }
+  LDS_BARRIER();                                               // bar3: post-reset features are in LDS
+  STAMP(9);
 
-  STAMP(6);
-  // ---------------- phase G: reset_envs_idx for terminated envs (legged_robot_base.py:491-517,
-  // 599-686; motion_tracking.py:265-287,369-378,445-543) ------------------------------------------
-  const bool do_reset = valid && misc[M_RESET] != 0.0f;
-  float etr_val = 0.0f;
-  if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)io.action_delay_idx[env]; }
-  if (do_reset) {
-    const int Q = c.queue_len;
-    for (int d = lane; d < D; d += PBHC_G) {
-      act[d] = 0.0f; actd[d] = 0.0f;
-      float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
-      pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, d, ur);
-      if (c.randomize_pd_gain) {
-        at(io.kp_scale, eD + d) = io.ovr_kp ? at(io.ovr_kp, eD + d) : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
-        at(io.kd_scale, eD + d) = io.ovr_kd ? at(io.ovr_kd, eD + d) : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
-      }
-      if (c.randomize_rfi_lim)
-        at(io.rfi_lim_scale, eD + d) = io.ovr_rfi_lim ? at(io.ovr_rfi_lim, eD + d) : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
-      if (c.use_rao)
-        at(io.rao_scale, eD + d) = io.ovr_rao ? at(io.ovr_rao, eD + d) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
-      if (c.randomize_ctrl_delay)
-        for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)d) *= 0.0f;
-    }
-    for (int i = lane; i < c.hist_dim; i += PBHC_G) {
-      feat[hoff + i] *= 0.0f;
-    }
-    const u32 sbase = (u32)env * (u32)c.num_sum_cols;
-    for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
-      if (io.episode_rew_out) at(io.episode_rew_out, sbase + (u32)i) = at(io.episode_sums, sbase + (u32)i) / c.max_episode_length_s;
-      at(io.episode_sums, sbase + (u32)i) = 0.0f;
-    }
-    if (lane == 0) {
-      misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
-      misc[M_CONTACT0] = 0.0f; misc[M_CONTACT1] = 0.0f; misc[M_CFILT0] = 0.0f; misc[M_CFILT1] = 0.0f;
-      float old_start = misc[M_START];
-      float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
-      io.end_time_ratio_buf[env] = etr;
-      float mlen = m_len;                                  // = tbl.motion_len[mid], in registers since the prologue
-      io.motion_len[env] = mlen;
-      float ue[4];                                     // start phase and control delay of the new episode from one Philox call
-      pbhc::rng_uniform4(rt.seed, env, step_ctr, 6, 0, ue);
-      float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
-      io.motion_start_times[env] = ns;
-      misc[M_NEWSTART] = ns;
-      if (c.randomize_ctrl_delay) {
-        long long nd = io.ovr_delay ? io.ovr_delay[env]
-                                    : (long long)c.ctrl_delay_range[0] + (long long)(ue[1] * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
-        io.action_delay_idx[env] = nd;
-        misc[M_DELAY] = (float)nd;
-      }
-      misc[M_EPLEN] = 0.0f;
-    }
-  }
-  LDS_BARRIER();
-  if (do_reset) {
-    // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
-    // invalidated, motion_tracking.py:378,536-543,477-507)
-    float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
-    if (MODE) {
-      // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
-      // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
-      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
-      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
-    } else {
-      motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
-    }
-  }
-  LDS_BARRIER();
-  if (do_reset && lane == 0) {
-    st3(root, ld3(rp));
-    st4(root + 3, quat_mul(mk4(0.f, 0.f, 0.f, 1.f), ld4(rq)));       // quat_mul(small_random_quaternions(max_angle=0), root_rot)
-    st3(root + 7, ld3(rv));
-    st3(root + 10, ld3(rw));
-  }
-  if (valid && lane == 0) etr_val = io.end_time_ratio_buf[env];
-
-  STAMP(7);
-  // ---------------- phase H: remaining features ---------------------------------------------------
-  if (valid) {
-    const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
-    const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
-    for (int d = lane; d < D; d += PBHC_G) {
-      feat[o_q + d] = q[d] - c.default_dof_pos[d];
-      feat[o_qd + d] = qd[d];
-      feat[o_a + d] = act[d];
-      feat[o_kp + d] = at(io.kp_scale, eD + d);
-      feat[o_kd + d] = at(io.kd_scale, eD + d);
-    }
-    if (lane == 0) {
-      feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];
-      feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];              // a live view of the root state in the reference: reset envs show the reset height
-    }
-    if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
-  }
-  LDS_BARRIER();
-
-  STAMP(8);
-  // ---------------- phase I: observation groups + history write-back ------------------------------
+  // =============== both roles, interval 3: the remaining observation elements (64 lanes per env), noise, state write-back ==========
   // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
   if (valid) {
-    const float noise_cur = pf_noise_cur;
-    const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals: after a global store the
-    const int ngroups = c.num_groups;              // compiler otherwise reloads `c.x` (possible aliasing) and waits on lgkmcnt(0)
+    const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
+    const bool do_reset = misc[M_RESET] != 0.0f;
+    const int l64 = lane + (roleB ? PBHC_G : 0);
     if (map_words > 0) {
-      // compact maps from LDS.  Block of a group: [seg_scale 16][seg_noise 16][nn][noisy entries nn x (j | word << 16)][u16 word per element],
-      // word = 12-bit feature index | 4-bit (scale, noise) segment.  Pass 1 writes every element without noise, 8 per lane in flight;
-      // pass 2 revisits only the noisy elements (a few dozen per group), four per lane per Philox4x32 call.
       for (int g = 0; g < ngroups; ++g) {
         const int dim = c.groups[g].dim, clip = c.groups[g].clip;
+        const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
         const uint32_t* mg = mapl + c.groups[g].lds_off;
         const float* segs = (const float*)mg;
         const int nn = (int)mg[32];
-        const uint32_t* noisy = mg + 33;
-        const uint16_t* m16 = (const uint16_t*)(noisy + nn);
-        const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
-        float* __restrict__ const outg = io.obs[g];                 // uniform base; `ob` + element = 32-bit offset of this env's row
+        const uint32_t rc = mg[33];
+        const int n01 = (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu)), nruns = n01 + (int)((rc >> 16) & 0xFFu);
+        const uint32_t* noisy = mg + PBHC_MAP_HDR + nruns;
+        float* __restrict__ const outg = io.obs[g];
         const u32 ob = (u32)env * (u32)pitch_g;
-        if (((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) == 0)) {
-          // rows start 8-byte aligned: a lane takes PAIRS of elements — one 32-bit LDS word holds both map entries, one 8-byte store both values
-          const uint32_t* m32 = (const uint32_t*)m16;
-          const int npair = (dim + 1) >> 1;
-          // rows padded by at least two floats (ours are): lanes past the end store into the padding instead of being predicated off,
-          // and read a clamped map word — the batch is branch-free
-          const bool pad_ok = pitch_g >= dim + 2 + (dim & 1);
-          for (int p0 = lane; p0 < npair; p0 += 8 * PBHC_G) {
-            uint32_t w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = m32[min(p0 + u * PBHC_G, npair - 1)];
-#ifdef PBHC_STAMPS
-            if (g == 1 && p0 == lane) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(20); }
-#endif
-            float xa[8], xb[8], sa[8], sb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const uint32_t lo = w[u] & 0xFFFFu, hi = w[u] >> 16;
-              xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
-              xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
+        const bool paired = ((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(outg) & 7) == 0);
+        if (paired) {
+          // class 2 (post-reset features): every output element is written exactly once, by one lane ...
+          obs_write_runs<4>(mg, n01, nruns, l64, 2 * PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
+          // ... except for a terminated env, whose history was zeroed: the lanes that wrote classes 0 / 1 before bar3 write them again
+          // (same lane, same address: program order)
+          if (do_reset && roleB) obs_write_runs<8>(mg, 0, n01, lane, PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
+        } else {
+          // rows that are not 8-byte aligned (caller-owned outputs): every run, element by element, here only
+          const uint16_t* m16 = (const uint16_t*)(noisy + nn);
+          const uint32_t* runs = mg + PBHC_MAP_HDR;
+          for (int r = 0; r < nruns; ++r) {
+            const uint32_t rw = runs[r];
+            const int j0 = 2 * (int)(rw & 0xFFFFu), j1 = min(j0 + 2 * (int)(rw >> 16), dim);
+            for (int j = j0 + l64; j < j1; j += 2 * PBHC_G) {
+              const uint32_t w = m16[j];
+              float v = feat[w & 0xFFFu] * segs[w >> 12];
+              if (clip) v = clampf(v, -clipobs, clipobs);
+              at(outg, ob + (u32)j) = v;
             }
-#ifdef PBHC_STAMPS
-            if (g == 1 && p0 == lane) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(21); }
-#endif
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int j = 2 * (p0 + u * PBHC_G);
-              float va = xa[u] * sa[u], vb = xb[u] * sb[u];
-              if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
-              if (pad_ok) {
-                const int jj = (j + 1 < dim) ? j : ((j < dim) ? j : pitch_g - 2);      // a trailing odd element writes its pair's second half into the padding
-                *reinterpret_cast<float2*>(&at(outg, ob + (u32)jj)) = make_float2(va, vb);
-              } else if (j + 1 < dim) *reinterpret_cast<float2*>(&at(outg, ob + (u32)j)) = make_float2(va, vb);
-              else if (j < dim) at(outg, ob + (u32)j) = va;
-            }
-#ifdef PBHC_STAMPS
-            if (g == 1 && p0 == lane) STAMP(22);
-#endif
-          }
-        } else
-        for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
-          uint32_t w[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { const int j = j0 + u * PBHC_G; w[u] = j < dim ? m16[j] : 0u; }
-          float x[8], sc[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { x[u] = feat[w[u] & 0xFFFu]; sc[u] = segs[w[u] >> 12]; }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * PBHC_G;
-            float v = x[u] * sc[u];
-            if (clip) v = clampf(v, -clipobs, clipobs);
-            if (j < dim) at(outg, ob + (u32)j) = v;
           }
         }
-        STAMP(12 + 2 * g);
-        for (int k0 = 4 * lane; k0 < nn; k0 += 4 * PBHC_G) {
+        // noisy elements — and the other element of a pair that holds one — belong to no run: they are written here only, four per lane
+        // per Philox4x32 call
+        for (int k0 = 4 * l64; k0 < nn; k0 += 8 * PBHC_G) {
           uint32_t r[4];
           philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16 + g, (uint32_t)(k0 >> 2), r);
 #pragma unroll
@@ -1139,70 +1262,72 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
               at(outg, ob + (e & 0xFFFFu)) = v;
             }
         }
-        STAMP(13 + 2 * g);
       }
-    } else
-    for (int g = 0; g < c.num_groups; ++g) {
-      const int dim = c.groups[g].dim, clip = c.groups[g].clip;
-      const int* __restrict__ mdst = rt.groups[g].dst;
-      const int* __restrict__ msrc = rt.groups[g].src;
-      const float* __restrict__ mscale = rt.groups[g].scale;
-      const float* __restrict__ mnoise = rt.groups[g].noise;
-      float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
-      for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
-        int si[8], di[8]; float sc[8], ns[8];
+    } else if (!roleB) {
+      for (int g = 0; g < c.num_groups; ++g) {
+        const int dim = c.groups[g].dim, clip = c.groups[g].clip;
+        const int* __restrict__ mdst = rt.groups[g].dst;
+        const int* __restrict__ msrc = rt.groups[g].src;
+        const float* __restrict__ mscale = rt.groups[g].scale;
+        const float* __restrict__ mnoise = rt.groups[g].noise;
+        float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
+        for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
+          int si[8], di[8]; float sc[8], ns[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u * PBHC_G;
-          const bool ok = j < dim;
-          si[u] = ok ? msrc[j] : 0; sc[u] = ok ? mscale[j] : 0.0f; ns[u] = ok ? mnoise[j] : 0.0f;
-          di[u] = ok ? (mdst ? mdst[j] : j) : 0;
-        }
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * PBHC_G;
+            const bool ok = j < dim;
+            si[u] = ok ? msrc[j] : 0; sc[u] = ok ? mscale[j] : 0.0f; ns[u] = ok ? mnoise[j] : 0.0f;
+            di[u] = ok ? (mdst ? mdst[j] : j) : 0;
+          }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u * PBHC_G;
-          if (j < dim) {
-            float x = feat[si[u]];
-            if (ns[u] != 0.0f) x = x + (rng_uniform(rt.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
-            x = x * sc[u];
-            if (clip) x = clampf(x, -c.clip_observations, c.clip_observations);
-            out[di[u]] = x;
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * PBHC_G;
+            if (j < dim) {
+              float x = feat[si[u]];
+              if (ns[u] != 0.0f) x = x + (rng_uniform(rt.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
+              x = x * sc[u];
+              if (clip) x = clampf(x, -c.clip_observations, c.clip_observations);
+              out[di[u]] = x;
+            }
           }
         }
       }
     }
-    STAMP(9);
-    // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
-    for (int d = lane; d < D; d += PBHC_G) {
-      at(io.actions, eD + d) = act[d];
-      at(io.last_actions, eD + d) = act[d];
-      at(io.actions_after_delay, eD + d) = actd[d];
-      at(io.torques, eD + d) = tau[d];
-      at(io.dof_state, (eD + d) * 2) = q[d];
-      at(io.dof_state, (eD + d) * 2 + 1) = qd[d];
-      at(io.last_dof_pos, eD + d) = q[d];
-      at(io.last_dof_vel, eD + d) = qd[d];
-    }
-    if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];
-    if (lane < NF) {
-      const u32 fo = (u32)env * (u32)NF + (u32)lane;
-      at(io.feet_air_time, fo) = misc[M_FAT0 + lane];
-      at(io.contacts, fo) = misc[M_CONTACT0 + lane];
-      at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];
-      at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];
-      at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];
-    }
-    if (lane == 0) {
-      io.episode_length_buf[env] = (long long)misc[M_EPLEN];
-      io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];
-      io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;
-      io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;
+    if (!roleB) {
+      STAMP(10);
+      // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
+      for (int dd = lane; dd < D; dd += PBHC_G) {
+        at(io.actions, eD + dd) = act[dd];
+        at(io.last_actions, eD + dd) = act[dd];
+        at(io.actions_after_delay, eD + dd) = actd[dd];
+        at(io.torques, eD + dd) = tau[dd];
+        at(io.dof_state, (eD + dd) * 2) = q[dd];
+        at(io.dof_state, (eD + dd) * 2 + 1) = qd[dd];
+        at(io.last_dof_pos, eD + dd) = q[dd];
+        at(io.last_dof_vel, eD + dd) = qd[dd];
+      }
+      if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];
+      if (lane < NF) {
+        const u32 fo = (u32)env * (u32)NF + (u32)lane;
+        at(io.feet_air_time, fo) = misc[M_FAT0 + lane];
+        at(io.contacts, fo) = misc[M_CONTACT0 + lane];
+        at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];
+        at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];
+        at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];
+      }
+      if (lane == 0) {
+        io.episode_length_buf[env] = (long long)misc[M_EPLEN];
+        io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];
+        io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;
+        io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;
+      }
     }
   }
 
-  STAMP(10);
+  STAMP(11);
   // ---------------- workgroup partial sums for the host-side scalars of the reference ------------
-  if (lane == 0) {
+  if (!roleB && lane == 0) {
     float* bpq = blockpart + le * PBHC_NP;
     for (int k = 0; k < PBHC_NP; ++k) bpq[k] = 0.0f;
     if (valid) {
@@ -1221,13 +1346,13 @@ __global__ __launch_bounds__(PBHC_G* PBHC_EPB, PBHC_MIN_WAVES) void k_env_step(c
       }
     }
   }
-  LDS_BARRIER();
+  LDS_BARRIER();                                               // bar4
   if (threadIdx.x < PBHC_NP) {
     float v = 0.0f;
     for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];
     partials[(u32)blockIdx.x * (u32)PBHC_NP + threadIdx.x] = v;
   }
-  STAMP(11);
+  STAMP(12);
   WG_STAMP(1);
 }
 
@@ -1612,7 +1737,7 @@ int pbhc_abi_version(void) { return PBHC_ABI_VERSION; }
 #ifdef PBHC_STAMPS
 int pbhc_debug_read_stamps(unsigned long long* out, int n) {
   HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32)));
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64)));
   return PBHC_OK;
 }
 int pbhc_debug_read_wg_times(unsigned long long* out, int num_workgroups) {
@@ -1718,7 +1843,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   if (cfg->map_lds_words > 0) {
     int need = 0;
     for (int g = 0; g < cfg->num_groups; ++g) {
-      ARG_CHECK(cfg->groups[g].dst == nullptr && cfg->groups[g].lds_off == need && cfg->groups[g].map_words >= 33 + ((cfg->groups[g].dim + 1) >> 1));
+      ARG_CHECK(cfg->groups[g].dst == nullptr && cfg->groups[g].lds_off == need && cfg->groups[g].map_words >= PBHC_MAP_HDR + ((cfg->groups[g].dim + 1) >> 1));
       need += cfg->groups[g].map_words;
     }
     ARG_CHECK(need == cfg->map_lds_words && cfg->feat_dim <= 4096 && cfg->map_image != nullptr);
@@ -1806,10 +1931,10 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   // begin / end timestamps), so the reading is the kernel's execution time, without the dispatch gap a hipEventRecord pair would add
   hipEvent_t pe0 = e->profile ? e->ev0[slot] : nullptr, pe1 = e->profile ? e->ev1[slot] : nullptr;
   if (e->cfg.tracking_mode)
-    hipExtLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
+    hipExtLaunchKernelGGL(k_env_step<1>, dim3(e->nblocks), dim3(PBHC_TPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
                           (const double*)e->d_glob, e->d_partials, e->lds_stride, (const float*)e->d_skc, (const uint32_t*)e->cfg.map_image);
   else
-    hipExtLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_G * PBHC_EPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
+    hipExtLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_TPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
                           (const double*)e->d_glob, e->d_partials, e->lds_stride, (const float*)e->d_skc, (const uint32_t*)e->cfg.map_image);
   if (e->profile) e->prof_count++;
   hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames,

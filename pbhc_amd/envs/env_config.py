@@ -369,6 +369,14 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
             c.feat_off[K["PBHC_F_" + name]] = trash
             off = max(off, trash + n)
     c.feat_dim = off
+    # readiness class of every feature word (see the compact maps below): which phase of the step kernel produces it
+    CLASS0 = {"HISTORY", "ZERO", "BASE_LIN_VEL", "BASE_ANG_VEL", "PROJECTED_GRAVITY", "REF_MOTION_PHASE", "RELYAW", "ROLL_PITCH", "DR_BASE_COM",
+              "DR_LINK_MASS", "DR_FRICTION", "DR_BASE_MASS", "REF_CONTACT_MASK", "FUT_ROOT_HEIGHT", "FUT_ROLL_PITCH", "FUT_BASE_LIN_VEL",
+              "FUT_BASE_ANG_VEL", "FUT_DOF_POS", "FUT_LOCAL_KEY_POS"}
+    CLASS2 = {"DOF_POS", "DOF_VEL", "ACTIONS", "DR_KP", "DR_KD", "DR_CTRL_DELAY", "BASE_POS_Z", "CONTACT_MASK"}
+    feat_class = np.ones(max(off, 1), dtype=np.int64)
+    for name, o_ in feat_off.items():
+        feat_class[o_:o_ + fdim[name]] = 0 if name in CLASS0 else (2 if name in CLASS2 else 1)
     c.dr_link_mass_dim = sim_link_mass_dim
     L.feat_off, L.feat_dim_each = feat_off, fdim
 
@@ -494,10 +502,32 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
             tabs = np.zeros(32, dtype=np.float32)
             for k, (a_, b_) in enumerate(pairs):
                 tabs[k], tabs[16 + k] = a_, b_
-            noisy = np.array([j | (int(pk[j]) << 16) for j in range(len(src)) if ns[j] != 0.0], dtype=np.uint32)
             if len(src) >= 65536:
                 raise _lib.PbhcError("observation group too wide for the compact maps")
-            blk = np.concatenate([tabs.view(np.uint32), np.array([len(noisy)], dtype=np.uint32), noisy, pk.view(np.uint32)])
+            # The kernel writes a row in element PAIRS (one 8-byte store), in three passes by readiness class of the pair's sources
+            # (feat_class): 0 = ready before the body state is (history, DR, per-env scalars, reference / future targets), 1 = difference
+            # features, 2 = post-reset features.  A pair that holds a noisy element belongs to no pass: both of its elements go to the
+            # noise list, which the kernel visits last.  Runs = maximal stretches of consecutive pairs of one class.
+            n_el = len(src)
+            npair = (n_el + 1) // 2
+            pair_noisy = [any(ns[j] != 0.0 for j in (2 * p_, 2 * p_ + 1) if j < n_el) for p_ in range(npair)]
+            pair_class = [max(int(feat_class[src[j]]) for j in (2 * p_, 2 * p_ + 1) if j < n_el) for p_ in range(npair)]
+            runs = {0: [], 1: [], 2: []}
+            p_ = 0
+            while p_ < npair:
+                if pair_noisy[p_]:
+                    p_ += 1
+                    continue
+                q_ = p_
+                while q_ + 1 < npair and not pair_noisy[q_ + 1] and pair_class[q_ + 1] == pair_class[p_]:
+                    q_ += 1
+                runs[pair_class[p_]].append(p_ | ((q_ - p_ + 1) << 16))
+                p_ = q_ + 1
+            if any(len(r) > 255 for r in runs.values()):
+                raise _lib.PbhcError("observation group too fragmented for the compact maps")
+            noisy = np.array([j | (int(pk[j]) << 16) for j in range(n_el) if pair_noisy[j // 2]], dtype=np.uint32)
+            hdr = np.array([len(noisy), len(runs[0]) | (len(runs[1]) << 8) | (len(runs[2]) << 16)], dtype=np.uint32)
+            blk = np.concatenate([tabs.view(np.uint32), hdr, np.array(runs[0] + runs[1] + runs[2], dtype=np.uint32), noisy, pk.view(np.uint32)])
             image.append(blk)
             c.groups[i].dst = None                                  # identity
             c.groups[i].lds_off = lds_off

@@ -26,21 +26,23 @@ _lib.check(lib.pbhc_env_profile_read(env._env, buf, 100, C.byref(cnt)))
 ms = sorted(buf[i] for i in range(cnt.value))
 print(f"k_env_step N={N}: median {ms[len(ms)//2]*1e3:.1f} us  min {ms[0]*1e3:.1f} us  mean {sum(ms)/len(ms)*1e3:.1f} us")
 if hasattr(lib, "pbhc_debug_read_stamps"):
-    st = (C.c_ulonglong * 32)()
-    lib.pbhc_debug_read_stamps(st, 32)
-    names = ["A load+torque", "B fk", "C scalars", "D lookup", "E diffs", "F reward", "G reset", "H features", "I obs", "J writeback", "partials"]
-    tot = st[11] - st[0]
-    for i, n in enumerate(names):
-        d = st[i + 1] - st[i]
-        print(f"  {n:16s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
-    print(f"  total {tot} cycles")
-    if st[12]:
-        prev = st[8]
-        for g in range(3):
-            print(f"  obs group {g}: pass1 {st[12 + 2 * g] - prev} cyc, noisy pass {st[13 + 2 * g] - st[12 + 2 * g]} cyc")
-            prev = st[13 + 2 * g]
-        if st[20]:
-            print(f"  group 1 first batch: map reads {st[20] - st[13]} cyc, feature+segment reads {st[21] - st[20]} cyc, scale/clip/stores {st[22] - st[21]} cyc")
+    st = (C.c_ulonglong * 64)()
+    lib.pbhc_debug_read_stamps(st, 64)
+    # role A (thread 0 of workgroup 0): stamps 0..12 at its phase boundaries; role B (thread 128): stamps 32+1..32+5
+    namesA = ["loads -> bar0", "FK chain", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features", "wait bar3",
+              "obs class 2 + noise", "J writeback", "partials"]
+    tot = st[12] - st[0]
+    print("  role A (dynamics chain):")
+    for i, n in enumerate(namesA):
+        dd = st[i + 1] - st[i]
+        print(f"    {n:28s} {dd:8d} cyc  {100.0 * dd / tot:5.1f}%")
+    print(f"    total {tot} cycles")
+    namesB = ["C scalars (from A's start)", "D reference frame", "futures", "E joint-space + outputs (from bar1)", "obs classes 0/1 + outputs (from bar2)"]
+    refs = [st[0], st[32 + 1], st[32 + 2], st[3], st[5]]
+    print("  role B (reference / observations):")
+    for i, n in enumerate(namesB):
+        dd = st[32 + i + 1] - refs[i]
+        print(f"    {n:40s} ends {st[32 + i + 1] - st[0]:8d} cyc after start  (+{dd})")
 
 if hasattr(lib, "pbhc_debug_read_wg_times"):
     nwg = (N + 3) // 4
