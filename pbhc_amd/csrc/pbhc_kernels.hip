@@ -397,43 +397,42 @@ extern __shared__ float smem[];
 
 #define PBHC_TPB (2 * PBHC_G * PBHC_EPB)                   // threads per workgroup of k_env_step: two roles x 32 lanes x 4 envs
 #define PBHC_HREG (384 / PBHC_G)                           // history words per lane held in registers (hist_dim <= 384)
-#define PBHC_MAP_HDR 34                                    // compact map block: [16 scales][16 noises][nn][n_runs0 | n_runs1 << 8 | n_runs2 << 16][runs][noisy][pairs]
+#define PBHC_MAP_HDR 35                                    // compact map block: [16 scales][16 noises][nn][n_early][n_late][u16 pair list][noisy][pairs]
 
-// Observation elements of group block `mg` whose pair runs are [r0, r1): out[j] = clip(feat[src[j]] * scale[seg[j]]) for the element pairs of
-// each run (a run = consecutive pairs of one readiness class, built on the host).  `nl` lanes (32 or 64) of this env cooperate, `l` is this
-// lane's index among them.  Lanes past the end of a run recompute its last pair and store the same value to the same address (branch-free).
+// Observation elements of group block `mg`: out[j] = clip(feat[src[j]] * scale[seg[j]]) for the element pairs named by entries [k0, k1) of
+// the block's pair list (16-bit pair indices, grouped on the host by readiness class).  `nl` lanes (32 or 64) of this env cooperate, `l` is
+// this lane's index among them; every pair costs one list read, one map word, four feature / scale reads and ONE 8-byte store.  Lanes past
+// the end recompute the last entry and store the same value to the same address (branch-free batches).
 template <int BATCH>
-__device__ __forceinline__ void obs_write_runs(const uint32_t* mg, int r0, int r1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
+__device__ __forceinline__ void obs_write_list(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
                                                int dim, int pitch_g, int clip, float clipobs) {
   const float* segs = (const float*)mg;
   const int nn = (int)mg[32];
-  const uint32_t rc = mg[33];
-  const int nruns = (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu) + ((rc >> 16) & 0xFFu));
-  const uint32_t* runs = mg + PBHC_MAP_HDR;
-  const uint32_t* m32 = runs + nruns + nn;
+  const int nlist = (int)(mg[33] + mg[34]);
+  const uint16_t* list = (const uint16_t*)(mg + PBHC_MAP_HDR);
+  const uint32_t* m32 = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1) + nn;
   const bool pad_ok = pitch_g >= dim + 1;                  // a trailing odd element stores its pair's second half into the row padding
-  for (int r = r0; r < r1; ++r) {
-    const uint32_t rw = runs[r];
-    const int ps = (int)(rw & 0xFFFFu), pe = ps + (int)(rw >> 16) - 1;
-    for (int p0 = ps + l; p0 <= pe; p0 += BATCH * nl) {
-      uint32_t w[BATCH];
+  for (int e0 = k0 + l; e0 < k1; e0 += BATCH * nl) {
+    int p[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) w[u] = m32[min(p0 + u * nl, pe)];
-      float xa[BATCH], xb[BATCH], sa[BATCH], sb[BATCH];
+    for (int u = 0; u < BATCH; ++u) p[u] = (int)list[min(e0 + u * nl, k1 - 1)];
+    uint32_t w[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const uint32_t lo = w[u] & 0xFFFFu, hi = w[u] >> 16;
-        xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
-        xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
-      }
+    for (int u = 0; u < BATCH; ++u) w[u] = m32[p[u]];
+    float xa[BATCH], xb[BATCH], sa[BATCH], sb[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const int j = 2 * min(p0 + u * nl, pe);
-        float va = xa[u] * sa[u], vb = xb[u] * sb[u];
-        if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
-        if (j + 1 < dim || pad_ok) *reinterpret_cast<float2*>(&at(outg, ob + (unsigned int)j)) = make_float2(va, vb);
-        else at(outg, ob + (unsigned int)j) = va;
-      }
+    for (int u = 0; u < BATCH; ++u) {
+      const uint32_t lo = w[u] & 0xFFFFu, hi = w[u] >> 16;
+      xa[u] = feat[lo & 0xFFFu]; sa[u] = segs[lo >> 12];
+      xb[u] = feat[hi & 0xFFFu]; sb[u] = segs[hi >> 12];
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int j = 2 * p[u];
+      float va = xa[u] * sa[u], vb = xb[u] * sb[u];
+      if (clip) { va = __builtin_amdgcn_fmed3f(va, -clipobs, clipobs); vb = __builtin_amdgcn_fmed3f(vb, -clipobs, clipobs); }
+      if (j + 1 < dim || pad_ok) *reinterpret_cast<float2*>(&at(outg, ob + (unsigned int)j)) = make_float2(va, vb);
+      else at(outg, ob + (unsigned int)j) = va;
     }
   }
 }
@@ -482,7 +481,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   typedef unsigned int u32;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
-  float* blockpart = skc + SKC_WORDS;                         // [EPB][PBHC_NP]
+  float* blockpart = skc + ((Bx * SKC_W + 3) & ~3);           // [EPB][PBHC_NP]
   uint32_t* mapl = (uint32_t*)(blockpart + PBHC_EPB * PBHC_NP);   // [map_lds_words] compact observation maps, shared by the workgroup
   const float dt = c.dt;
   const u32 eD = (u32)env * (u32)D;
@@ -1189,16 +1188,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         }
       if (io.contact_forces)
         for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
-      // classes 0 (history, DR, per-env scalars, reference / future targets: this role's own products) and 1 (difference features of
-      // interval 2a) of every group; a terminated env's history elements are rewritten (as zeros) after bar3
+      // the "early" pairs of every group: sources that are final by now — history, DR, per-env scalars, reference / future targets (this
+      // role's own products) and the difference features of interval 2a; a terminated env's are rewritten (history zeroed) after bar3
       if (map_words > 0)
         for (int g = 0; g < ngroups; ++g) {
           const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
           if (((pitch_g & 1) != 0) || ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) != 0)) continue;      // unaligned rows: everything after bar3
           const uint32_t* mg = mapl + c.groups[g].lds_off;
-          const uint32_t rc = mg[33];
-          obs_write_runs<8>(mg, 0, (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu)), lane, PBHC_G, feat, io.obs[g], (u32)env * (u32)pitch_g, c.groups[g].dim, pitch_g,
-                            c.groups[g].clip, clipobs);
+          obs_write_list<8>(mg, 0, (int)mg[33], lane, PBHC_G, feat, io.obs[g], (u32)env * (u32)pitch_g, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs);
         }
     }
     STAMPB(5);
@@ -1219,26 +1216,24 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         const uint32_t* mg = mapl + c.groups[g].lds_off;
         const float* segs = (const float*)mg;
         const int nn = (int)mg[32];
-        const uint32_t rc = mg[33];
-        const int n01 = (int)((rc & 0xFFu) + ((rc >> 8) & 0xFFu)), nruns = n01 + (int)((rc >> 16) & 0xFFu);
-        const uint32_t* noisy = mg + PBHC_MAP_HDR + nruns;
+        const int n_early = (int)mg[33], nlist = n_early + (int)mg[34];
+        const uint32_t* noisy = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1);
         float* __restrict__ const outg = io.obs[g];
         const u32 ob = (u32)env * (u32)pitch_g;
         const bool paired = ((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(outg) & 7) == 0);
         if (paired) {
-          // class 2 (post-reset features): every output element is written exactly once, by one lane ...
-          obs_write_runs<4>(mg, n01, nruns, l64, 2 * PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
-          // ... except for a terminated env, whose history was zeroed: the lanes that wrote classes 0 / 1 before bar3 write them again
+          // the "late" pairs (post-reset features): every output element is written exactly once, by one lane ...
+          obs_write_list<2>(mg, n_early, nlist, l64, 2 * PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
+          // ... except for a terminated env, whose history was zeroed: the lanes that wrote the early pairs before bar3 write them again
           // (same lane, same address: program order)
-          if (do_reset && roleB) obs_write_runs<8>(mg, 0, n01, lane, PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
+          if (do_reset && roleB) obs_write_list<8>(mg, 0, n_early, lane, PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
         } else {
-          // rows that are not 8-byte aligned (caller-owned outputs): every run, element by element, here only
+          // rows that are not 8-byte aligned (caller-owned outputs): every listed pair, element by element, here only
           const uint16_t* m16 = (const uint16_t*)(noisy + nn);
-          const uint32_t* runs = mg + PBHC_MAP_HDR;
-          for (int r = 0; r < nruns; ++r) {
-            const uint32_t rw = runs[r];
-            const int j0 = 2 * (int)(rw & 0xFFFFu), j1 = min(j0 + 2 * (int)(rw >> 16), dim);
-            for (int j = j0 + l64; j < j1; j += 2 * PBHC_G) {
+          const uint16_t* list = (const uint16_t*)(mg + PBHC_MAP_HDR);
+          for (int e = l64; e < 2 * nlist; e += 2 * PBHC_G) {
+            const int j = 2 * (int)list[e >> 1] + (e & 1);
+            if (j < dim) {
               const uint32_t w = m16[j];
               float v = feat[w & 0xFFFu] * segs[w >> 12];
               if (clip) v = clampf(v, -clipobs, clipobs);
@@ -1850,7 +1845,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   }
   {
     // the compact maps must not cost a resident workgroup per CU (160 KB LDS): otherwise the per-element maps stay in global memory
-    const size_t base = ((size_t)PBHC_EPB * e->lds_stride + SKC_WORDS + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+    const size_t base = ((size_t)PBHC_EPB * e->lds_stride + (size_t)((Bx * SKC_W + 3) & ~3) + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
     const size_t with = base + (size_t)cfg->map_lds_words * sizeof(float);
     if (cfg->map_lds_words > 0 && (160 * 1024) / with < (160 * 1024) / base) e->cfg.map_lds_words = 0;
     e->lds_bytes = e->cfg.map_lds_words > 0 ? with : base;

@@ -504,30 +504,20 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
                 tabs[k], tabs[16 + k] = a_, b_
             if len(src) >= 65536:
                 raise _lib.PbhcError("observation group too wide for the compact maps")
-            # The kernel writes a row in element PAIRS (one 8-byte store), in three passes by readiness class of the pair's sources
-            # (feat_class): 0 = ready before the body state is (history, DR, per-env scalars, reference / future targets), 1 = difference
-            # features, 2 = post-reset features.  A pair that holds a noisy element belongs to no pass: both of its elements go to the
-            # noise list, which the kernel visits last.  Runs = maximal stretches of consecutive pairs of one class.
+            # The kernel writes a row in element PAIRS (one 8-byte store), in two passes by readiness of the pair's sources (feat_class):
+            # "early" = everything but the post-reset features (history, DR, per-env scalars, reference / future targets, difference
+            # features), written while the dynamics chain still runs; "late" = pairs that read a post-reset feature.  A pair that holds a
+            # noisy element belongs to neither: both of its elements go to the noise list, which the kernel visits last.
             n_el = len(src)
             npair = (n_el + 1) // 2
             pair_noisy = [any(ns[j] != 0.0 for j in (2 * p_, 2 * p_ + 1) if j < n_el) for p_ in range(npair)]
-            pair_class = [max(int(feat_class[src[j]]) for j in (2 * p_, 2 * p_ + 1) if j < n_el) for p_ in range(npair)]
-            runs = {0: [], 1: [], 2: []}
-            p_ = 0
-            while p_ < npair:
-                if pair_noisy[p_]:
-                    p_ += 1
-                    continue
-                q_ = p_
-                while q_ + 1 < npair and not pair_noisy[q_ + 1] and pair_class[q_ + 1] == pair_class[p_]:
-                    q_ += 1
-                runs[pair_class[p_]].append(p_ | ((q_ - p_ + 1) << 16))
-                p_ = q_ + 1
-            if any(len(r) > 255 for r in runs.values()):
-                raise _lib.PbhcError("observation group too fragmented for the compact maps")
+            pair_late = [any(int(feat_class[src[j]]) == 2 for j in (2 * p_, 2 * p_ + 1) if j < n_el) for p_ in range(npair)]
+            early = [p_ for p_ in range(npair) if not pair_noisy[p_] and not pair_late[p_]]
+            late = [p_ for p_ in range(npair) if not pair_noisy[p_] and pair_late[p_]]
+            plist = np.array(early + late + [0] * ((len(early) + len(late)) % 2), dtype=np.uint16)
             noisy = np.array([j | (int(pk[j]) << 16) for j in range(n_el) if pair_noisy[j // 2]], dtype=np.uint32)
-            hdr = np.array([len(noisy), len(runs[0]) | (len(runs[1]) << 8) | (len(runs[2]) << 16)], dtype=np.uint32)
-            blk = np.concatenate([tabs.view(np.uint32), hdr, np.array(runs[0] + runs[1] + runs[2], dtype=np.uint32), noisy, pk.view(np.uint32)])
+            hdr = np.array([len(noisy), len(early), len(late)], dtype=np.uint32)
+            blk = np.concatenate([tabs.view(np.uint32), hdr, plist.view(np.uint32), noisy, pk.view(np.uint32)])
             image.append(blk)
             c.groups[i].dst = None                                  # identity
             c.groups[i].lds_off = lds_off
