@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 3
+#define PBHC_ABI_VERSION 4
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -161,13 +161,17 @@ typedef struct PbhcOutMap {
   int32_t dim;               /* number of elements this map writes */
   int32_t clip;              /* 1: clip to +-clip_observations */
   int32_t pitch;             /* floats per env row of the output tensor */
-  int32_t pad_;
+  int32_t role;              /* which half of a k_env_step workgroup writes this row: 0 = the dynamics waves (after their reward phase),
+                              * 1 = the reference / observation waves; balanced by row width on the host */
   const int32_t* dst;        /* device [dim] position inside the row, or NULL = identity */
   const int32_t* src;        /* device [dim] index into the feature row */
   const float* scale;        /* device [dim] */
   const float* noise;        /* device [dim] noise scale (0 = none) */
   /* compact form (PbhcEnvConfig.map_image): word offset and size of this group's block
-   * [seg_scale 16 floats][seg_noise 16 floats][nn][nn noisy entries: j | word[j] << 16][u16 word[j] x dim], word[j] = src[j] | seg[j] << 12 */
+   * [seg_scale 16 floats][seg_noise 16 floats][nn_early][nn_late][n_early][n_late][u16 pair index x (n_early + n_late), padded to a word]
+   * [noisy entries: j | word[j] << 16, early then late][u16 word[j] x dim, padded to a pair], word[j] = src[j] | seg[j] << 12.
+   * A row is written in element pairs (2p, 2p+1): "late" pairs read a post-reset feature, a pair holding a noisy element is in neither
+   * list (both of its elements are noise entries) */
   int32_t lds_off;
   int32_t map_words;
 } PbhcOutMap;

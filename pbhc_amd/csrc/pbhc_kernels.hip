@@ -397,7 +397,8 @@ extern __shared__ float smem[];
 
 #define PBHC_TPB (2 * PBHC_G * PBHC_EPB)                   // threads per workgroup of k_env_step: two roles x 32 lanes x 4 envs
 #define PBHC_HREG (384 / PBHC_G)                           // history words per lane held in registers (hist_dim <= 384)
-#define PBHC_MAP_HDR 35                                    // compact map block: [16 scales][16 noises][nn][n_early][n_late][u16 pair list][noisy][pairs]
+#define PBHC_MAPREG 8                                      // map words per role-B thread held in registers while staged (the rest: a loop)
+#define PBHC_MAP_HDR 36                                    // compact map block: [16 scales][16 noises][nn_early][nn_late][n_early][n_late][u16 pair list][noisy][pairs]
 
 // Observation elements of group block `mg`: out[j] = clip(feat[src[j]] * scale[seg[j]]) for the element pairs named by entries [k0, k1) of
 // the block's pair list (16-bit pair indices, grouped on the host by readiness class).  `nl` lanes (32 or 64) of this env cooperate, `l` is
@@ -407,8 +408,8 @@ template <int BATCH>
 __device__ __forceinline__ void obs_write_list(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
                                                int dim, int pitch_g, int clip, float clipobs) {
   const float* segs = (const float*)mg;
-  const int nn = (int)mg[32];
-  const int nlist = (int)(mg[33] + mg[34]);
+  const int nn = (int)(mg[32] + mg[33]);
+  const int nlist = (int)(mg[34] + mg[35]);
   const uint16_t* list = (const uint16_t*)(mg + PBHC_MAP_HDR);
   const uint32_t* m32 = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1) + nn;
   const bool pad_ok = pitch_g >= dim + 1;                  // a trailing odd element stores its pair's second half into the row padding
@@ -434,6 +435,48 @@ __device__ __forceinline__ void obs_write_list(const uint32_t* mg, int k0, int k
       if (j + 1 < dim || pad_ok) *reinterpret_cast<float2*>(&at(outg, ob + (unsigned int)j)) = make_float2(va, vb);
       else at(outg, ob + (unsigned int)j) = va;
     }
+  }
+}
+
+// The same element by element, for caller-owned rows that are not 8-byte aligned.
+__device__ __forceinline__ void obs_write_list_unaligned(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
+                                                         int dim, int clip, float clipobs) {
+  const float* segs = (const float*)mg;
+  const int nn = (int)(mg[32] + mg[33]);
+  const int nlist = (int)(mg[34] + mg[35]);
+  const uint16_t* list = (const uint16_t*)(mg + PBHC_MAP_HDR);
+  const uint16_t* m16 = (const uint16_t*)(mg + PBHC_MAP_HDR + ((nlist + 1) >> 1) + nn);
+  for (int e = 2 * k0 + l; e < 2 * k1; e += nl) {
+    const int j = 2 * (int)list[e >> 1] + (e & 1);
+    if (j < dim) {
+      const uint32_t w = m16[j];
+      float v = feat[w & 0xFFFu] * segs[w >> 12];
+      if (clip) v = clampf(v, -clipobs, clipobs);
+      at(outg, ob + (unsigned int)j) = v;
+    }
+  }
+}
+
+// Noisy elements [k0, k1) of the block's noise list — and the other element of a pair that holds one: such pairs belong to no pair list —
+// out[j] = clip((feat[src] + (2U - 1) * noise * curriculum) * scale), four entries per lane per Philox4x32 call (helpers.py:128-152).
+__device__ __forceinline__ void obs_write_noisy(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
+                                                int clip, float clipobs, float noise_cur, uint64_t seed, uint32_t env, uint32_t step_ctr, uint32_t stream) {
+  const float* segs = (const float*)mg;
+  const int nlist = (int)(mg[34] + mg[35]);
+  const uint32_t* noisy = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1);
+  for (int kb = k0 + 4 * l; kb < k1; kb += 4 * nl) {
+    uint32_t r[4];
+    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), env, step_ctr, stream, (uint32_t)(kb >> 2), r);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (kb + u < k1) {
+        const uint32_t e = noisy[kb + u];
+        const uint32_t w = e >> 16;
+        const int seg = w >> 12;
+        float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
+        if (clip) v = clampf(v, -clipobs, clipobs);
+        at(outg, ob + (e & 0xFFFFu)) = v;
+      }
   }
 }
 
@@ -495,21 +538,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
   STAMP(0);
 
-  // ---------------- shared staging: skeleton constants + compact observation maps, loads issued first ----------------------------
-#define SKC_REGS2 ((SKC_WORDS + PBHC_TPB - 1) / PBHC_TPB)
-#define PBHC_MAPREG (MODE ? 8 : 4)
-  float skreg[SKC_REGS2];
-  {
-    const int n = Bx * SKC_W;
-#pragma unroll
-    for (int u = 0; u < SKC_REGS2; ++u) { const int i = threadIdx.x + u * PBHC_TPB; skreg[u] = skc_img[min(i, n - 1)]; }
-  }
-  uint32_t mreg[PBHC_MAPREG];
-  if (map_words > 0) {
-#pragma unroll
-    for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min((int)threadIdx.x + u * PBHC_TPB, map_words - 1)];
-  }
-
   // ---------------- per-env scalars both roles need (tiny, redundant loads) ------------------------------------------------------
   const long long ep1 = io.episode_length_buf[envc] + 1;
   const float start = io.motion_start_times[envc];
@@ -526,28 +554,28 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, etr_old = 0.0f;
   int pf_tid = 0, pf_tpen = 0, pf_tcol = 0, pf_tsrc = -1;
   long long adelay = 0;
-  // role-B registers that live across phases
+  // role-B registers that live across phases (loads issued in its prologue, consumed after bar1)
   float pf_last_act = 0.0f, pf_last_qd = 0.0f;
   float tref = 0.0f;
+  float qold[PBHC_MAX_QUEUE];
+  float a_in = 0, qp = 0, qv = 0, kp = 1, kd = 1, rfs = 1, ras = 0, u_inj = 0, bmass = 1, lmreg = 0, combias = 0, fric = 0;
+  int didx = 0;
+  const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
   // reductions of the two roles (role A: body sums, role B: joint-space sums); declared here, reduced after their loops
   float s_up = 0, s_lo = 0, s_vr = 0, s_feet = 0, s_rot = 0, s_vel = 0, s_ang = 0, s_maxn = 0, s_upn = 0, s_lon = 0, s_vrn = 0;
   float s_key = 0, s_keyn = 0, s_lkey = 0, s_lkeyn = 0, s_lkrot = 0, s_kvel = 0, s_kang = 0, s_lupn = 0, s_llon = 0, s_lvrn = 0, s_bodyz = 0;
 
-  // staging stores of the shared images + bar0.  Expanded inside EACH role's path, so that the wait for the image loads (the first in the
-  // wave's queue) is counted against that role's own later loads, which stay in flight across the barrier.
-#define STAGE_AND_BAR0()                                                                                               \
-  do {                                                                                                                 \
-    const int n_ = Bx * SKC_W;                                                                                         \
-    _Pragma("unroll") for (int u = 0; u < SKC_REGS2; ++u) { const int i = threadIdx.x + u * PBHC_TPB; if (i < n_) skc[i] = skreg[u]; } \
-    if (map_words > 0) {                                                                                               \
-      _Pragma("unroll") for (int u = 0; u < PBHC_MAPREG; ++u) { const int i = threadIdx.x + u * PBHC_TPB; if (i < map_words) mapl[i] = mreg[u]; } \
-      for (int i = threadIdx.x + PBHC_MAPREG * PBHC_TPB; i < map_words; i += PBHC_TPB) mapl[i] = map_img[i];           \
-    }                                                                                                                  \
-    LDS_BARRIER();                                                                                                     \
-  } while (0)
-
   if (!roleB) {
-    // =============== role A, interval 0: the replay frame -> LDS (what the FK chain waits for), then the loads of its later phases
+    // =============== role A, interval 0: the replay frame + the skeleton constants -> LDS (what the FK chain waits for), then the loads
+    // of its later phases.  Each role-A wave stages the WHOLE constant image for itself (identical words from both waves: benign), so the
+    // chain starts after one memory round trip and waits for nobody.
+#define SKC_REGSW ((SKC_WORDS + 63) / 64)
+    float skreg[SKC_REGSW];
+    {
+      const int n = Bx * SKC_W, wl = threadIdx.x & 63;
+#pragma unroll
+      for (int u = 0; u < SKC_REGSW; ++u) skreg[u] = skc_img[min(wl + u * 64, n - 1)];
+    }
     const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
     const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
@@ -560,7 +588,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
     }
-    STAGE_AND_BAR0();                                          // bar0: skeleton constants + maps staged
+    {
+      const int n = Bx * SKC_W, wl = threadIdx.x & 63;
+#pragma unroll
+      for (int u = 0; u < SKC_REGSW; ++u) { const int i = wl + u * 64; if (i < n) skc[i] = skreg[u]; }
+    }
     STAMP(1);
     if (valid) {
       if (d < D) { q[d] = fq; qd[d] = fqd; }
@@ -573,36 +605,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   } else {
     // =============== role B, interval 0: every other load of the step, issued back to back (indices clamped, not predicated: one basic
     // block), then _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
-    float hreg[PBHC_HREG];
-    {
-      const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
-      const int hlast = c.hist_dim - 1;
-#pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
-    }
-    float creg[128 / PBHC_G];
-    {
-      const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
-      const u32 cbase = (u32)envc * (u32)(B * 3);
-#pragma unroll
-      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
-    }
-    const float broot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));     // B's own copy of the root state (phase C)
-    float qold[PBHC_MAX_QUEUE];
-    const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
-#pragma unroll
-    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
-    const float a_in = at(io.actions_in, eDc + dc);
-    const float qp = at(io.dof_state, (eDc + dc) * 2), qv = at(io.dof_state, (eDc + dc) * 2 + 1);
-    const float kp = at(io.kp_scale, eDc + dc), kd = at(io.kd_scale, eDc + dc), rfs = at(io.rfi_lim_scale, eDc + dc), ras = at(io.rao_scale, eDc + dc);
-    const float u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
-    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
-    const int didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
-    const float bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
-    const int nlm = max(c.dr_link_mass_dim, 1);
-    const float lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
-    const float combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
-    const float fric = io.dr_friction[envc];
     const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
     // reference rows: address from the env scalars, loads issued now, consumed in phase D
     float blend = 0.0f;
@@ -625,54 +627,47 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       rd0 = r0[dc]; rd1 = r1[dc]; rdv0 = r0[D + dc]; rdv1 = r1[D + dc];
       rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
-    float u_rfi = 0.5f;
-    if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
-    STAGE_AND_BAR0();                                          // bar0: skeleton constants + maps staged
-    float clipcnt = 0.0f;
-    if (valid) {
+    float hreg[PBHC_HREG];
+    {
+      const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
+      const int hlast = c.hist_dim - 1;
 #pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
-      if (c.hist_dim > PBHC_HREG * PBHC_G)
-        copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
+      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+    }
+    float creg[128 / PBHC_G];
+    {
+      const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
+      const u32 cbase = (u32)envc * (u32)(B * 3);
+#pragma unroll
+      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
+    }
+    const float broot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));     // B's own copy of the root state (phase C)
+    // operands of the pre-physics step / torques / joint-space sums: issued last, consumed after bar1
+#pragma unroll
+    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
+    a_in = at(io.actions_in, eDc + dc);
+    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);
+    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc);
+    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
+    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
+    didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
+    bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
+    {
+      const int nlm = max(c.dr_link_mass_dim, 1);
+      lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
+    }
+    combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
+    fric = io.dr_friction[envc];
+    if (valid) {
+      // what phase C reads: contact forces, the previous contacts, this role's copy of the root state (`red` is free until bar1)
 #pragma unroll
       for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
-      if (lane < 13) red[lane] = broot;                       // scratch until bar1 (role A first writes `red` after it)
-      if (d < D) {
-        const float tl = c.torque_limits[d];
-        const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
-        if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
-        act[d] = a;
-        float delayed = a;
-        if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
-#pragma unroll
-          for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
-            if (k < Q) {
-              float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
-              at(io.action_queue, qoff + (u32)(k * D)) = nv;
-              if (k == didx) delayed = nv;
-            }
-        }
-        actd[d] = delayed;
-        float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
-        if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
-        if (c.use_rao) tq = tq + ras * tl;
-        if (c.clip_torques) tq = clampf(tq, -tl, tl);
-        tau[d] = tq;
-      }
-      if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
-      if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
-      if (lane == 0) {
-        feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
-        feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
-        if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
-      }
+      if (lane < 13) red[lane] = broot;
       if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
       if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
     }
-    clipcnt = group_sum(clipcnt);
-    if (valid && lane == 0) misc[M_CLIPCNT] = clipcnt;
     WAVE_LDS_FENCE();
-    // =============== role B, interval 1: per-env scalars, reference frame, future targets ==========================================
+    // =============== role B, interval 1: per-env scalars, reference frame ============================================================
     // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588),
     // while the reference rows are in flight
     if (valid) {
@@ -732,63 +727,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       }
     }
     STAMPB(2);
-    // ---- general tracking: future reference targets (general_tracking.py:500-565) ----------------------------------------------
-    // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
-    // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
-    // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.  Wave-local (no barrier between the passes).
-    if (MODE && c.future_num_steps > 0) {
-      const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
-      float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
-      const int row0 = m_row0, nf_c = m_nf;
-      const float len_c = m_len, dt_c = m_dt;
-      const float tb = (float)ep1 * dt + start;
-      if (valid)
-        for (int st = lane; st < NS; st += PBHC_G) {
-          const float t = (float)c.future_steps[st] * dt + tb;
-          int f0, f1; float bl;
-          frame_blend(t, len_c, nf_c, dt_c, &f0, &f1, &bl);
-          const float* q0 = tbl.frames + (size_t)(row0 + f0) * tbl.row;
-          const float* q1 = tbl.frames + (size_t)(row0 + f1) * tbl.row;
-          const float al = 1.0f - bl;
-          const f4 rr = slerp(ld4(q0 + o_rot), ld4(q1 + o_rot), bl);
-          const f3 v0 = ld3(q0 + o_vel), v1 = ld3(q1 + o_vel), w0 = ld3(q0 + o_ang), w1 = ld3(q1 + o_ang);
-          const f3 e = euler_xyz(rr);
-          feat[c.feat_off[PBHC_F_FUT_ROOT_HEIGHT] + st] = al * q0[o_pos + 2] + bl * q1[o_pos + 2] + origin.z;
-          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st] = e.x;
-          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st + 1] = e.y;
-          st3(feat + c.feat_off[PBHC_F_FUT_BASE_LIN_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * v0.x + bl * v1.x, al * v0.y + bl * v1.y, al * v0.z + bl * v1.z)));
-          st3(feat + c.feat_off[PBHC_F_FUT_BASE_ANG_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * w0.x + bl * w1.x, al * w0.y + bl * w1.y, al * w0.z + bl * w1.z)));
-          const f4 aq = an == 0 ? rr : slerp(ld4(q0 + o_rot + 4 * an), ld4(q1 + o_rot + 4 * an), bl);
-          const f3 p0 = ld3(q0 + o_pos + 3 * an), p1 = ld3(q1 + o_pos + 3 * an);
-          float* fs = fut + 10 * st;
-          fs[0] = __int_as_float(f0); fs[1] = __int_as_float(f1); fs[2] = bl;
-          st4(fs + 3, quat_conj(aq));
-          st3(fs + 7, mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z));
-        }
-      WAVE_LDS_FENCE();
-      if (valid) {
-        const int o_fd = c.feat_off[PBHC_F_FUT_DOF_POS], o_fk = c.feat_off[PBHC_F_FUT_LOCAL_KEY_POS];
-        int st = 0, dd = lane;                                       // (step, dof) without divisions: D may be < 32
-        while (dd >= D) { dd -= D; ++st; }
-        for (; st < NS;) {
-          const float* fs = fut + 10 * st;
-          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
-          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
-          feat[o_fd + st * D + dd] = (1.0f - fs[2]) * q0[dd] + fs[2] * q1[dd];
-          dd += PBHC_G;
-          while (dd >= D) { dd -= D; ++st; }
-        }
-        for (int i = lane; i < NS * Kn; i += PBHC_G) {
-          const int st2 = i / Kn, k = i - st2 * Kn, body = c.key[k];
-          const float* fs = fut + 10 * st2;
-          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
-          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
-          const float bl = fs[2], al = 1.0f - bl;
-          const f3 p0 = ld3(q0 + o_pos + 3 * body), p1 = ld3(q1 + o_pos + 3 * body);
-          const f3 pw = mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z);
-          st3(feat + o_fk + 3 * i, quat_apply(ld4(fs + 3), sub3(pw, ld3(fs + 7))));
-        }
-      }
+    // ---- the history row -> feature row (its loads were issued behind the reference rows; they have long landed)
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
+      if (c.hist_dim > PBHC_HREG * PBHC_G)
+        copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
     }
     STAMPB(3);
   }
@@ -921,15 +865,60 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       misc[M_TIMEOUT] = tout;
       misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f) ? 1.0f : 0.0f;
     }
+    WAVE_LDS_FENCE();
+    // a terminated env's history is zero in the observations of this very step (history_handler.py:33-38 via reset_envs_idx): zeroed
+    // here, before bar2, so that both roles' observation passes of interval 2b see it
+    if (valid && misc[M_RESET] != 0.0f)
+      for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
     STAMP(4);
   } else {
-    // =============== role B, interval 2a: outputs of the pre-reset reference, joint-space differences + reductions, foot norms ====
+    // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the
+    // post-reset features of a NON-terminated env (what phase H of role A computes after a reset), the observation maps -> LDS ========
+    uint32_t mreg[PBHC_MAPREG];
+    if (map_words > 0) {
+      const int wl = threadIdx.x - 2 * PBHC_G * 2;            // 0..127 over the two role-B waves
+#pragma unroll
+      for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min(wl + u * 128, map_words - 1)];
+    }
+    // ---- _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
+    float u_rfi = 0.5f;
+    if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
+    float clipcnt = 0.0f;
+    if (valid) {
+      if (d < D) {
+        const float tl = c.torque_limits[d];
+        const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
+        if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
+        act[d] = a;
+        float delayed = a;
+        if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
+#pragma unroll
+          for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
+            if (k < Q) {
+              float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
+              at(io.action_queue, qoff + (u32)(k * D)) = nv;
+              if (k == didx) delayed = nv;
+            }
+        }
+        actd[d] = delayed;
+        float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
+        if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
+        if (c.use_rao) tq = tq + ras * tl;
+        if (c.clip_torques) tq = clampf(tq, -tl, tl);
+        tau[d] = tq;
+      }
+      if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
+      if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
+      if (lane == 0) {
+        feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
+        feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
+        if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
+      }
+    }
+    clipcnt = group_sum(clipcnt);
+    WAVE_LDS_FENCE();
     float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
     if (valid) {
-      if (io.ref_body_pos_extend)
-        for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
-      if (io.ref_body_rot_extend)
-        for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
       const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
       const float inv_dt = 1.0f / dt;
       const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
@@ -973,19 +962,75 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     s_maxjp = group_max(s_maxjp);
     if (valid && lane == 0) {
       red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
-      red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = misc[M_CLIPCNT];
+      red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = clipcnt;
+    }
+    // post-reset features as they stand WITHOUT a reset (phase H recomputes them for a terminated env, after bar2): with them every
+    // observation element of a surviving env can be written while the dynamics chain is still in its reward phase
+    if (valid) {
+      const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
+      const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
+      if (d < D) {
+        feat[o_q + d] = q[d] - c.default_dof_pos[d];
+        feat[o_qd + d] = qd[d];
+        feat[o_a + d] = act[d];
+        feat[o_kp + d] = kp;
+        feat[o_kd + d] = kd;
+      }
+      if (lane == 0) {
+        feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = (float)io.action_delay_idx[envc];
+        feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];
+      }
+      if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
+    }
+    if (map_words > 0) {
+      const int wl = threadIdx.x - 2 * PBHC_G * 2;
+#pragma unroll
+      for (int u = 0; u < PBHC_MAPREG; ++u) { const int i = wl + u * 128; if (i < map_words) mapl[i] = mreg[u]; }
+      for (int i = wl + PBHC_MAPREG * 128; i < map_words; i += 128) mapl[i] = map_img[i];
     }
     STAMPB(4);
   }
   LDS_BARRIER();                                               // bar2: both halves of the reduction row + termination flags are in LDS
   STAMP(5);
 
+  const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals
+  const int ngroups = c.num_groups;
+  // Observation rows: group g is written by the role the host assigned it to (PbhcOutMap.role, balanced by row width), 32 lanes per env.
+  // `late_too`: also the pairs / noisy elements that read post-reset features — valid when this role has them (role A after its phase H;
+  // role B for a surviving env, whose no-reset values it wrote itself; for a terminated env role B defers them past bar3).
+  const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
+#define OBS_GROUPS(ROLE, LATE_TOO)                                                                                                  \
+  for (int g = 0; g < ngroups; ++g) {                                                                                               \
+    if (c.groups[g].role != (ROLE)) continue;                                                                                       \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    const uint32_t* mg = mapl + c.groups[g].lds_off;                                                                                \
+    const int n_early = (int)mg[34], nlist = n_early + (int)mg[35], nn_early = (int)mg[32], nn = nn_early + (int)mg[33];            \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    if (((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(outg) & 7) == 0))                                                     \
+      obs_write_list<8>(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs); \
+    else                                                                                                                            \
+      obs_write_list_unaligned(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);   \
+    obs_write_noisy(mg, 0, (LATE_TOO) ? nn : nn_early, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g); \
+  }
+#define OBS_GROUPS_LATE(ROLE)                                                                                                       \
+  for (int g = 0; g < ngroups; ++g) {                                                                                               \
+    if (c.groups[g].role != (ROLE)) continue;                                                                                       \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    const uint32_t* mg = mapl + c.groups[g].lds_off;                                                                                \
+    const int n_early = (int)mg[34], nlist = n_early + (int)mg[35], nn_early = (int)mg[32], nn = nn_early + (int)mg[33];            \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    if (((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(outg) & 7) == 0))                                                     \
+      obs_write_list<4>(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs);     \
+    else                                                                                                                            \
+      obs_write_list_unaligned(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);       \
+    obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g); \
+  }
   float err[PBHC_NUM_SIGMA];
 #pragma unroll
   for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
   float rew_total = 0.0f, etr_val = 0.0f;
-  const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals
-  const int ngroups = c.num_groups;
 
   if (!roleB) {
     // =============== role A, interval 2b: _compute_reward (legged_robot_base.py:715-761): lane i <-> term i ========================
@@ -1108,7 +1153,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         if (c.randomize_ctrl_delay)
           for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
       }
-      for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
       const u32 sbase = (u32)env * (u32)c.num_sum_cols;
       for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
         if (io.episode_rew_out) at(io.episode_rew_out, sbase + (u32)i) = at(io.episode_sums, sbase + (u32)i) / c.max_episode_length_s;
@@ -1160,8 +1204,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     }
     WAVE_LDS_FENCE();
     STAMP(7);
-    // ---------------- phase H: post-reset features ------------------------------------------------------------------------------
-    if (valid) {
+    // ---------------- phase H: post-reset features (role B wrote the no-reset values before bar2) ------------------------------------
+    if (do_reset) {
       const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
       const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
       for (int dd = lane; dd < D; dd += PBHC_G) {
@@ -1177,10 +1221,18 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       }
       if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
     }
+    WAVE_LDS_FENCE();
     STAMP(8);
+    // ---------------- observation rows of the groups assigned to this role (helpers.py:128-152, legged_robot_base.py:787-793,326-331,
+    // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)
+    if (valid && map_words > 0) OBS_GROUPS(0, true);
   } else {
-    // =============== role B, interval 2b: state outputs + the observation elements whose sources are final ========================
+    // =============== role B, interval 2b: state outputs, future targets, the observation rows assigned to this role ================
     if (valid) {
+      if (io.ref_body_pos_extend)
+        for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
+      if (io.ref_body_rot_extend)
+        for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
       if (io.rigid_body_state)
         for (int b = lane; b < B; b += PBHC_G) {
           float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
@@ -1188,77 +1240,83 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         }
       if (io.contact_forces)
         for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
-      // the "early" pairs of every group: sources that are final by now — history, DR, per-env scalars, reference / future targets (this
-      // role's own products) and the difference features of interval 2a; a terminated env's are rewritten (history zeroed) after bar3
-      if (map_words > 0)
-        for (int g = 0; g < ngroups; ++g) {
-          const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
-          if (((pitch_g & 1) != 0) || ((reinterpret_cast<uintptr_t>(io.obs[g]) & 7) != 0)) continue;      // unaligned rows: everything after bar3
-          const uint32_t* mg = mapl + c.groups[g].lds_off;
-          obs_write_list<8>(mg, 0, (int)mg[33], lane, PBHC_G, feat, io.obs[g], (u32)env * (u32)pitch_g, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs);
+    }
+    // ---- general tracking: future reference targets (general_tracking.py:500-565) ----------------------------------------------
+    // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
+    // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
+    // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.  Wave-local (no barrier between the passes).
+    if (MODE && c.future_num_steps > 0) {
+      const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
+      float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
+      const int row0 = m_row0, nf_c = m_nf;
+      const float len_c = m_len, dt_c = m_dt;
+      const float tb = (float)ep1 * dt + start;
+      if (valid)
+        for (int st = lane; st < NS; st += PBHC_G) {
+          const float t = (float)c.future_steps[st] * dt + tb;
+          int f0, f1; float bl;
+          frame_blend(t, len_c, nf_c, dt_c, &f0, &f1, &bl);
+          const float* q0 = tbl.frames + (size_t)(row0 + f0) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + f1) * tbl.row;
+          const float al = 1.0f - bl;
+          const f4 rr = slerp(ld4(q0 + o_rot), ld4(q1 + o_rot), bl);
+          const f3 v0 = ld3(q0 + o_vel), v1 = ld3(q1 + o_vel), w0 = ld3(q0 + o_ang), w1 = ld3(q1 + o_ang);
+          const f3 e = euler_xyz(rr);
+          feat[c.feat_off[PBHC_F_FUT_ROOT_HEIGHT] + st] = al * q0[o_pos + 2] + bl * q1[o_pos + 2] + origin.z;
+          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st] = e.x;
+          feat[c.feat_off[PBHC_F_FUT_ROLL_PITCH] + 2 * st + 1] = e.y;
+          st3(feat + c.feat_off[PBHC_F_FUT_BASE_LIN_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * v0.x + bl * v1.x, al * v0.y + bl * v1.y, al * v0.z + bl * v1.z)));
+          st3(feat + c.feat_off[PBHC_F_FUT_BASE_ANG_VEL] + 3 * st, quat_rotate_inverse(rr, mk3(al * w0.x + bl * w1.x, al * w0.y + bl * w1.y, al * w0.z + bl * w1.z)));
+          const f4 aq = an == 0 ? rr : slerp(ld4(q0 + o_rot + 4 * an), ld4(q1 + o_rot + 4 * an), bl);
+          const f3 p0 = ld3(q0 + o_pos + 3 * an), p1 = ld3(q1 + o_pos + 3 * an);
+          float* fs = fut + 10 * st;
+          fs[0] = __int_as_float(f0); fs[1] = __int_as_float(f1); fs[2] = bl;
+          st4(fs + 3, quat_conj(aq));
+          st3(fs + 7, mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z));
         }
+      WAVE_LDS_FENCE();
+      if (valid) {
+        const int o_fd = c.feat_off[PBHC_F_FUT_DOF_POS], o_fk = c.feat_off[PBHC_F_FUT_LOCAL_KEY_POS];
+        int st = 0, dd = lane;                                       // (step, dof) without divisions: D may be < 32
+        while (dd >= D) { dd -= D; ++st; }
+        for (; st < NS;) {
+          const float* fs = fut + 10 * st;
+          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+          feat[o_fd + st * D + dd] = (1.0f - fs[2]) * q0[dd] + fs[2] * q1[dd];
+          dd += PBHC_G;
+          while (dd >= D) { dd -= D; ++st; }
+        }
+        for (int i = lane; i < NS * Kn; i += PBHC_G) {
+          const int st2 = i / Kn, k = i - st2 * Kn, body = c.key[k];
+          const float* fs = fut + 10 * st2;
+          const float* q0 = tbl.frames + (size_t)(row0 + __float_as_int(fs[0])) * tbl.row;
+          const float* q1 = tbl.frames + (size_t)(row0 + __float_as_int(fs[1])) * tbl.row;
+          const float bl = fs[2], al = 1.0f - bl;
+          const f3 p0 = ld3(q0 + o_pos + 3 * body), p1 = ld3(q1 + o_pos + 3 * body);
+          const f3 pw = mk3(al * p0.x + bl * p1.x + origin.x, al * p0.y + bl * p1.y + origin.y, al * p0.z + bl * p1.z + origin.z);
+          st3(feat + o_fk + 3 * i, quat_apply(ld4(fs + 3), sub3(pw, ld3(fs + 7))));
+        }
+      }
+    }
+    WAVE_LDS_FENCE();
+    if (valid && map_words > 0) {
+      // a surviving env: every pair; a terminated env: all but the pairs that read post-reset features (after bar3)
+      if (misc[M_RESET] != 0.0f) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
     }
     STAMPB(5);
   }
   LDS_BARRIER();                                               // bar3: post-reset features are in LDS
   STAMP(9);
 
-  // =============== both roles, interval 3: the remaining observation elements (64 lanes per env), noise, state write-back ==========
-  // (helpers.py:128-152, legged_robot_base.py:787-793,326-331, history_handler.py:40-44)
+  // =============== interval 3: a terminated env's post-reset pairs of role B's rows; state write-back (role A) =======================
   if (valid) {
-    const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
     const bool do_reset = misc[M_RESET] != 0.0f;
-    const int l64 = lane + (roleB ? PBHC_G : 0);
     if (map_words > 0) {
-      for (int g = 0; g < ngroups; ++g) {
-        const int dim = c.groups[g].dim, clip = c.groups[g].clip;
-        const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;
-        const uint32_t* mg = mapl + c.groups[g].lds_off;
-        const float* segs = (const float*)mg;
-        const int nn = (int)mg[32];
-        const int n_early = (int)mg[33], nlist = n_early + (int)mg[34];
-        const uint32_t* noisy = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1);
-        float* __restrict__ const outg = io.obs[g];
-        const u32 ob = (u32)env * (u32)pitch_g;
-        const bool paired = ((pitch_g & 1) == 0) && ((reinterpret_cast<uintptr_t>(outg) & 7) == 0);
-        if (paired) {
-          // the "late" pairs (post-reset features): every output element is written exactly once, by one lane ...
-          obs_write_list<2>(mg, n_early, nlist, l64, 2 * PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
-          // ... except for a terminated env, whose history was zeroed: the lanes that wrote the early pairs before bar3 write them again
-          // (same lane, same address: program order)
-          if (do_reset && roleB) obs_write_list<8>(mg, 0, n_early, lane, PBHC_G, feat, outg, ob, dim, pitch_g, clip, clipobs);
-        } else {
-          // rows that are not 8-byte aligned (caller-owned outputs): every listed pair, element by element, here only
-          const uint16_t* m16 = (const uint16_t*)(noisy + nn);
-          const uint16_t* list = (const uint16_t*)(mg + PBHC_MAP_HDR);
-          for (int e = l64; e < 2 * nlist; e += 2 * PBHC_G) {
-            const int j = 2 * (int)list[e >> 1] + (e & 1);
-            if (j < dim) {
-              const uint32_t w = m16[j];
-              float v = feat[w & 0xFFFu] * segs[w >> 12];
-              if (clip) v = clampf(v, -clipobs, clipobs);
-              at(outg, ob + (u32)j) = v;
-            }
-          }
-        }
-        // noisy elements — and the other element of a pair that holds one — belong to no run: they are written here only, four per lane
-        // per Philox4x32 call
-        for (int k0 = 4 * l64; k0 < nn; k0 += 8 * PBHC_G) {
-          uint32_t r[4];
-          philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16 + g, (uint32_t)(k0 >> 2), r);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (k0 + u < nn) {
-              const uint32_t e = noisy[k0 + u];
-              const uint32_t w = e >> 16;
-              const int seg = w >> 12;
-              float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
-              if (clip) v = clampf(v, -clipobs, clipobs);
-              at(outg, ob + (e & 0xFFFFu)) = v;
-            }
-        }
-      }
-    } else if (!roleB) {
+      if (roleB && do_reset) { OBS_GROUPS_LATE(1); }
+    } else {
+      // per-element maps in global memory (a feature row too large for the compact LDS maps): both roles, 64 lanes per env
+      const int l64 = lane + (roleB ? PBHC_G : 0);
       for (int g = 0; g < c.num_groups; ++g) {
         const int dim = c.groups[g].dim, clip = c.groups[g].clip;
         const int* __restrict__ mdst = rt.groups[g].dst;
@@ -1266,18 +1324,18 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         const float* __restrict__ mscale = rt.groups[g].scale;
         const float* __restrict__ mnoise = rt.groups[g].noise;
         float* __restrict__ out = io.obs[g] + (size_t)env * (io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch);
-        for (int j0 = lane; j0 < dim; j0 += 8 * PBHC_G) {
+        for (int j0 = l64; j0 < dim; j0 += 8 * 2 * PBHC_G) {
           int si[8], di[8]; float sc[8], ns[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * PBHC_G;
+            const int j = j0 + u * 2 * PBHC_G;
             const bool ok = j < dim;
             si[u] = ok ? msrc[j] : 0; sc[u] = ok ? mscale[j] : 0.0f; ns[u] = ok ? mnoise[j] : 0.0f;
             di[u] = ok ? (mdst ? mdst[j] : j) : 0;
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * PBHC_G;
+            const int j = j0 + u * 2 * PBHC_G;
             if (j < dim) {
               float x = feat[si[u]];
               if (ns[u] != 0.0f) x = x + (rng_uniform(rt.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);

@@ -515,14 +515,30 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
             early = [p_ for p_ in range(npair) if not pair_noisy[p_] and not pair_late[p_]]
             late = [p_ for p_ in range(npair) if not pair_noisy[p_] and pair_late[p_]]
             plist = np.array(early + late + [0] * ((len(early) + len(late)) % 2), dtype=np.uint16)
-            noisy = np.array([j | (int(pk[j]) << 16) for j in range(n_el) if pair_noisy[j // 2]], dtype=np.uint32)
-            hdr = np.array([len(noisy), len(early), len(late)], dtype=np.uint32)
+            noisy_e = [j | (int(pk[j]) << 16) for j in range(n_el) if pair_noisy[j // 2] and not pair_late[j // 2]]
+            noisy_l = [j | (int(pk[j]) << 16) for j in range(n_el) if pair_noisy[j // 2] and pair_late[j // 2]]
+            if noisy_e:
+                noisy_e += [noisy_e[-1]] * ((-len(noisy_e)) % 4)      # early list padded to a Philox quad (repeats rewrite the same value)
+            noisy = np.array(noisy_e + noisy_l, dtype=np.uint32)
+            hdr = np.array([len(noisy_e), len(noisy_l), len(early), len(late)], dtype=np.uint32)
             blk = np.concatenate([tabs.view(np.uint32), hdr, plist.view(np.uint32), noisy, pk.view(np.uint32)])
             image.append(blk)
             c.groups[i].dst = None                                  # identity
             c.groups[i].lds_off = lds_off
             c.groups[i].map_words = len(blk)
             lds_off += len(blk)
+    # who writes which row: role 0 (dynamics waves, free once their reward phase is done) or role 1 (reference / observation waves).  Greedy by
+    # width, role 0 handicapped by the work of its reward / reset phases; a row that reads future targets — produced by role 1 while role 0
+    # already writes — stays with role 1.
+    fut_lo = min([feat_off[n_] for n_ in feat_off if n_.startswith("FUT_")] or [1 << 30])
+    fut_hi = max([feat_off[n_] + fdim[n_] for n_ in feat_off if n_.startswith("FUT_")] or [-1])
+    load = [0.45 * sum(len(m[2]) for m in maps), 0.0]
+    for i in sorted(range(len(maps)), key=lambda i_: -len(maps[i_][2])):
+        reads_future = any(fut_lo <= s_ < fut_hi for s_ in maps[i][2])
+        r_ = 1 if (reads_future or load[1] <= load[0]) else 0
+        c.groups[i].role = r_
+        load[r_] += len(maps[i][2])
+    L.group_roles = [int(c.groups[i].role) for i in range(len(maps))]
     c.map_lds_words = lds_off if compact else 0
     if compact:
         L.map_image = torch.from_numpy(np.concatenate(image).view(np.int32).copy()).to(device)

@@ -29,15 +29,16 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
     st = (C.c_ulonglong * 64)()
     lib.pbhc_debug_read_stamps(st, 64)
     # role A (thread 0 of workgroup 0): stamps 0..12 at its phase boundaries; role B (thread 128): stamps 32+1..32+5
-    namesA = ["loads -> bar0", "FK chain", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features", "wait bar3",
-              "obs class 2 + noise", "J writeback", "partials"]
+    namesA = ["loads + constants -> LDS", "FK chain", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features",
+              "obs rows of role 0 + wait bar3", "(late rows of a reset env)", "J writeback", "partials"]
     tot = st[12] - st[0]
     print("  role A (dynamics chain):")
     for i, n in enumerate(namesA):
         dd = st[i + 1] - st[i]
         print(f"    {n:28s} {dd:8d} cyc  {100.0 * dd / tot:5.1f}%")
     print(f"    total {tot} cycles")
-    namesB = ["C scalars (from A's start)", "D reference frame", "futures", "E joint-space + outputs (from bar1)", "obs classes 0/1 + outputs (from bar2)"]
+    namesB = ["C scalars (from the start)", "D reference frame", "history -> LDS (then bar1)", "torques + joint-space sums + maps (from bar1)",
+              "outputs + obs rows of role 1 (from bar2)"]
     refs = [st[0], st[32 + 1], st[32 + 2], st[3], st[5]]
     print("  role B (reference / observations):")
     for i, n in enumerate(namesB):
