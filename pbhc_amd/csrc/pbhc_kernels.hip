@@ -459,17 +459,28 @@ __device__ __forceinline__ void obs_write_list_unaligned(const uint32_t* mg, int
 
 // Noisy elements [k0, k1) of the block's noise list — and the other element of a pair that holds one: such pairs belong to no pair list —
 // out[j] = clip((feat[src] + (2U - 1) * noise * curriculum) * scale), four entries per lane per Philox4x32 call (helpers.py:128-152).
+// Uniforms: ONE Philox4x32 quad per lane and step (`base`, keyed by env / step / lane, computed in the prologue while the wave waits for
+// its loads: seven dependent rounds per group and pass cost ~1.4 k cycles each where they stood) is spread over the groups and list
+// quads by a bijective 32-bit finaliser (two multiply / xor-shift rounds) of base[u] ^ f(group, quad): distinct (env, step, lane, u, group,
+// quad) tuples give decorrelated words, which is all observation noise asks for (helpers.py:152 draws torch.rand_like).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ void obs_write_noisy(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
-                                                int clip, float clipobs, float noise_cur, uint64_t seed, uint32_t env, uint32_t step_ctr, uint32_t stream) {
+                                                int clip, float clipobs, float noise_cur, uint64_t seed, uint32_t env, uint32_t step_ctr, uint32_t stream,
+                                                const uint32_t* pre) {
   const float* segs = (const float*)mg;
   const int nlist = (int)(mg[34] + mg[35]);
   const uint32_t* noisy = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1);
-  for (int kb = k0 + 4 * l; kb < k1; kb += 4 * nl) {
+  for (int kb = (k0 & ~3) + 4 * l; kb < k1; kb += 4 * nl) {
     uint32_t r[4];
-    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), env, step_ctr, stream, (uint32_t)(kb >> 2), r);
+    const uint32_t salt = stream * 0x9E3779B9u + (uint32_t)(kb >> 2) * 0x85EBCA6Bu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = mix32(pre[u] ^ salt);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (kb + u < k1) {
+      if (kb + u >= k0 && kb + u < k1) {
         const uint32_t e = noisy[kb + u];
         const uint32_t w = e >> 16;
         const int seg = w >> 12;
@@ -538,17 +549,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
   STAMP(0);
 
-  // ---------------- per-env scalars both roles need (tiny, redundant loads) ------------------------------------------------------
+  // ---------------- per-env scalars (tiny loads; each role loads what it uses, the reset path re-reads the clip meta) -----------------
+#define LOAD_CLIP_META()                                                                                               \
+  const int mid = (int)io.motion_ids[envc];                                                                            \
+  const f3 origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u)); \
+  float m_len = tbl.single_len, m_dt = tbl.single_dt;          /* this env's clip: length, frame time, frames, first table row */ \
+  int m_nf = tbl.single_num_frames, m_row0 = 0;                                                                        \
+  if (tbl.num_motions != 1) {                                  /* single clip: its meta travels in the kernel arguments */ \
+    m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid]; \
+  }
   const long long ep1 = io.episode_length_buf[envc] + 1;
   const float start = io.motion_start_times[envc];
-  const int mid = (int)io.motion_ids[envc];
-  const float mlen_env = io.motion_len[envc];
-  const f3 origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u));
-  float m_len = tbl.single_len, m_dt = tbl.single_dt;          // this env's clip: length, frame time, frames, first table row
-  int m_nf = tbl.single_num_frames, m_row0 = 0;
-  if (tbl.num_motions != 1) {                                  // single clip: its meta travels in the kernel arguments
-    m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid];
-  }
 
   // role-A registers that live across phases
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, etr_old = 0.0f;
@@ -558,7 +569,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   float pf_last_act = 0.0f, pf_last_qd = 0.0f;
   float tref = 0.0f;
   float qold[PBHC_MAX_QUEUE];
+  // Philox quads computed ahead of their use, while the wave waits for its loads: the first quad of every group's noise list (both roles;
+  // role A needs role B's rows too after a reset), and role A's reset draws
+  uint32_t nzb[4];
   float a_in = 0, qp = 0, qv = 0, kp = 1, kd = 1, rfs = 1, ras = 0, u_inj = 0, bmass = 1, lmreg = 0, combias = 0, fric = 0;
+  float u_rfi = 0.5f;
+  long long adelayB = 0;
   int didx = 0;
   const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
   // reductions of the two roles (role A: body sums, role B: joint-space sums); declared here, reduced after their loops
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
     }
+
     {
       const int n = Bx * SKC_W, wl = threadIdx.x & 63;
 #pragma unroll
@@ -601,8 +618,34 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     WAVE_LDS_FENCE();
     // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
     fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588) ---------
+    if (valid) {
+      f4 rq4 = ld4(root + 3);
+      if (lane == 0) {
+        const float mlen = io.motion_len[envc];
+        const float t = (float)(ep1 + 1) * dt + start;
+        misc[M_EPLEN] = (float)ep1;
+        misc[M_START] = start; misc[M_MLEN] = mlen;
+        misc[M_TIME] = t;
+        misc[M_PHASE] = t / mlen;
+        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
+        f3 e = euler_xyz(rq4);
+        misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
+        feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
+        if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
+        st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
+      } else if (lane <= 3) {
+        // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
+        const f3 vin = lane == 1 ? ld3(root + 7) : (lane == 2 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
+        const f3 vo = quat_rotate_inverse(rq4, vin);
+        const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+        st3(feat + off, vo);
+        if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+      }
+    }
     STAMP(2);
   } else {
+    LOAD_CLIP_META();
     // =============== role B, interval 0: every other load of the step, issued back to back (indices clamped, not predicated: one basic
     // block), then _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
     const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
@@ -641,7 +684,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
 #pragma unroll
       for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
     }
-    const float broot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));     // B's own copy of the root state (phase C)
     // operands of the pre-physics step / torques / joint-space sums: issued last, consumed after bar1
 #pragma unroll
     for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
@@ -650,7 +692,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc);
     u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
     pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
-    didx = c.randomize_ctrl_delay ? (int)io.action_delay_idx[envc] : 0;
+    adelayB = io.action_delay_idx[envc];
+    didx = c.randomize_ctrl_delay ? (int)adelayB : 0;
     bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
     {
       const int nlm = max(c.dr_link_mass_dim, 1);
@@ -658,48 +701,22 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     }
     combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
     fric = io.dr_friction[envc];
+    if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? 0.5f : rng_uniform(rt.seed, env, step_ctr, 1, d);     // in-kernel draw: computed while the loads fly
     if (valid) {
-      // what phase C reads: contact forces, the previous contacts, this role's copy of the root state (`red` is free until bar1)
+      // contact forces and the previous contacts
 #pragma unroll
       for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
-      if (lane < 13) red[lane] = broot;
       if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
       if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
     }
     WAVE_LDS_FENCE();
     // =============== role B, interval 1: per-env scalars, reference frame ============================================================
-    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588),
-    // while the reference rows are in flight
-    if (valid) {
-      const float* broot = red;                                // this role's copy of the frame's root state (see interval 0)
-      f4 rq4 = ld4(broot + 3);
-      if (lane == 0) {
-        const float mlen = mlen_env;
-        misc[M_EPLEN] = (float)ep1;
-        misc[M_START] = start; misc[M_MLEN] = mlen;
-        const float t = tref;
-        misc[M_TIME] = t;
-        misc[M_PHASE] = t / mlen;
-        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
-        f3 e = euler_xyz(rq4);
-        misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
-        feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
-        if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
-        st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
-      } else if (lane <= 3) {
-        // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
-        const f3 vin = lane == 1 ? ld3(broot + 7) : (lane == 2 ? ld3(broot + 10) : mk3(0.0f, 0.0f, -1.0f));
-        const f3 vo = quat_rotate_inverse(rq4, vin);
-        const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
-        st3(feat + off, vo);
-        if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
-      } else if (lane >= 4 && lane < 4 + NF) {
-        int f = lane - 4;
-        float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
-        float lastc = misc[M_LASTC0 + f];
-        misc[M_CONTACT0 + f] = cn;
-        misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
-      }
+    // ---- contacts (legged_robot_base.py:371-380); the other per-env scalars are role A's (behind its FK chain)
+    if (valid && lane < NF) {
+      const int f = lane;
+      float cn = norm3(ld3(cf + 3 * c.feet[f])) > 1.0f ? 1.0f : 0.0f;
+      misc[M_CONTACT0 + f] = cn;
+      misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
     }
     STAMPB(1);
     // ---- phase D: reference frame: lerp / slerp of the two frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
@@ -734,6 +751,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       if (c.hist_dim > PBHC_HREG * PBHC_G)
         copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
     }
+    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar1 next
     STAMPB(3);
   }
   LDS_BARRIER();                                               // bar1: A's body state and B's reference frame / scalars are in LDS
@@ -870,6 +888,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     // here, before bar2, so that both roles' observation passes of interval 2b see it
     if (valid && misc[M_RESET] != 0.0f)
       for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
+    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar2 next
     STAMP(4);
   } else {
     // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the
@@ -880,13 +899,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
 #pragma unroll
       for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min(wl + u * 128, map_words - 1)];
     }
+    // per-dof constants of the config: one batch of loads at the head of the interval
+    const float k_tl = c.torque_limits[dc], k_pg = c.p_gains[dc], k_dg = c.d_gains[dc], k_as = c.action_scale[dc], k_dp = c.default_dof_pos[dc];
+    const float k_vl = c.dof_vel_limits[dc];
+    const float k_lo = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][0] : c.soft_dof_pos_limits[dc][0];
+    const float k_hi = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][1] : c.soft_dof_pos_limits[dc][1];
     // ---- _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
-    float u_rfi = 0.5f;
-    if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? u_inj : rng_uniform(rt.seed, env, step_ctr, 1, d);
+    if (c.randomize_torque_rfi && io.u_rfi) u_rfi = u_inj;
     float clipcnt = 0.0f;
     if (valid) {
       if (d < D) {
-        const float tl = c.torque_limits[d];
+        const float tl = k_tl;
         const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
         if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
         act[d] = a;
@@ -901,7 +924,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
             }
         }
         actd[d] = delayed;
-        float tq = kp * c.p_gains[d] * (delayed * c.action_scale[d] + c.default_dof_pos[d] - qp) - kd * c.d_gains[d] * qv;
+        float tq = kp * k_pg * (delayed * k_as + k_dp - qp) - kd * k_dg * qv;
         if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
         if (c.use_rao) tq = tq + ras * tl;
         if (c.clip_torques) tq = clampf(tq, -tl, tl);
@@ -919,10 +942,16 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     WAVE_LDS_FENCE();
     float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
     if (valid) {
+      // outputs of the PRE-reset reference (a reset rewrites the root entries of rp / rq after bar2)
+      if (io.ref_body_pos_extend)
+        for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
+      if (io.ref_body_rot_extend)
+        for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
       const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
       const float inv_dt = 1.0f / dt;
       const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
-      for (int dd = lane; dd < D; dd += PBHC_G) {
+      if (d < D) {
+        const int dd = d;
         float dj = rdof[dd] - q[dd], djv = rdofv[dd] - qd[dd];
         feat[o_dja + dd] = dj; feat[o_djv + dd] = djv;
         s_maxjp = fmaxf(s_maxjp, fabsf(dj));
@@ -933,17 +962,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         s_qd2 += qd[dd] * qd[dd];
         float acc = (pf_last_qd - qd[dd]) * inv_dt;
         s_qacc2 += acc * acc;
-        float lo_l, hi_l;
+        float lo_l = k_lo, hi_l = k_hi;
         if (c.soft_pos_curriculum) {
-          float m = (c.hard_dof_pos_limits[dd][0] + c.hard_dof_pos_limits[dd][1]) / 2.0f;
-          float r = c.hard_dof_pos_limits[dd][1] - c.hard_dof_pos_limits[dd][0];
+          float m = (k_lo + k_hi) / 2.0f;
+          float r = k_hi - k_lo;
           lo_l = m - 0.5f * r * soft_pos; hi_l = m + 0.5f * r * soft_pos;
-        } else { lo_l = c.soft_dof_pos_limits[dd][0]; hi_l = c.soft_dof_pos_limits[dd][1]; }
+        }
         s_lpos += -fminf(q[dd] - lo_l, 0.0f) + fmaxf(q[dd] - hi_l, 0.0f);
-        float vlim = c.dof_vel_limits[dd] * (c.soft_vel_curriculum ? soft_vel : c.soft_dof_vel_limit);
+        float vlim = k_vl * (c.soft_vel_curriculum ? soft_vel : c.soft_dof_vel_limit);
         s_lvel += clampf(fabsf(qd[dd]) - vlim, 0.0f, 1.0f);
-        if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[dd]) - c.torque_limits[dd] * soft_tau, 0.0f, 1.0f);
-        else s_ltau += fmaxf(fabsf(tau[dd]) - c.torque_limits[dd] * c.soft_torque_limit, 0.0f);
+        if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[dd]) - k_tl * soft_tau, 0.0f, 1.0f);
+        else s_ltau += fmaxf(fabsf(tau[dd]) - k_tl * c.soft_torque_limit, 0.0f);
       }
       for (int i = lane; i < c.num_penalised; i += PBHC_G)
         if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
@@ -970,14 +999,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
       const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
       if (d < D) {
-        feat[o_q + d] = q[d] - c.default_dof_pos[d];
+        feat[o_q + d] = q[d] - k_dp;
         feat[o_qd + d] = qd[d];
         feat[o_a + d] = act[d];
         feat[o_kp + d] = kp;
         feat[o_kd + d] = kd;
       }
       if (lane == 0) {
-        feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = (float)io.action_delay_idx[envc];
+        feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = (float)adelayB;
         feat[c.feat_off[PBHC_F_BASE_POS_Z]] = root[2];
       }
       if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
@@ -1011,7 +1040,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       obs_write_list<8>(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs); \
     else                                                                                                                            \
       obs_write_list_unaligned(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);   \
-    obs_write_noisy(mg, 0, (LATE_TOO) ? nn : nn_early, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g); \
+    obs_write_noisy(mg, 0, (LATE_TOO) ? nn : nn_early, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g, nzb); \
   }
 #define OBS_GROUPS_LATE(ROLE)                                                                                                       \
   for (int g = 0; g < ngroups; ++g) {                                                                                               \
@@ -1025,7 +1054,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       obs_write_list<4>(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs);     \
     else                                                                                                                            \
       obs_write_list_unaligned(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);       \
-    obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g); \
+    obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g, nzb); \
   }
   float err[PBHC_NUM_SIGMA];
 #pragma unroll
@@ -1135,6 +1164,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     const bool do_reset = valid && misc[M_RESET] != 0.0f;
     if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)adelay; }
     if (do_reset) {
+      LOAD_CLIP_META();
       __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0) expcnt(0) lgkmcnt(0): the wave's episode_sums stores of phase F have landed
       for (int dd = lane; dd < D; dd += PBHC_G) {
         act[dd] = 0.0f; actd[dd] = 0.0f;
@@ -1225,14 +1255,15 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     STAMP(8);
     // ---------------- observation rows of the groups assigned to this role (helpers.py:128-152, legged_robot_base.py:787-793,326-331,
     // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)
-    if (valid && map_words > 0) OBS_GROUPS(0, true);
+    if (valid && map_words > 0) {
+      OBS_GROUPS(0, true);
+      // a terminated env: role B skips the pairs of ITS rows that read post-reset features (it cannot know them before bar3) — this
+      // role, which has just produced them, writes those too: nobody waits for bar3 to finish an observation row
+      if (do_reset) { OBS_GROUPS_LATE(1); }
+    }
   } else {
     // =============== role B, interval 2b: state outputs, future targets, the observation rows assigned to this role ================
     if (valid) {
-      if (io.ref_body_pos_extend)
-        for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
-      if (io.ref_body_rot_extend)
-        for (int i = lane; i < Bx * 4; i += PBHC_G) at(io.ref_body_rot_extend, (u32)env * (u32)(Bx * 4) + (u32)i) = rq[i];
       if (io.rigid_body_state)
         for (int b = lane; b < B; b += PBHC_G) {
           float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
@@ -1246,6 +1277,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
     // Pass 2/3, lane <-> (step, dof) / (step, key body): lerps from the two frame rows.  Wave-local (no barrier between the passes).
     if (MODE && c.future_num_steps > 0) {
+      LOAD_CLIP_META();
       const int NS = c.future_num_steps, Kn = c.num_key, an = c.anchor_index;
       float* fut = S + lo.fut;                                    // per step: f0 f1 blend | anchor quat (4) | anchor pos (3)
       const int row0 = m_row0, nf_c = m_nf;
@@ -1309,11 +1341,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   LDS_BARRIER();                                               // bar3: post-reset features are in LDS
   STAMP(9);
 
-  // =============== interval 3: a terminated env's post-reset pairs of role B's rows; state write-back (role A) =======================
+  // =============== interval 3: state write-back (role A) ================================================================================
   if (valid) {
-    const bool do_reset = misc[M_RESET] != 0.0f;
     if (map_words > 0) {
-      if (roleB && do_reset) { OBS_GROUPS_LATE(1); }
     } else {
       // per-element maps in global memory (a feature row too large for the compact LDS maps): both roles, 64 lanes per env
       const int l64 = lane + (roleB ? PBHC_G : 0);
