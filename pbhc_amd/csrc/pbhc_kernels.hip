@@ -573,7 +573,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   // role A needs role B's rows too after a reset), and role A's reset draws
   uint32_t nzb[4];
   float a_in = 0, qp = 0, qv = 0, kp = 1, kd = 1, rfs = 1, ras = 0, u_inj = 0, bmass = 1, lmreg = 0, combias = 0, fric = 0;
-  float u_rfi = 0.5f;
+  float u_rfi = 0.5f, k_tl = 0.0f, k_dp = 0.0f, clipcnt = 0.0f;
   long long adelayB = 0;
   int didx = 0;
   const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
@@ -751,6 +751,44 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       if (c.hist_dim > PBHC_HREG * PBHC_G)
         copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
     }
+    // per-dof constants of the config: one batch of loads at the head of the interval
+    k_tl = c.torque_limits[dc]; k_dp = c.default_dof_pos[dc];
+    const float k_pg = c.p_gains[dc], k_dg = c.d_gains[dc], k_as = c.action_scale[dc];
+    // ---- _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
+    if (c.randomize_torque_rfi && io.u_rfi) u_rfi = u_inj;
+    if (valid) {
+      if (d < D) {
+        const float tl = k_tl;
+        const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
+        if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
+        act[d] = a;
+        float delayed = a;
+        if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
+#pragma unroll
+          for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
+            if (k < Q) {
+              float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
+              at(io.action_queue, qoff + (u32)(k * D)) = nv;
+              if (k == didx) delayed = nv;
+            }
+        }
+        actd[d] = delayed;
+        float tq = kp * k_pg * (delayed * k_as + k_dp - qp) - kd * k_dg * qv;
+        if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
+        if (c.use_rao) tq = tq + ras * tl;
+        if (c.clip_torques) tq = clampf(tq, -tl, tl);
+        tau[d] = tq;
+      }
+      if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
+      if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
+      if (lane == 0) {
+        feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
+        feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
+        if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
+      }
+    }
+    clipcnt = group_sum(clipcnt);
+    WAVE_LDS_FENCE();
     philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar1 next
     STAMPB(3);
   }
@@ -899,47 +937,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
 #pragma unroll
       for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min(wl + u * 128, map_words - 1)];
     }
-    // per-dof constants of the config: one batch of loads at the head of the interval
-    const float k_tl = c.torque_limits[dc], k_pg = c.p_gains[dc], k_dg = c.d_gains[dc], k_as = c.action_scale[dc], k_dp = c.default_dof_pos[dc];
     const float k_vl = c.dof_vel_limits[dc];
     const float k_lo = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][0] : c.soft_dof_pos_limits[dc][0];
     const float k_hi = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][1] : c.soft_dof_pos_limits[dc][1];
-    // ---- _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
-    if (c.randomize_torque_rfi && io.u_rfi) u_rfi = u_inj;
-    float clipcnt = 0.0f;
-    if (valid) {
-      if (d < D) {
-        const float tl = k_tl;
-        const float a = clampf(a_in, -c.action_clip_value, c.action_clip_value);
-        if (fabsf(a) == c.action_clip_value) clipcnt += 1.0f;
-        act[d] = a;
-        float delayed = a;
-        if (c.randomize_ctrl_delay) {            // queue[k] <- queue[k-1], queue[0] <- a ; delayed = queue[delay_idx]
-#pragma unroll
-          for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
-            if (k < Q) {
-              float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
-              at(io.action_queue, qoff + (u32)(k * D)) = nv;
-              if (k == didx) delayed = nv;
-            }
-        }
-        actd[d] = delayed;
-        float tq = kp * k_pg * (delayed * k_as + k_dp - qp) - kd * k_dg * qv;
-        if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
-        if (c.use_rao) tq = tq + ras * tl;
-        if (c.clip_torques) tq = clampf(tq, -tl, tl);
-        tau[d] = tq;
-      }
-      if (lane < 3) feat[c.feat_off[PBHC_F_DR_BASE_COM] + lane] = combias;
-      if (lane < c.dr_link_mass_dim) feat[c.feat_off[PBHC_F_DR_LINK_MASS] + lane] = lmreg;
-      if (lane == 0) {
-        feat[c.feat_off[PBHC_F_DR_FRICTION]] = fric;
-        feat[c.feat_off[PBHC_F_ZERO]] = 0.0f;
-        if (MODE) feat[c.feat_off[PBHC_F_DR_BASE_MASS]] = bmass;
-      }
-    }
-    clipcnt = group_sum(clipcnt);
-    WAVE_LDS_FENCE();
     float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
     if (valid) {
       // outputs of the PRE-reset reference (a reset rewrites the root entries of rp / rq after bar2)
