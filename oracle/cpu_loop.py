@@ -21,8 +21,9 @@ def init_params(in_dim, hidden, out_dim, prefix, gen):
     return p
 
 
-def run_iteration(cfg, skel, clip, num_envs, seed=0):
-    """Returns dict(env_steps, seconds, rollout_s, update_s)."""
+def run_iteration(cfg, skel, clip, num_envs, seed=0, return_state=False):
+    """Returns dict(env_steps, seconds, rollout_s, update_s) [+ the rollout buffer, the actor's weights before / after and the adapted
+    learning rate with return_state]."""
     g = torch.Generator().manual_seed(seed)
     N = num_envs
     ml = MotionLib(skel, [clip])
@@ -45,6 +46,7 @@ def run_iteration(cfg, skel, clip, num_envs, seed=0):
     ap["std"] = acfg.init_noise_std * torch.ones(D)
     cp = init_params(obs_dims["critic_obs"], acfg.module_dict.critic.layer_config.hidden_dims, env.R, "critic_module", g)
     up = ppo.MHPPOUpdate(ap, cp, acfg)
+    ap0 = {k: v.clone() for k, v in ap.items()} if return_state else None
     st = {k: torch.zeros(T, N, d) for k, d in obs_dims.items()}
     st.update(actions=torch.zeros(T, N, D), rewards=torch.zeros(T, N, env.R), dones=torch.zeros(T, N, 1, dtype=torch.bool), values=torch.zeros(T, N, env.R),
               actions_log_prob=torch.zeros(T, N, 1), action_mean=torch.zeros(T, N, D), action_sigma=torch.zeros(T, N, D))
@@ -68,7 +70,10 @@ def run_iteration(cfg, skel, clip, num_envs, seed=0):
     t1 = time.perf_counter()
     up.training_step(st, torch.randperm(T * N, generator=g))
     t2 = time.perf_counter()
-    return dict(env_steps=T * N, seconds=t2 - t0, rollout_s=t1 - t0, update_s=t2 - t1)
+    out = dict(env_steps=T * N, seconds=t2 - t0, rollout_s=t1 - t0, update_s=t2 - t1)
+    if return_state:
+        out.update(state=st, actor_params0=ap0, actor_params={k: v.detach().clone() for k, v in up.ap.items()}, lr=float(up.lr_a))
+    return out
 
 
 def _samples(N, D, L, g):

@@ -178,20 +178,25 @@ def test_env_step_matches_oracle_4096():
     _env_step_vs_oracle(4096, 4)
 
 
+def test_env_step_matches_oracle_4096_walk_config():
+    """BASELINE configs[1] at its full size: 4096 envs, G1 23-DoF, g1_walk_45cms (no contact mask -> teleop_contact_mask 0, 20 reward
+    columns) — the bench's own workload — HIP step vs the oracle on identical synthetic replay tensors, resets and time-outs included."""
+    _env_step_vs_oracle(4096, 4, tag="walk", cfgname="v1_g1_23dof_walk.yaml")
+
+
 def test_env_step_matches_oracle_ragged_tail():
     """13 envs: the last workgroup is only partly filled (loads of its missing envs are clamped onto env N-1, nothing is stored for them),
     and the env-count-dependent reductions (log means, curricula) divide by 13."""
     _env_step_vs_oracle(13, 4)
 
 
-def _env_step_vs_oracle(N, T):
+def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml"):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
 
-    cfgname = "v1_g1_23dof_horse_stance.yaml"
     cfg, env = build_hip_env(cfgname, N)
-    g = load_env_golden("horse")
+    g = load_env_golden(tag)
     skel = skel_from_golden()
     oml = OML(skel, [clip_from_env_golden(g)])
     ocfg = fixture_config(cfgname, N)
@@ -450,6 +455,72 @@ def test_observation_noise_is_bounded_uniform_and_only_where_configured():
     assert 0 < float(dh.abs().max()) <= amp * (1 + 1e-5)
     da = (noisy["actor_obs"] - clean["actor_obs"]).cpu()
     assert float((dh[:, 0] - da[:, 0]).abs().max()) > 0        # different draws than the actor group's
+
+
+def test_reset_draws_have_the_reference_distributions():
+    """The reset path's IN-KERNEL Philox draws (every other reset test injects the reference's recorded draws): start phase
+    `U * motion_len` (sample_time, motion_lib_base.py:486-495 via motion_tracking.py:369-378), kp / kd / rfi-limit scales `U(lo, hi)` and
+    rao `U(-lim, lim)` per dof (legged_robot_base.py:599-635), control delay `randint(lo, hi + 1)` (:627-631).  4096 envs are forced to
+    time out twice; checked: ranges, first two moments, ten-bin histograms, independence between envs / dofs / consecutive resets, and
+    that the same seed reproduces the same draws."""
+    N = 4096
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(21)
+        cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", N, noise_off=True)
+        dr = cfg.domain_rand
+        torch.manual_seed(22)
+        env.reset_all()
+        snaps = []
+        for k in range(2):
+            env.episode_length_buf = torch.full((N,), int(env.max_episode_length) + 5, device=DEV)       # -> every env times out this step
+            _, _, reset, extras = env.step({"actions": torch.zeros(N, env.num_dof, device=DEV)})
+            torch.cuda.synchronize()
+            assert int(reset.sum()) == N and bool(extras["time_outs"].all())
+            snaps.append(dict(start=env.motion_start_times.cpu().clone(), kp=env._kp_scale.cpu().clone(), kd=env._kd_scale.cpu().clone(),
+                              rfi=env._rfi_lim_scale.cpu().clone(), rao=env._rao_scale.cpu().clone(), delay=env.action_delay_idx.cpu().clone(),
+                              mlen=env.motion_len.cpu().clone()))
+        runs.append(snaps)
+    for a, b in zip(runs[0], runs[1]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"same seed, different {k}"
+
+    def uniform(x, lo, hi, what):
+        x = x.double().flatten()
+        n = x.numel()
+        assert float(x.min()) >= lo - 1e-6 and float(x.max()) < hi + 1e-6 * max(1.0, abs(hi)), (what, float(x.min()), float(x.max()))
+        u = (x - lo) / (hi - lo)
+        assert abs(float(u.mean()) - 0.5) < 4.0 * (1.0 / 12.0 / n) ** 0.5 + 1e-4, (what, "mean", float(u.mean()))
+        assert abs(float(u.var()) * 12.0 - 1.0) < 0.05 + 6.0 / n ** 0.5, (what, "variance", float(u.var()))
+        h = torch.histc(u.float(), bins=10, min=0.0, max=1.0).double() / n
+        assert float((h - 0.1).abs().max()) < 5.0 * (0.09 / n) ** 0.5 + 1e-3, (what, "histogram", h.tolist())
+
+    def uncorrelated(x, y, what):
+        x, y = x.double().flatten(), y.double().flatten()
+        r = float(((x - x.mean()) * (y - y.mean())).mean() / (x.std() * y.std()))
+        assert abs(r) < 5.0 / x.numel() ** 0.5, (what, r)
+
+    s0, s1 = runs[0]
+    mlen = float(s0["mlen"][0])
+    for tag, s in (("first reset", s0), ("second reset", s1)):
+        uniform(s["start"], 0.0, mlen, tag + " start phase")
+        uniform(s["kp"], dr.kp_range[0], dr.kp_range[1], tag + " kp")
+        uniform(s["kd"], dr.kd_range[0], dr.kd_range[1], tag + " kd")
+        uniform(s["rfi"], dr.rfi_lim_range[0], dr.rfi_lim_range[1], tag + " rfi limit")
+        uniform(s["rao"], -dr.rao_lim, dr.rao_lim, tag + " rao")
+        lo, hi = dr.ctrl_delay_step_range
+        cnt = torch.bincount(s["delay"] - lo, minlength=hi - lo + 1).double() / N
+        assert int(s["delay"].min()) >= lo and int(s["delay"].max()) <= hi
+        assert float((cnt - 1.0 / (hi - lo + 1)).abs().max()) < 5.0 * (0.25 / N) ** 0.5, (tag, "delay", cnt.tolist())
+        uncorrelated(s["kp"], s["kd"], tag + " kp vs kd")
+        uncorrelated(s["kp"], s["rfi"], tag + " kp vs rfi")
+        uncorrelated(s["kp"][:, 0], s["kp"][:, 1], tag + " kp dof 0 vs dof 1")
+        uncorrelated(s["kp"][:-1], s["kp"][1:], tag + " kp env i vs env i+1")
+        uncorrelated(s["start"], s["kp"][:, 0], tag + " start vs kp")
+        uncorrelated(s["start"][:-1], s["start"][1:], tag + " start env i vs env i+1")
+    uncorrelated(s0["start"], s1["start"], "start phase, consecutive resets")
+    uncorrelated(s0["kp"], s1["kp"], "kp, consecutive resets")
+    assert not torch.equal(s0["delay"], s1["delay"])
 
 
 def test_act_bwd_bias_matches_torch():

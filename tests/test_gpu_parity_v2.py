@@ -154,6 +154,17 @@ def test_ppo_mimic_learn_runs_two_iterations():
 def test_general_tracking_multi_clip_matches_oracle():
     """Mixed library (BASELINE configs[2]): 3 synthetic clips of different lengths, slots cycling through them, 512 envs — the HIP step
     against the oracle on identical replay tensors, with resets (per-slot motion lengths) and futures running past clip ends."""
+    _multi_clip_vs_oracle(512, 4, 3)
+
+
+def test_general_tracking_full_size_library_matches_oracle():
+    """BASELINE configs[2] at its full size: 4096 envs, G1 29-DoF, the 256-clip synthetic library `bench.py --workload v2_teacher29
+    --clips 256` measures (the AMASS / LAFAN sets are not shipped), per-env clip and phase — two control steps of the HIP step against
+    the oracle on identical replay tensors (the oracle's Python FK of 256 clips and two 4096-env general-tracking steps: about a minute)."""
+    _multi_clip_vs_oracle(4096, 2, 256, library_seed=7)
+
+
+def _multi_clip_vs_oracle(N, T, M, library_seed=3):
     import bench
     from oracle.env_v2 import GeneralTrackingOracle
     from oracle.fk import sim_fk
@@ -161,10 +172,9 @@ def test_general_tracking_multi_clip_matches_oracle():
     from pbhc_amd import motion_lib as ML
     from tests.helpers import clip_from_env_golden, fixture_config, skel_from_golden, synth_replay
 
-    N, T, M = 512, 4, 3
     cfgname = "v2_g1_29dof_teacher.yaml"
     g = dict(np.load(os.path.join(GOLDEN, "env_v2_teacher29.npz")))
-    clips = bench.synth_library(clip_from_env_golden(g), M, seed=3)
+    clips = bench.synth_library(clip_from_env_golden(g), M, seed=library_seed)
     orig = ML.load_motion_file
     ML.load_motion_file = lambda path: [(f"c{i}", c) for i, c in enumerate(clips)]
     try:
@@ -180,12 +190,12 @@ def test_general_tracking_multi_clip_matches_oracle():
     orc.env_origins = env.env_origins.cpu()
     orc.ref_init_yaw = env.ref_init_yaw
     orc.slot_clip = env._motion_lib.slot_clip.cpu().clone()
-    assert orc.slot_clip.tolist() == [i % M for i in range(N)]
+    assert len(set(orc.slot_clip.tolist())) == min(M, N) or M > 64           # every clip in use (small libraries)
     D = 29
     gen = torch.Generator().manual_seed(5)
     mlen = oml.motion_len[orc.slot_clip]
     start = torch.rand(N, generator=gen) * mlen
-    start[:48] = mlen[:48] - 0.05                        # motion-end time-outs (all three clips)
+    start[:48] = mlen[:48] - 0.05                        # motion-end time-outs (several clips)
     ep = torch.randint(0, 50, (N,), generator=gen)
     st = {k: v.clone() for k, v in orc.s.items()}
     st["motion_start_times"] = start; st["episode_length_buf"] = ep; st["last_episode_length_buf"] = ep.clone(); st["motion_len"] = mlen.clone()
