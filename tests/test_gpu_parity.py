@@ -15,14 +15,51 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-# Two quantities of the reference are discontinuous / ill-conditioned in fp32 and get a two-tier bound
-# (`hard` = worst case, `frac` = share of elements allowed above `tol`):
-#  * slerp (rotations.py:210-232) switches to 0.5*(q0+q1) when sin(half angle) < 1e-3: one ulp in the dot
-#    product flips the branch for near-static clips, a jump of up to |t-0.5|*|q1-q0| ~ 1e-3;
-#  * table angular velocities come from acos(2w^2-1) of a near-identity quaternion
-#    (torch_humanoid_batch.py:282-290): one ulp of w moves them by ~2e-4/|omega| rad/s.
-SLERP = dict(hard=1.2e-3, frac=0.05)
-ANGVEL = dict(hard=1e-2, frac=0.02, tol_override=2e-3)
+# Two quantities of the reference are discontinuous / ill-conditioned in fp32.  The HIP load-time FK already follows the reference's op
+# order (3x3 matrix chain, plain left-to-right products exactly like torch's CPU matmul, matrix_to_quaternion candidates): table
+# ROTATIONS agree to 2.4e-7 = 2 ulp (tools/tolerance_probe.py, profiles/round2_tolerance_probe.txt).  What is left comes from the
+# 1-ulp differences between glibc's and the GPU's sinf / cosf / acosf, amplified by the reference's own formulas:
+#  * table angular velocities are axis * acos(2w^2-1) / dt of a near-identity quaternion (torch_humanoid_batch.py:282-290):
+#    d(omega) = 4 dw / (omega dt^2), so k ulps of w move a slow body's omega by k * 4 * 6e-8 / (omega dt^2).  Bound PER ELEMENT by that
+#    conditioning with k = 4 ulps (`angvel_tol`; measured: 0 of 17010 table elements above it, the worst 5.9e-3 at |omega| < 0.05 rad/s,
+#    1.8e-4 above 1 rad/s) — not a blanket tolerance;
+#  * slerp (rotations.py:210-232) switches to 0.5*(q0+q1) when sin(half angle) < 1e-3, and it forms that sine as sqrt(1 - cos^2) with
+#    cos within 5e-7 of 1: one ulp of the dot product moves sin^2 by 12 %, so pairs with sin(half angle) in [0.7e-3, 1.4e-3] can take
+#    either branch (a jump of up to |t-0.5|*|q1-q0| ~ 1e-3).  Where the pair is known (`slerp_flip_zone`) the loose bound applies ONLY
+#    inside that zone and the plain one everywhere else; where only the outputs are at hand (env traces) SLERP keeps the two-tier form
+#    (`hard` = worst case, `frac` = share of elements allowed above `tol`; measured share 0.35 % on the near-static Horse-stance clip).
+SLERP = dict(hard=1.2e-3, frac=0.02)
+ANGVEL = dict(hard=1e-2, frac=0.02, tol_override=2e-3)     # env traces only (root angular velocity written by a reset: no frame pair at hand)
+
+
+def angvel_tol(ref, dt, k=16.0, base=5e-5, norm=None):
+    """elementwise bound for table / looked-up angular velocities: base + k * eps / (dt^2 |omega|), |omega| floored at 1e-3 rad per frame.
+    `norm` [..., 1]: the speed that conditions the element when it is not the element's own (see table_speed_floor)."""
+    ref = torch.as_tensor(ref).float()
+    wn = (ref.norm(dim=-1, keepdim=True) if norm is None else torch.as_tensor(norm).float()).clamp(min=1e-3 / dt)
+    return (base + k * 6e-8 / (dt * dt * wn)).expand_as(ref)
+
+
+def table_speed_floor(gavs_t, radius=8):
+    """[F, Bx, 1]: the slowest |omega| within the reference's Gaussian filter window (sigma 2, truncate 4 -> 8 frames either side): a table
+    entry is a weighted mean of the RAW per-frame values around it, and the slow ones among them carry the error"""
+    n = torch.as_tensor(gavs_t).float().norm(dim=-1)                       # [F, Bx]
+    F = n.shape[0]
+    idx = (torch.arange(F)[:, None] + torch.arange(-radius, radius + 1)[None, :]).clamp(0, F - 1)       # [F, 2r+1]
+    return n[idx].min(dim=1).values.unsqueeze(-1)
+
+
+def slerp_jump_bound(q0, q1, base=5e-5):
+    """[..., 1] bound on a slerp output of the pair (q0, q1): the reference's slerp (rotations.py:210-232) has two fall-backs, 0.5*(q0+q1)
+    when sin(half angle) < 1e-3 and q0 when cos >= 1, and it forms that sine as sqrt(1 - cos^2) with cos within 5e-7 of 1 — an ulp of the
+    dot product moves sin^2 by 12 % there — so a pair with sin(half angle) below 1.4e-3 may take another branch than the reference did: a
+    jump of at most 0.5 * |q1 - q0| (between the interpolated and the averaged / first quaternion).  Above it: the plain bound."""
+    q0, q1 = torch.as_tensor(q0).double(), torch.as_tensor(q1).double()
+    q1 = torch.where(((q0 * q1).sum(-1, keepdim=True) < 0), -q1, q1)
+    c = (q0 * q1).sum(-1, keepdim=True).clamp(max=1.0)
+    sh = torch.sqrt(1.0 - c * c)
+    jump = 0.5 * (q1 - q0).norm(dim=-1, keepdim=True) + 2e-5
+    return torch.where(sh < 1.4e-3, base + jump, torch.full_like(jump, base)).float()
 
 
 def close(a, b, tol, what, rtol=None, hard=None, frac=0.0, tol_override=None):
@@ -31,6 +68,10 @@ def close(a, b, tol, what, rtol=None, hard=None, frac=0.0, tol_override=None):
     b = torch.as_tensor(b).detach().float().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = (a - b).abs()
+    if torch.is_tensor(tol):                                  # elementwise absolute bound (conditioned tolerances)
+        tol = tol.detach().float().cpu()
+        assert tol.shape == b.shape, (what, tol.shape, b.shape)
+        rtol = 0.0 if rtol is None else rtol
     lim = tol + (tol if rtol is None else rtol) * b.abs()
     bad = err > lim
     if hard is not None:
@@ -73,13 +114,12 @@ def test_motion_build_matches_reference_fk():
     rot = rows[:, o + 3 * Bx:o + 7 * Bx].view(F, Bx, 4)
     close(rot, g["grs_t"], 3e-6, "grs_t")
     close(rows[:, o + 7 * Bx:o + 10 * Bx].view(F, Bx, 3), g["gvs_t"], 5e-5, "gvs_t")
-    # angular velocity = axis * acos(2w^2-1) / dt of a near-identity quaternion (reference
-    # torch_humanoid_batch.py:282-290) is ill-conditioned: one ulp of w moves it by ~4*ulp/(dt^2*|w|) ≈ 2e-4/|omega| rad/s,
-    # and HIP sinf/cosf differ from glibc by an ulp.  Bound: abs 1e-2 and 2e-3 relative Frobenius error over the table.
+    # angular velocity = axis * acos(2w^2-1) / dt of a near-identity quaternion (torch_humanoid_batch.py:282-290): bounded element by
+    # element by its conditioning (see angvel_tol above), plus the table-wide relative Frobenius error
     gav = rows[:, o + 10 * Bx:].view(F, Bx, 3)
-    close(gav, g["gavs_t"], 1e-2, "gavs_t")
     ref = torch.from_numpy(g["gavs_t"])
-    assert float((gav - ref).norm() / ref.norm()) < 2e-3
+    close(gav, ref, angvel_tol(ref, 1.0 / int(g["fps"]), norm=table_speed_floor(ref)), "gavs_t")
+    assert float((gav - ref).norm() / ref.norm()) < 1e-3
 
 
 @pytest.mark.parametrize("tag", ["wjx_horse", "origin_walk"])
@@ -91,10 +131,29 @@ def test_motion_state_matches_reference(tag):
     N = g["times"].shape[0]
     sk, ml = _hip_motion_lib(clip, N)
     res = ml.get_motion_state(torch.arange(N, device=DEV), torch.from_numpy(g["times"]).to(DEV), torch.from_numpy(g["offset"]).to(DEV))
+    # the frame pair of every lookup (oracle tables = the reference's, tests/test_oracle_motion.py): where can the reference's slerp flip?
+    from oracle.motion_lib import MotionLib as OML
+
+    oml = OML(skel_from_golden(), [clip])
+    times = torch.from_numpy(g["times"])
+    ids = torch.zeros(N, dtype=torch.long)
+    f0, f1, _ = oml.calc_frame_blend(times, oml.motion_len[ids], oml.num_frames[ids], oml.motion_dt[ids])
+    rot_tol = slerp_jump_bound(oml.cat["grs_t"][f0], oml.cat["grs_t"][f1])          # [N, Bx, 1]
+    speed = table_speed_floor(oml.cat["gavs_t"])                                    # [F, Bx, 1]
+    speed = torch.minimum(speed[f0], speed[f1])                                     # [N, Bx, 1]
+    dt_clip = float(oml.motion_dt[0])
     for k in ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos_t", "rg_rot_t", "body_vel_t", "body_ang_vel_t",
               "rg_pos", "rb_rot", "body_vel", "body_ang_vel"] + (["contact_mask"] if "contact_mask" in g else []):
-        extra = ANGVEL if "ang_vel" in k else (SLERP if "rot" in k else {})
-        close(res[k], g[k], 5e-5, f"{tag}:{k}", **extra)
+        ref = torch.from_numpy(g[k])
+        if "ang_vel" in k:
+            # lerp of two table rows: the slower of the two frames' filter windows conditions the pair
+            sp = speed[:, 0] if ref.dim() == 2 else speed[:, :ref.shape[1]]
+            close(res[k], ref, angvel_tol(ref, dt_clip, norm=sp), f"{tag}:{k}")
+        elif "rot" in k:
+            rt = rot_tol[:, 0] if ref.dim() == 2 else rot_tol[:, :ref.shape[1]]
+            close(res[k], ref, rt.expand_as(ref), f"{tag}:{k}", rtol=5e-5)
+        else:
+            close(res[k], ref, 5e-5, f"{tag}:{k}")
 
 
 def test_sim_fk_matches_oracle():
@@ -152,7 +211,9 @@ def test_env_step_matches_reference_trace(tag, cfgname):
             close(getattr(env, name), g["step__state__" + name][k], 3e-5, w + "state " + name)
         close(env.simulator.dof_pos, g["step__state__dof_pos"][k], 3e-5, w + "dof_pos")
         close(env.simulator.robot_root_states[:, :10], g["step__state__root_states"][k][:, :10], 3e-5, w + "root_states", **SLERP)
-        close(env.simulator.robot_root_states[:, 10:], g["step__state__root_states"][k][:, 10:], 3e-5, w + "root ang vel", **ANGVEL)
+        # a reset writes the looked-up root angular velocity of the reference motion: bounded by ITS conditioning (angvel_tol), everything else 3e-5
+        ref_w = torch.from_numpy(g["step__state__root_states"][k][:, 10:])
+        close(env.simulator.robot_root_states[:, 10:], ref_w, angvel_tol(ref_w, float(env._motion_lib._motion_dt[0]), k=32.0, base=3e-5), w + "root ang vel", rtol=3e-5)
         assert torch.equal(env.episode_length_buf.cpu(), torch.from_numpy(g["step__state__episode_length_buf"][k]))
         for name, col in env.episode_sums.items():
             close(col, g["step__state__sum__" + name][k], 3e-5, w + "sum " + name, rtol=1e-4)

@@ -30,9 +30,11 @@ for lo, hi in ((0, 0.05), (0.05, 0.2), (0.2, 1.0), (1.0, 100.0)):
         print(f"  |omega| in [{lo}, {hi}): n {int(m.sum())}, max err {float(err[m].max()):.3e}, max err*|omega| {float((err * wn)[m].max()):.3e}")
 # conditioning: d(omega) ~ k * eps / (dt^2 * |omega|) for the raw value; the sigma=2 Gaussian filter (17 taps) averages independent errors
 eps = 6e-8
-for kk in (2, 4, 8, 16):
-    bound = 5e-5 + kk * eps / (dt * dt * torch.clamp(wn, min=1e-3 / dt))
-    print(f"  k = {kk}: elements above 5e-5 + k*eps/(dt^2 |omega|): {int((err > bound).sum())}")
+from tests.test_gpu_parity import table_speed_floor
+for name, w_ in (("own |omega|", wn), ("slowest |omega| in the filter window", table_speed_floor(ref))):
+    for kk in (2, 4, 8, 16):
+        bound = 5e-5 + kk * eps / (dt * dt * torch.clamp(w_, min=1e-3 / dt))
+        print(f"  {name}, k = {kk}: elements above 5e-5 + k*eps/(dt^2 |omega|): {int((err > bound).sum())} of {err.numel()}")
 rot = rows[:, o + 3 * Bx:o + 7 * Bx].view(F, Bx, 4)
 print(f"table rotations: max err {float((rot - torch.from_numpy(g['grs_t'])).abs().max()):.3e}")
 for tag in ("wjx_horse", "origin_walk"):
