@@ -316,6 +316,7 @@ class MHPPO:
         self._last_obs = {k: torch.zeros(N, _lib.padded_width(d), device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
         self._sample_seed = pdist.rank_seed(int(torch.randint(0, 2**62, (1,)).item()))
         self._branch_stream = torch.cuda.Stream(device=self.device)
+        self._update_streams = os.environ.get("PBHC_UPDATE_STREAMS", "0") == "1"      # measured slower (37.0 vs 34.5 ms per update): off
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd MHPPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
         mb = (T * N) // self.num_mini_batches
@@ -475,8 +476,23 @@ class MHPPO:
             return self._update_ppo_eager(b, loss)
         lib = _lib.lib()
         c = self
-        mu = self.actor.actor_module(b["actor_obs"])
-        value = self.critic.critic_module(b["critic_obs"])
+        # The two networks are independent until the loss kernel: the critic's forward runs on the branch stream next to the actor's, and
+        # autograd replays each backward on the stream its forward ran on — the narrow layers of one network (128 / 23 / 21 columns: fewer
+        # output tiles than CUs) share the chip with the wide layers of the other.  Measured on MI355X (4096 envs): 37.0 ms per update
+        # against 34.5 ms on one stream — the wide GEMMs are tuned to own the chip and lose more than the narrow ones gain — so this
+        # stays an experiment behind PBHC_UPDATE_STREAMS=1.
+        two = self._update_streams
+        cur, br = torch.cuda.current_stream(), self._branch_stream
+        if two:
+            br.wait_stream(cur)
+            with torch.cuda.stream(br):
+                value = self.critic.critic_module(b["critic_obs"])
+            mu = self.actor.actor_module(b["actor_obs"])
+            cur.wait_stream(br)
+            value.record_stream(cur)                     # allocated on the branch stream, read by the loss kernel on this one
+        else:
+            mu = self.actor.actor_module(b["actor_obs"])
+            value = self.critic.critic_module(b["critic_obs"])
         B = mu.shape[0]
         if B != self._mb:
             raise _lib.PbhcError("minibatch size changed")
@@ -503,7 +519,11 @@ class MHPPO:
             h_a.wait(); h_c.wait()
             self._gflat.div_(self.world_size)
         else:
+            if two:
+                br.wait_stream(cur)                      # the loss kernel's gradients are ready for the critic's backward on its stream
             torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+            if two:
+                cur.wait_stream(br)
         # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm)
         _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
                                        self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
