@@ -346,6 +346,14 @@ int pbhc_sizeof_step_io(void);
 int pbhc_motion_build(const PbhcSkeleton* skel, const float* pose_aa, const float* trans, const float* contact,
                       int num_frames, float dt, float* out_rows, float* scratch, void* stream);
 
+/* The same for a whole library in ONE launch set (the reference runs the FK once per env slot in a Python loop over clips,
+ * motion_lib_base.py:403-472): the clips' frames concatenated — pose_aa [total_frames,Bx,3], trans [total_frames,3], contact [total_frames,2]
+ * or NULL — with frame_clip [total_frames] (clip of every frame), clip_start [num_clips+1] (first frame of every clip, then the total) and
+ * clip_dt [num_clips] (1 / fps), all device int32 / float.  Velocities and the Gaussian filter stop at clip boundaries.
+ * out_rows [total_frames,row]; scratch >= total_frames*Bx*14 floats. */
+int pbhc_motion_build_batch(const PbhcSkeleton* skel, const float* pose_aa, const float* trans, const float* contact, int total_frames, int num_clips,
+                            const int32_t* frame_clip, const int32_t* clip_start, const float* clip_dt, float* out_rows, float* scratch, void* stream);
+
 /* Phase lookup + lerp/slerp.  Replaces MotionLibBase.get_motion_state (motion_lib_base.py:123-259).
  * ids [N] int64, times [N], offset [N,3] or NULL -> out [N,row] packed like a frame row
  * (positions include the offset). */

@@ -190,7 +190,21 @@ def part_motion_state():
              motion_dt=np.float32(dt), num_frames=np.int64(ml._motion_num_frames[0]), **{k: res[k] for k in keys})
 
 
-PARTS = dict(rotations=part_rotations, skeleton_fk=part_skeleton_fk, motion_state=part_motion_state)
+def part_target_heading():
+    """load_motions(target_heading=...) of the reference (motion_lib_base.py:445-456): every clip re-based to face the target heading."""
+    from humanoidverse.utils.motion_lib.motion_lib_robot import MotionLibRobot
+
+    f = "motion_data/g1_walk_45cms_23dof.pkl"
+    th = np.array([0.0, 0.0, np.sin(0.35), np.cos(0.35)])                    # 0.7 rad about z, xyzw
+    ml = MotionLibRobot(motion_cfg(ROBOTS["g1_23dof"], f), num_envs=2, device="cpu")
+    ml.load_motions(random_sample=False, target_heading=th)
+    F = int(ml._motion_num_frames[0])
+    clip = next(iter(safe_pkl.load(f).values()))
+    save("motion_target_heading_walk.npz", clip_file=np.array(f), target_heading=th, pose_aa=clip["pose_aa"], root_trans_offset=clip["root_trans_offset"],
+         fps=np.int64(clip["fps"]), gts_t=ml.gts_t[:F], grs_t=ml.grs_t[:F], gvs_t=ml.gvs_t[:F], gavs_t=ml.gavs_t[:F], dof_pos=ml.dof_pos[:F])
+
+
+PARTS = dict(rotations=part_rotations, skeleton_fk=part_skeleton_fk, motion_state=part_motion_state, target_heading=part_target_heading)
 
 if __name__ == "__main__":
     try:

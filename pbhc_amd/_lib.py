@@ -86,7 +86,7 @@ PbhcStepIO = _S["PbhcStepIO"]
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
-           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations"]
+           "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch"]
 
 
 class PbhcError(RuntimeError):
@@ -107,6 +107,7 @@ def _load():
         raise PbhcError("struct layout mismatch between libpbhc_hip.so and include/pbhc_hip.h — rebuild")
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     lib.pbhc_motion_build.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, f, vp, vp, vp]
+    lib.pbhc_motion_build_batch.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp]
     lib.pbhc_motion_state.argtypes = [C.POINTER(PbhcMotionTable), i, i, vp, vp, vp, i, vp, vp]
     lib.pbhc_sim_fk.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp]
     lib.pbhc_env_create.argtypes = [C.POINTER(PbhcEnvConfig), C.POINTER(PbhcMotionTable), vp, C.POINTER(vp)]

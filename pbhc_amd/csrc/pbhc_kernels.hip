@@ -1640,12 +1640,19 @@ __global__ void k_motion_fk(PbhcSkeleton sk, const float* __restrict__ pose_aa, 
 }
 
 // raw velocities: np.gradient/dt and angle-axis of q_{t+1} * conj(q_t) (torch_humanoid_batch.py:272-290)
-__global__ void k_motion_rawvel(const float* __restrict__ pos, const float* __restrict__ rot, int F, int Bx, float dt,
+// `frame_clip` / `clip_start` / `clip_dt` (may be NULL: one clip of F frames): frame -> clip, first frame of every clip (+ the total),
+// frame time per clip — the batched build of a whole library in one launch set (pbhc_motion_build_batch)
+__global__ void k_motion_rawvel(const float* __restrict__ pos, const float* __restrict__ rot, int Ftot, int Bx, float dt1,
+                                const int32_t* __restrict__ frame_clip, const int32_t* __restrict__ clip_start, const float* __restrict__ clip_dt,
                                 float* __restrict__ vel, float* __restrict__ ang) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F * Bx) return;
-  int f = i / Bx, b = i % Bx;
-  auto P = [&](int ff, int k) { return pos[((size_t)ff * Bx + b) * 3 + k]; };
+  if (i >= Ftot * Bx) return;
+  int fg = i / Bx, b = i % Bx;
+  int base = 0, F = Ftot;
+  float dt = dt1;
+  if (frame_clip) { const int cidx = frame_clip[fg]; base = clip_start[cidx]; F = clip_start[cidx + 1] - base; dt = clip_dt[cidx]; }
+  const int f = fg - base;
+  auto P = [&](int ff, int k) { return pos[((size_t)(base + ff) * Bx + b) * 3 + k]; };
   for (int k = 0; k < 3; ++k) {
     float g;
     if (F == 1) g = 0.0f;
@@ -1655,7 +1662,7 @@ __global__ void k_motion_rawvel(const float* __restrict__ pos, const float* __re
     vel[(size_t)i * 3 + k] = g / dt;
   }
   f4 dq = mk4(0.f, 0.f, 0.f, 1.f);
-  if (f < F - 1) dq = quat_unit(quat_mul(ld4(rot + ((size_t)(f + 1) * Bx + b) * 4), quat_conj(ld4(rot + ((size_t)f * Bx + b) * 4))));
+  if (f < F - 1) dq = quat_unit(quat_mul(ld4(rot + ((size_t)(fg + 1) * Bx + b) * 4), quat_conj(ld4(rot + ((size_t)fg * Bx + b) * 4))));
   float s = 2.0f * (dq.w * dq.w) - 1.0f;
   float angle = acosf(clampf(s, -1.0f, 1.0f));
   float n = fmaxf(sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-9f);
@@ -1667,11 +1674,19 @@ __global__ void k_motion_rawvel(const float* __restrict__ pos, const float* __re
 // scipy.ndimage.gaussian_filter1d(sigma=2, mode="nearest", truncate=4) along time, double accumulation,
 // then pack the frame rows
 __global__ void k_motion_pack(PbhcSkeleton sk, const float* __restrict__ pose_aa, const float* __restrict__ contact, const float* __restrict__ pos,
-                              const float* __restrict__ rot, const float* __restrict__ vel, const float* __restrict__ ang, int F, float dt, int row,
+                              const float* __restrict__ rot, const float* __restrict__ vel, const float* __restrict__ ang, int Ftot, float dt1, int row,
+                              const int32_t* __restrict__ frame_clip, const int32_t* __restrict__ clip_start, const float* __restrict__ clip_dt,
                               float* __restrict__ out) {
   const int Bx = sk.num_bodies_ext, D = sk.num_dof, B = sk.num_bodies;
-  int f = blockIdx.x;
-  float* o = out + (size_t)f * row;
+  const int fg = blockIdx.x;
+  int base = 0, F = Ftot;
+  float dt = dt1;
+  if (frame_clip) { const int cidx = frame_clip[fg]; base = clip_start[cidx]; F = clip_start[cidx + 1] - base; dt = clip_dt[cidx]; }
+  const int f = fg - base;
+  // everything below indexes frames of THIS clip: shift the per-frame arrays to its first frame
+  pose_aa += (size_t)base * Bx * 3; pos += (size_t)base * Bx * 3; rot += (size_t)base * Bx * 4; vel += (size_t)base * Bx * 3; ang += (size_t)base * Bx * 3;
+  if (contact) contact += (size_t)base * 2;
+  float* o = out + (size_t)fg * row;
   double w[9];
   double wsum = 0.0;
   for (int k = 0; k <= 8; ++k) { w[k] = exp(-0.5 * (double)(k * k) / 4.0); wsum += (k == 0 ? 1.0 : 2.0) * w[k]; }
@@ -1863,8 +1878,29 @@ int pbhc_motion_build(const PbhcSkeleton* skel, const float* pose_aa, const floa
   float* vel = rot + (size_t)F * Bx * 4;
   float* ang = vel + (size_t)F * Bx * 3;
   hipLaunchKernelGGL(k_motion_fk, dim3((F + 63) / 64), dim3(64), 0, st, *skel, pose_aa, trans, F, pos, rot);
-  hipLaunchKernelGGL(k_motion_rawvel, dim3((F * Bx + 127) / 128), dim3(128), 0, st, pos, rot, F, Bx, dt, vel, ang);
-  hipLaunchKernelGGL(k_motion_pack, dim3(F), dim3(128), 0, st, *skel, pose_aa, contact, pos, rot, vel, ang, F, dt, row, out_rows);
+  hipLaunchKernelGGL(k_motion_rawvel, dim3((F * Bx + 127) / 128), dim3(128), 0, st, pos, rot, F, Bx, dt, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                     (const float*)nullptr, vel, ang);
+  hipLaunchKernelGGL(k_motion_pack, dim3(F), dim3(128), 0, st, *skel, pose_aa, contact, pos, rot, vel, ang, F, dt, row, (const int32_t*)nullptr,
+                     (const int32_t*)nullptr, (const float*)nullptr, out_rows);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_motion_build_batch(const PbhcSkeleton* skel, const float* pose_aa, const float* trans, const float* contact, int total_frames, int num_clips,
+                            const int32_t* frame_clip, const int32_t* clip_start, const float* clip_dt, float* out_rows, float* scratch, void* stream) {
+  int rc = check_skel(skel);
+  if (rc) return rc;
+  ARG_CHECK(pose_aa && trans && out_rows && scratch && frame_clip && clip_start && clip_dt && total_frames >= 1 && num_clips >= 1 && num_clips <= total_frames);
+  hipStream_t st = (hipStream_t)stream;
+  const int Bx = skel->num_bodies_ext, D = skel->num_dof, F = total_frames;
+  const int row = 2 * D + 2 + 13 * Bx;
+  float* pos = scratch;
+  float* rot = pos + (size_t)F * Bx * 3;
+  float* vel = rot + (size_t)F * Bx * 4;
+  float* ang = vel + (size_t)F * Bx * 3;
+  hipLaunchKernelGGL(k_motion_fk, dim3((F + 63) / 64), dim3(64), 0, st, *skel, pose_aa, trans, F, pos, rot);
+  hipLaunchKernelGGL(k_motion_rawvel, dim3((unsigned)(((size_t)F * Bx + 127) / 128)), dim3(128), 0, st, pos, rot, F, Bx, 0.0f, frame_clip, clip_start, clip_dt, vel, ang);
+  hipLaunchKernelGGL(k_motion_pack, dim3(F), dim3(128), 0, st, *skel, pose_aa, contact, pos, rot, vel, ang, F, 0.0f, row, frame_clip, clip_start, clip_dt, out_rows);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }

@@ -54,6 +54,29 @@ def save_motion_npz(path, clips):
     np.savez_compressed(path, **arrs)
 
 
+def rebase_heading(clip, target_heading):
+    """motion_lib_base.py:445-456 on the host, in float64 like the reference (scipy Rotation): heading_delta = target * inv(heading of the first
+    root rotation); root pose_aa <- heading_delta * root rotation, root translation <- translation @ heading_delta^T."""
+    from scipy.spatial.transform import Rotation as sRot
+
+    pose = np.array(clip["pose_aa"], dtype=np.float32, copy=True)
+    trans = np.asarray(clip["root_trans_offset"])
+    q0 = sRot.from_rotvec(pose[0, 0].astype(np.float64)).as_quat()                     # xyzw
+    # calc_heading_quat_inv (isaac_utils/rotations.py:296-306) in fp32 like the reference's torch call: rotate the x axis, atan2, -heading about z
+    q = q0.astype(np.float32)
+    w = q[3]
+    v = np.array([1.0, 0.0, 0.0], np.float32)
+    rot = v * (2.0 * w * w - 1.0) + np.cross(q[:3], v) * w * 2.0 + q[:3] * np.dot(q[:3], v) * 2.0
+    heading = np.float32(np.arctan2(rot[1], rot[0]))
+    hinv = np.array([0.0, 0.0, np.sin(-heading / 2.0), np.cos(-heading / 2.0)], dtype=np.float32)
+    delta = sRot.from_quat(np.asarray(target_heading, dtype=np.float64)) * sRot.from_quat(hinv.astype(np.float64))
+    pose[:, 0] = (delta * sRot.from_rotvec(pose[:, 0].astype(np.float64))).as_rotvec().astype(np.float32)
+    out = dict(clip)
+    out["pose_aa"] = pose
+    out["root_trans_offset"] = (trans.astype(np.float64) @ delta.as_matrix().squeeze().T).astype(np.float32)
+    return out
+
+
 class MotionLib:
     def __init__(self, skeleton, clips, num_envs, device, max_len=-1):
         """clips: list of clip dicts (see load_motion_file).  max_len > 0: `load_motions` gives every env slot its own random crop of at most
@@ -83,35 +106,50 @@ class MotionLib:
         self.max_len = -1
         self._raw = None
         self.slot_table = self.slot_clip                 # the kernel's motion ids: unique-clip tables, slot -> clip
-        rows, starts, nframes, dts, lens = [], [], [], [], []
-        s = 0
-        st = _lib.current_stream()
+        self._clips = clips                              # kept for load_motions(target_heading=...) (host arrays)
+        self._build_unique_tables(clips)
+
+    def _build_unique_tables(self, clips, into=None):
+        """FK + filtered velocities of EVERY unique clip in one launch set (`pbhc_motion_build_batch`): the clips' frames are concatenated on the
+        host, uploaded once, and the kernels stop velocities / the Gaussian filter at clip boundaries — no per-clip launch, copy or
+        synchronisation (the reference runs a Python FK per env slot).  `into`: rebuild in place (same row count)."""
+        Bx = self.skeleton.num_bodies_ext
+        nframes, dts = [], []
         for c in clips:
-            fps = int(c["fps"])
-            pose = torch.as_tensor(np.asarray(c["pose_aa"], dtype=np.float32)[:, :Bx]).contiguous().to(self.device)
-            trans = torch.as_tensor(np.asarray(c["root_trans_offset"], dtype=np.float32)).contiguous().to(self.device)
-            if pose.shape[1] != Bx:
-                raise _lib.PbhcError(f"pose_aa has {pose.shape[1]} bodies, skeleton needs {Bx}")
-            F = pose.shape[0]
-            contact = None
-            if self.has_contact_mask:
-                contact = torch.as_tensor(np.asarray(c["contact_mask"], dtype=np.float32)).contiguous().to(self.device)
-                if tuple(contact.shape) != (F, 2):
-                    raise _lib.PbhcError(f"contact mask shape {tuple(contact.shape)} is not supported")
-            out = torch.empty(F, self.row, device=self.device)
-            scratch = torch.empty(F * Bx * 14, device=self.device)
-            _lib.check(_lib.lib().pbhc_motion_build(C.byref(self._csk), _lib.ptr(pose), _lib.ptr(trans), _lib.ptr(contact), F,
-                                                    1.0 / fps, _lib.ptr(out), _lib.ptr(scratch), st), "pbhc_motion_build")
-            torch.cuda.current_stream().synchronize()      # scratch/pose are freed after this iteration
-            rows.append(out)
-            starts.append(s); nframes.append(F); dts.append(1.0 / fps); lens.append(1.0 / fps * (F - 1))
-            s += F
-        self.frames = torch.cat(rows, dim=0).contiguous()
-        self.length_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
-        self.num_frames = torch.tensor(nframes, dtype=torch.int32, device=self.device)
-        self._motion_dt = torch.tensor(dts, dtype=torch.float32, device=self.device)
-        self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=self.device)
-        self._fill_table(len(clips), int(nframes[0]), dts[0], lens[0])
+            if np.asarray(c["pose_aa"]).shape[1] < Bx:
+                raise _lib.PbhcError(f"pose_aa has {np.asarray(c['pose_aa']).shape[1]} bodies, skeleton needs {Bx}")
+            F = np.asarray(c["pose_aa"]).shape[0]
+            if self.has_contact_mask and tuple(np.asarray(c["contact_mask"]).shape) != (F, 2):
+                raise _lib.PbhcError(f"contact mask shape {tuple(np.asarray(c['contact_mask']).shape)} is not supported")
+            nframes.append(F); dts.append(1.0 / int(c["fps"]))
+        starts = np.concatenate([[0], np.cumsum(nframes)]).astype(np.int32)
+        total = int(starts[-1])
+        pose = np.concatenate([np.asarray(c["pose_aa"], dtype=np.float32)[:, :Bx] for c in clips], axis=0)
+        trans = np.concatenate([np.asarray(c["root_trans_offset"], dtype=np.float32) for c in clips], axis=0)
+        dev = self.device
+        d_pose = torch.from_numpy(np.ascontiguousarray(pose)).to(dev)
+        d_trans = torch.from_numpy(np.ascontiguousarray(trans)).to(dev)
+        d_contact = None
+        if self.has_contact_mask:
+            d_contact = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(c["contact_mask"], dtype=np.float32) for c in clips], axis=0))).to(dev)
+        d_fc = torch.from_numpy(np.repeat(np.arange(len(clips), dtype=np.int32), nframes)).to(dev)
+        d_start = torch.from_numpy(starts).to(dev)
+        d_dt = torch.tensor(dts, dtype=torch.float32, device=dev)
+        out = torch.empty(total, self.row, device=dev) if into is None else into
+        assert out.shape[0] == total
+        scratch = torch.empty(total * Bx * 14, device=dev)
+        _lib.check(_lib.lib().pbhc_motion_build_batch(C.byref(self._csk), _lib.ptr(d_pose), _lib.ptr(d_trans), _lib.ptr(d_contact), total, len(clips),
+                                                      _lib.ptr(d_fc), _lib.ptr(d_start), _lib.ptr(d_dt), _lib.ptr(out), _lib.ptr(scratch),
+                                                      _lib.current_stream()), "pbhc_motion_build_batch")
+        torch.cuda.current_stream().synchronize()          # ONE synchronisation: the staging tensors above die with this scope
+        if into is not None:
+            return
+        self.frames = out
+        self.length_starts = d_start[:-1].contiguous()
+        self.num_frames = torch.tensor(nframes, dtype=torch.int32, device=dev)
+        self._motion_dt = d_dt
+        self._motion_lengths = torch.tensor([dt * (F - 1) for dt, F in zip(dts, nframes)], dtype=torch.float32, device=dev)
+        self._fill_table(len(clips), int(nframes[0]), dts[0], dts[0] * (nframes[0] - 1))
 
     def _fill_table(self, num_entries, f0, dt0, len0):
         self.table.frames = self.frames.data_ptr()
@@ -189,9 +227,12 @@ class MotionLib:
     def load_motions(self, random_sample=True, start_idx=0, max_len=-1, target_heading=None, sampling_prob=None, crop_starts=None):
         """Slot -> clip assignment; the per-clip FK tables were built once at construction (the reference re-runs FK for every slot here).
         With a library built for `max_len` crops, every slot's crop is re-drawn and its table rebuilt (crop_starts: fixed starts, tests).
-        `target_heading` re-basing is not supported."""
+        `target_heading` (xyzw quaternion): every clip is yawed so that its first frame faces that heading (root rotation and translation,
+        motion_lib_base.py:445-456) and the tables are rebuilt in place."""
         if target_heading is not None:
-            raise NotImplementedError("load_motions(target_heading)")
+            if self.max_len > 0:
+                raise NotImplementedError("load_motions(target_heading) with max_len crops")
+            self._build_unique_tables([rebase_heading(c, target_heading) for c in self._clips], into=self.frames)
         if max_len != -1 and max_len != self.max_len and (self.max_len != -1 or any(int(f) >= max_len for f in self.num_frames.tolist())):
             raise _lib.PbhcError(f"load_motions(max_len={max_len}): the library was built with max_len={self.max_len} (pass robot.motion.motion_max_len at construction)")
         # in place: the step kernel holds the pointer of this tensor

@@ -156,6 +156,44 @@ def test_motion_state_matches_reference(tag):
             close(res[k], ref, 5e-5, f"{tag}:{k}")
 
 
+def test_library_batch_build_directory_mode_and_target_heading(tmp_path):
+    """Motion-library ingestion: a DIRECTORY of clip files (motion_lib_base.py:63-107) built by ONE batched launch set — every
+    clip's rows equal its own single-clip build bit for bit (velocities and the Gaussian filter stop at clip boundaries) — and
+    load_motions(target_heading=...) (motion_lib_base.py:445-456) against the tables the reference built with that heading."""
+    import bench
+    from pbhc_amd import _lib
+    from pbhc_amd.motion_lib import MotionLib, save_motion_npz
+    from pbhc_amd.skeleton import Skeleton
+
+    sk = Skeleton.from_json(os.path.join(GOLDEN, "skeleton_g1_23dof_lock_wrist_fitmotionONLY.json"))
+    g = dict(np.load(os.path.join(GOLDEN, "motion_target_heading_walk.npz")))
+    base = dict(pose_aa=g["pose_aa"], root_trans_offset=g["root_trans_offset"], fps=int(g["fps"]))
+    clips = bench.synth_library(base, 5, seed=1)
+    for i, c in enumerate(clips):                                       # one file per clip, names out of order: the directory is read sorted
+        save_motion_npz(str(tmp_path / f"clip_{(7 * i) % 5}.npz"), [(f"m{i}", c)])
+    mcfg = type("Cfg", (dict,), {"__getattr__": dict.get})(motion_file=str(tmp_path), motion_lib_type="origin")
+    ml = MotionLib.from_config(mcfg, sk, 16, DEV)
+    order = sorted(range(5), key=lambda i: f"clip_{(7 * i) % 5}.npz")
+    assert ml._num_unique_motions == 5 and ml.num_frames.tolist() == [clips[i]["pose_aa"].shape[0] for i in order]
+    for k, i in enumerate(order):
+        single = MotionLib(sk, [clips[i]], 1, DEV)
+        a = int(ml.length_starts[k])
+        assert torch.equal(ml.frames[a:a + single.frames.shape[0]], single.frames), f"clip {i}: batched rows differ from its own build"
+    # target heading: the library of ONE clip the reference fixture was made from
+    one = MotionLib(sk, [base], 4, DEV)
+    ptr = one.frames.data_ptr()
+    one.load_motions(random_sample=False, target_heading=g["target_heading"])
+    assert one.frames.data_ptr() == ptr and one.table.frames == ptr       # rebuilt in place: the step kernel's pointers stay valid
+    rows = one.frames.cpu()
+    D, Bx = sk.num_dof, sk.num_bodies_ext
+    F = rows.shape[0]
+    o = 2 * D + 2
+    close(rows[:, o:o + 3 * Bx].view(F, Bx, 3), g["gts_t"], 5e-6, "target heading gts_t")
+    close(rows[:, o + 3 * Bx:o + 7 * Bx].view(F, Bx, 4).abs(), np.abs(g["grs_t"]), 5e-6, "target heading grs_t")
+    close(rows[:, :D], g["dof_pos"], 2e-6, "target heading dof_pos")
+    close(rows[:, o + 7 * Bx:o + 10 * Bx].view(F, Bx, 3), g["gvs_t"], 1e-4, "target heading gvs_t")
+
+
 def test_sim_fk_matches_oracle():
     from oracle.fk import sim_fk
     from pbhc_amd import _lib

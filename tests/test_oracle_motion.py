@@ -89,3 +89,25 @@ def test_motion_state(golden_dir, tag):
         assert torch.allclose(a, b, rtol=1e-5, atol=2e-5), (k, float((a - b).abs().max()))
     B = int(sk["num_bodies"])
     assert np.allclose(g["rg_pos"], g["rg_pos_t"][:, :B]) and np.allclose(g["body_vel"], g["body_vel_t"][:, :B], atol=1e-6)
+
+
+def test_target_heading_rebase_matches_reference(golden_dir):
+    """load_motions(target_heading=...) (motion_lib_base.py:445-456): the host-side re-basing of pbhc_amd.motion_lib.rebase_heading, pushed
+    through the (pinned) oracle FK, reproduces the tables the reference built with the same target heading."""
+    from pbhc_amd.motion_lib import rebase_heading
+
+    g = dict(np.load(os.path.join(golden_dir, "motion_target_heading_walk.npz")))
+    clip = dict(pose_aa=g["pose_aa"], root_trans_offset=g["root_trans_offset"], fps=int(g["fps"]))
+    reb = rebase_heading(clip, g["target_heading"])
+    skel = dict(np.load(os.path.join(golden_dir, "skeleton_fk_g1_23dof.npz")))
+    from tests.helpers import skel_from_golden
+
+    t = motion_fk(skel_from_golden(), reb["pose_aa"], reb["root_trans_offset"], 1.0 / int(g["fps"]))
+    assert torch.allclose(t["gts_t"], torch.from_numpy(g["gts_t"]), atol=5e-6)
+    assert torch.allclose(t["grs_t"].abs(), torch.from_numpy(g["grs_t"]).abs(), atol=5e-6)
+    assert torch.allclose(t["dof_pos"], torch.from_numpy(g["dof_pos"]), atol=2e-6)
+    assert torch.allclose(t["gvs_t"], torch.from_numpy(g["gvs_t"]), atol=1e-4)
+    # the heading of the first root rotation is the target's
+    q = t["grs_t"][0, 0]
+    head = R.calc_heading(q[None])[0]
+    assert abs(float(head) - 0.7) < 1e-5
