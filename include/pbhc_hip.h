@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 4
+#define PBHC_ABI_VERSION 5
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -150,6 +150,7 @@ enum PbhcLog {
   PBHC_L_TERM_MOTION_END, PBHC_L_END_TIME_RATIO, PBHC_L_END_TIME_RATIO_STD, PBHC_L_NUM_RESETS, PBHC_L_REW_MEAN,
   PBHC_L_KEY_BODY_DIFF_NORM, PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM, PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM, PBHC_L_LOCAL_VR_3POINT_DIFF_NORM,
   PBHC_L_LOCAL_KEY_BODY_DIFF_NORM, PBHC_L_TERM_REF_POS_Z, PBHC_L_TERM_REF_ORI, PBHC_L_TERM_BODY_Z,
+  PBHC_L_TERM_CONTACT, PBHC_L_TERM_LOW_HEIGHT,
   PBHC_L_NUM
 };
 
@@ -257,6 +258,11 @@ typedef struct PbhcEnvConfig {
   int32_t future_num_steps, future_steps[PBHC_MAX_FUTURE];   /* linspace(1, future_max_steps, future_num_steps) as long */
   int32_t terminate_by_ref_pos_z, terminate_by_ref_ori, terminate_by_body_z;
   float ref_pos_z_threshold, ref_ori_threshold, body_z_threshold;
+  /* legged_robot_base.py:434-444: any |contact force| > 1 N on robot.terminate_after_contacts_on bodies; root height below a minimum */
+  int32_t terminate_by_contact, terminate_by_low_height;
+  int32_t num_term_contact, term_contact[PBHC_MAX_IDX];
+  float termination_min_base_height;
+  int32_t pad2_;
   uint64_t seed;
 } PbhcEnvConfig;
 

@@ -58,6 +58,10 @@ class MotionTrackingOracle:
         for name in rc.penalize_contacts_on:
             pen.extend([s for s in self.body_names if name in s])
         self.penalised = [find(s) for s in pen]
+        tcon = []
+        for n in rc.get("terminate_after_contacts_on", []):                     # base_task.py:178-180
+            tcon.extend([s_ for s_ in self.body_names if n in s_])
+        self.termination_contact = [find(s_) for s_ in tcon]
         m = rc.motion
         self.ext_parent = [self.body_list.index(e["parent_name"]) for e in m.extend_config]
         self.ext_pos = _f([list(e["pos"]) for e in m.extend_config])
@@ -268,9 +272,15 @@ class MotionTrackingOracle:
         reset = torch.zeros(N, dtype=torch.bool)
         by = {}
         T = ec.termination
+        if T.get("terminate_by_contact", False):              # legged_robot_base.py:434-436
+            by["contact"] = torch.any(torch.norm(frame["contact"][:, self.termination_contact, :], dim=-1) > 1.0, dim=1)
+            reset |= by["contact"]
         if T.terminate_by_gravity:
             by["gravity"] = torch.norm(self.projected_gravity[:, 0:2], dim=-1) > ec.termination_scales.termination_gravity
             reset |= by["gravity"]
+        if T.get("terminate_by_low_height", False):           # :442-444
+            by["low_height"] = frame["root"][:, 2] < ec.termination_scales.termination_min_base_height
+            reset |= by["low_height"]
         if T.terminate_when_motion_far:
             by["motion_far"] = torch.any(torch.norm(self.dif_pos, dim=-1) > self.motion_far_thr, dim=-1)
             reset |= by["motion_far"]

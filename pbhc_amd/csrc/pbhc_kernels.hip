@@ -69,6 +69,7 @@ enum {
   P_UPPER_NORM = PBHC_NUM_SIGMA, P_LOWER_NORM, P_VR_NORM, P_JOINT_NORM, P_CLIP_CNT, P_RESET_CNT, P_TERM_GRAVITY, P_TERM_FAR,
   P_TERM_TIMEOUT, P_TERM_END, P_RESET_EPLEN, P_ETR_SUM, P_ETR_SQ, P_REW_SUM,
   P_KEY_NORM, P_LUP_NORM, P_LLO_NORM, P_LVR_NORM, P_LKEY_NORM, P_TERM_REFZ, P_TERM_REFORI, P_TERM_BODYZ,      // general tracking
+  P_TERM_CONTACT, P_TERM_LOWH,
   P_NUM
 };
 static_assert(P_NUM <= PBHC_NP, "partials");
@@ -118,9 +119,10 @@ enum {
   M_RCONTACT0, M_RCONTACT1, M_GRAV, M_FAR, M_END, M_TOUT_LEN, M_LASTEP, M_NEWSTART, M_DELAY, M_FAT0, M_FAT1,
   M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ,
   M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI,                     // general tracking: termination causes, anchor z / gravity-z differences
-  M_CLIPCNT                                                     // clipped actions of this step (role B -> reduction row)
+  M_CLIPCNT,                                                    // clipped actions of this step (role B -> reduction row)
+  M_TCONTACT, M_TLOWH                                           // termination causes: contact on a terminating body, low base height
 };
-static_assert(M_CLIPCNT < 48, "MISC region");
+static_assert(M_TLOWH < 48, "MISC region");
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
 // flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
@@ -718,6 +720,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       misc[M_CONTACT0 + f] = cn;
       misc[M_CFILT0 + f] = (cn != 0.0f || lastc != 0.0f) ? 1.0f : 0.0f;
     }
+    if (c.terminate_by_contact) {                              // legged_robot_base.py:434-436
+      float hit = 0.0f;
+      if (valid)
+        for (int i = lane; i < c.num_term_contact; i += PBHC_G)
+          if (norm3(ld3(cf + 3 * c.term_contact[i])) > 1.0f) hit = 1.0f;
+      hit = group_max(hit);
+      if (valid && lane == 0) misc[M_TCONTACT] = hit;
+    }
     STAMPB(1);
     // ---- phase D: reference frame: lerp / slerp of the two frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
     if (valid) {
@@ -910,6 +920,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       tlen = misc[M_EPLEN] > c.max_episode_length ? 1.0f : 0.0f;
       if (c.terminate_when_motion_end) tend = (misc[M_EPLEN] * dt + misc[M_START]) > misc[M_MLEN] ? 1.0f : 0.0f;
       float tout = (tlen != 0.0f || tend != 0.0f) ? 1.0f : 0.0f;
+      float tcontact = 0.0f, tlowh = 0.0f;
+      if (c.terminate_by_contact) tcontact = misc[M_TCONTACT];
+      if (c.terminate_by_low_height) tlowh = root[2] < c.termination_min_base_height ? 1.0f : 0.0f;         // :442-444
+      misc[M_TCONTACT] = tcontact; misc[M_TLOWH] = tlowh;
       float refz = 0.0f, refori = 0.0f, bodyz = 0.0f;
       if (MODE) {                                   // general_tracking.py:241-254
         if (c.terminate_by_ref_pos_z) refz = fabsf(misc[M_ADZ]) > c.ref_pos_z_threshold ? 1.0f : 0.0f;
@@ -919,7 +933,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       }
       misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
       misc[M_TIMEOUT] = tout;
-      misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f) ? 1.0f : 0.0f;
+      misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f || tcontact != 0.0f || tlowh != 0.0f) ? 1.0f : 0.0f;
     }
     WAVE_LDS_FENCE();
     // a terminated env's history is zero in the observations of this very step (history_handler.py:33-38 via reset_envs_idx): zeroed
@@ -1423,6 +1437,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       bpq[P_RESET_EPLEN] = misc[M_RESET] != 0.0f ? misc[M_LASTEP] : 0.0f;
       bpq[P_ETR_SUM] = etr_val; bpq[P_ETR_SQ] = etr_val * etr_val;
       bpq[P_REW_SUM] = rew_total;
+      bpq[P_TERM_CONTACT] = misc[M_TCONTACT]; bpq[P_TERM_LOWH] = misc[M_TLOWH];
       if (MODE) {
         bpq[P_KEY_NORM] = red[R_KEYN]; bpq[P_LUP_NORM] = red[R_LUPN]; bpq[P_LLO_NORM] = red[R_LLON]; bpq[P_LVR_NORM] = red[R_LVRN];
         bpq[P_LKEY_NORM] = red[R_LKEYN]; bpq[P_TERM_REFZ] = misc[M_REFZ]; bpq[P_TERM_REFORI] = misc[M_REFORI]; bpq[P_TERM_BODYZ] = misc[M_BODYZ];
@@ -1519,6 +1534,7 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
   } else if (tid == 128) {
     L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
     L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
+    L[PBHC_L_TERM_CONTACT] = (tot[P_TERM_CONTACT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_LOW_HEIGHT] = (tot[P_TERM_LOWH] / N) / (rfrac + 1e-15);
     if (c.tracking_mode) {
       L[PBHC_L_TERM_REF_POS_Z] = (tot[P_TERM_REFZ] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_REF_ORI] = (tot[P_TERM_REFORI] / N) / (rfrac + 1e-15);
       L[PBHC_L_TERM_BODY_Z] = (tot[P_TERM_BODYZ] / N) / (rfrac + 1e-15);
@@ -1936,6 +1952,8 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   ARG_CHECK(cfg->num_feet >= 1 && cfg->num_feet <= PBHC_MAX_FEET);
   ARG_CHECK(cfg->num_terms >= 0 && cfg->num_terms <= PBHC_MAX_TERMS && cfg->num_terms <= PBHC_G && cfg->num_rew_cols <= PBHC_G);
   ARG_CHECK(cfg->num_groups >= 1 && cfg->num_groups <= PBHC_MAX_GROUPS);
+  ARG_CHECK(cfg->num_term_contact >= 0 && cfg->num_term_contact <= PBHC_MAX_IDX);
+  for (int i = 0; i < cfg->num_term_contact; ++i) ARG_CHECK(cfg->term_contact[i] >= 0 && cfg->term_contact[i] < cfg->skel.num_bodies);
   ARG_CHECK(cfg->queue_len >= 1 && cfg->queue_len <= PBHC_MAX_QUEUE);
   ARG_CHECK(tbl->row == 2 * D + 2 + 13 * Bx && tbl->frames && tbl->num_motions >= 1);
   ARG_CHECK(cfg->feat_dim > 0 && cfg->feat_dim < 16384);

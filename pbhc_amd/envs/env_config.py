@@ -161,8 +161,6 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
             raise NotImplementedError(f"domain_rand.{unsupported}")
     if dr.get("randomize_default_dof_pos", False):
         raise NotImplementedError("domain_rand.randomize_default_dof_pos")
-    if dr.get("reinit_epis_rand", -1) > 0:
-        raise NotImplementedError("domain_rand.reinit_epis_rand (re-randomisation of the episodic DR at exponential intervals, legged_robot_base.py:390-395)")
     # ---- body index sets
     names = skel.body_names
     ext = skel.body_names_ext
@@ -206,10 +204,21 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     L.feet, L.penalised, L.upper, L.lower, L.track, L.key = feet, pen, upper, lower, track, key_ids
     # ---- termination
     T = ec.termination
-    for flag in ("terminate_by_contact", "terminate_by_low_height", "terminate_when_close_to_dof_pos_limit",
-                 "terminate_when_close_to_dof_vel_limit", "terminate_when_close_to_torque_limit", "terminate_when_dof_far"):
+    for flag in ("terminate_when_close_to_dof_pos_limit", "terminate_when_close_to_dof_vel_limit", "terminate_when_close_to_torque_limit",
+                 "terminate_when_dof_far"):
         if T.get(flag, False):
             raise NotImplementedError(f"termination.{flag}")
+    c.terminate_by_contact = int(bool(T.get("terminate_by_contact", False)))                 # legged_robot_base.py:434-436
+    tcon = []
+    for n in rc.get("terminate_after_contacts_on", []):                                     # base_task.py:178-180,195-197
+        tcon.extend([names.index(s_) for s_ in names if n in s_])
+    if c.terminate_by_contact and len(tcon) > K["PBHC_MAX_IDX"]:
+        raise _lib.PbhcError("too many terminate_after_contacts_on bodies")
+    c.num_term_contact = len(tcon) if c.terminate_by_contact else 0
+    for i, b_ in enumerate(tcon[:c.num_term_contact]):
+        c.term_contact[i] = b_
+    c.terminate_by_low_height = int(bool(T.get("terminate_by_low_height", False)))           # :442-444
+    c.termination_min_base_height = float(ec.termination_scales.get("termination_min_base_height", 0.0))
     c.terminate_by_gravity = int(bool(T.terminate_by_gravity))
     c.termination_gravity = float(ec.termination_scales.termination_gravity)
     c.terminate_when_motion_far = int(bool(T.terminate_when_motion_far))

@@ -143,6 +143,10 @@ class LeggedRobotMotionTracking:
         self._resample_motion_times(torch.arange(N, device=dev))
         if config.get("resample_motion_when_training", False):
             self.resample_time_interval = np.ceil(config.resample_time_interval_s / self.dt)
+        # domain_rand.reinit_epis_rand > 0: the episodic DR of EVERY env is re-drawn at exponentially distributed intervals
+        # (legged_robot_base.py:149-151,390-395)
+        self.reinit_epis_rand = float(config.domain_rand.get("reinit_epis_rand", -1))
+        self.reinit_epis_rand_counter = float(-np.log(np.random.rand()) * self.reinit_epis_rand) if self.reinit_epis_rand > 0 else float("inf")
         self.init_done = True
 
     def _load_motions_initial(self):
@@ -370,20 +374,7 @@ class LeggedRobotMotionTracking:
         self._episode_length_buf.zero_()
         if not keep_reset_buf:
             self.reset_buf.fill_(1)
-        # _episodic_domain_randomization (legged_robot_base.py:599-635)
-        dr = self.config.domain_rand
-        D = self.num_dof
-        u = lambda lo, hi: (hi - lo) * torch.rand(N, D, device=dev, generator=self._gen) + lo
-        if dr.randomize_pd_gain:
-            self._kp_scale.copy_(u(dr.kp_range[0], dr.kp_range[1]))
-            self._kd_scale.copy_(u(dr.kd_range[0], dr.kd_range[1]))
-        if dr.randomize_rfi_lim:
-            self._rfi_lim_scale.copy_(u(dr.rfi_lim_range[0], dr.rfi_lim_range[1]))
-        if dr.use_rao:
-            self._rao_scale.copy_(u(-dr.rao_lim, dr.rao_lim))
-        if dr.randomize_ctrl_delay:
-            self.action_queue.zero_()
-            self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev, generator=self._gen))
+        self._episodic_domain_randomization_all()
         # curricula keyed on average_episode_length (legged_robot_base.py:882-900, motion_tracking.py:309-317)
         c = self._c
         avg_f = float(avg)
@@ -410,6 +401,22 @@ class LeggedRobotMotionTracking:
         self.extras["episode"]["end_epis_length"] = self.last_episode_length_buf.clone()
         self._episode_sums.zero_()
         self.extras["time_outs"] = self.time_out_buf
+
+    def _episodic_domain_randomization_all(self):
+        """_episodic_domain_randomization(arange(N)) (legged_robot_base.py:599-635): kp / kd / rfi-limit / rao scales, control delay."""
+        N, dev, D = self.num_envs, self.device, self.num_dof
+        dr = self.config.domain_rand
+        u = lambda lo, hi: (hi - lo) * torch.rand(N, D, device=dev, generator=self._gen) + lo
+        if dr.randomize_pd_gain:
+            self._kp_scale.copy_(u(dr.kp_range[0], dr.kp_range[1]))
+            self._kd_scale.copy_(u(dr.kd_range[0], dr.kd_range[1]))
+        if dr.randomize_rfi_lim:
+            self._rfi_lim_scale.copy_(u(dr.rfi_lim_range[0], dr.rfi_lim_range[1]))
+        if dr.use_rao:
+            self._rao_scale.copy_(u(-dr.rao_lim, dr.rao_lim))
+        if dr.randomize_ctrl_delay:
+            self.action_queue.zero_()
+            self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev, generator=self._gen))
 
     def step(self, actor_state):
         """legged_robot_base.py:239-265 — one fused launch."""
@@ -444,6 +451,9 @@ class LeggedRobotMotionTracking:
         # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
         # it takes effect one control step later — once every resample_time_interval (50 000 - 100 000 steps in the shipped configs).
         # The dones returned for this step stay the kernel's own (the reference's resample_motion does not touch reset_buf).
+        if self.common_step_counter >= self.reinit_epis_rand_counter:             # legged_robot_base.py:390-395 (after the fused launch: from the next step on)
+            self._episodic_domain_randomization_all()
+            self.reinit_epis_rand_counter = self.common_step_counter + float(-np.log(np.random.rand()) * self.reinit_epis_rand)
         if self.config.get("resample_motion_when_training", False) and self.common_step_counter % self.resample_time_interval == 0:
             self.resample_motion(keep_reset_buf=True)
         else:
@@ -470,6 +480,10 @@ class LeggedRobotMotionTracking:
             "average_episode_length": g[K["PBHC_G_AVG_EP_LEN"]], "terminate_when_motion_far_threshold": g[K["PBHC_G_MOTION_FAR_THR"]],
             "reward_mean": g[L0 + K["PBHC_L_REW_MEAN"]],
         }
+        if self._c.terminate_by_contact:
+            out["terminate_by_contact"] = g[L0 + K["PBHC_L_TERM_CONTACT"]]
+        if self._c.terminate_by_low_height:
+            out["terminate_by_low_height"] = g[L0 + K["PBHC_L_TERM_LOW_HEIGHT"]]
         for i, k in enumerate(env_config.SIGMA_KEYS):
             out["adp_sigma_" + k] = g[K["PBHC_G_SIGMA"] + i]
             out["error_ema_" + k] = g[K["PBHC_G_EMA"] + i]

@@ -289,16 +289,25 @@ def test_env_step_matches_oracle_ragged_tail():
     _env_step_vs_oracle(13, 4)
 
 
-def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml"):
+def test_env_step_contact_and_low_height_terminations():
+    """termination.terminate_by_contact / terminate_by_low_height (legged_robot_base.py:434-444; off in the shipped yamls): contact forces on
+    `robot.terminate_after_contacts_on` bodies and a base-height floor above some envs' root height — reset flags, rewards, observations
+    and the per-cause log means against the oracle."""
+    ov = {"env.config.termination.terminate_by_contact": True, "env.config.termination.terminate_by_low_height": True,
+          "env.config.termination_scales.termination_min_base_height": 0.74}
+    _env_step_vs_oracle(512, 3, overrides=ov, contact_hits=True)
+
+
+def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
 
-    cfg, env = build_hip_env(cfgname, N)
+    cfg, env = build_hip_env(cfgname, N, overrides=overrides)
     g = load_env_golden(tag)
     skel = skel_from_golden()
     oml = OML(skel, [clip_from_env_golden(g)])
-    ocfg = fixture_config(cfgname, N)
+    ocfg = fixture_config(cfgname, N, overrides)
     dr = dict(base_com_bias=env.simulator._base_com_bias.cpu(), link_mass_scale=env.simulator._link_mass_scale.cpu(), friction_coeffs=env.simulator.friction_coeffs.cpu())
     orc = MotionTrackingOracle(ocfg, skel, oml, N, dr)
     orc.env_origins = env.env_origins.cpu()
@@ -314,6 +323,12 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
     st["rfi_lim_scale"] = 0.5 + torch.rand(N, 23, generator=gen); st["rao_scale"] = 0.1 * (torch.rand(N, 23, generator=gen) - 0.5)
     st["action_delay_idx"] = torch.randint(0, 3, (N,), generator=gen)
     root, qp, qv, cf = synth_replay(oml, skel, N, T + 1, start, ep, orc.dt, orc.env_origins, 6, orc.feet)
+    if contact_hits:                                     # every 9th env: 5 N on one of the terminating bodies, in a different step each
+        assert len(orc.termination_contact) >= 2
+        for k in range(1, T + 1):
+            ids = torch.arange(k, N, 9 * T)
+            cf[k, ids, orc.termination_contact[k % len(orc.termination_contact)], 1] = 5.0
+        root[1:, ::7, 2] -= 0.08                         # every 7th env sinks below the base-height floor
     st["root_states"], st["dof_pos"], st["dof_vel"], st["contact_forces"] = root[0], qp[0], qv[0], cf[0]
     flat = {k: v.numpy() for k, v in st.items()}
     for k in orc.sums:
@@ -350,6 +365,11 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
+        if contact_hits:
+            log = env.read_log()
+            for cause in ("contact", "low_height", "gravity"):
+                close(torch.tensor(log["terminate_by_" + cause]), orc.log["terminate_by_" + cause], 1e-5, w + "log terminate_by_" + cause)
+            assert float(orc.log["terminate_by_contact"]) > 0 and float(orc.log["terminate_by_low_height"]) > 0
         # extras["episode"] (legged_robot_base.py:510-515): per reset env, gathered lazily on the device.  Step k's mapping is read one step
         # LATE (after step k+1 ran): env.step() materialises a mapping that somebody kept before it overwrites the buffers.
         if int(o_reset.sum()) > 0:
