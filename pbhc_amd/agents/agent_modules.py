@@ -210,12 +210,6 @@ class ActorCritic(nn.Module):
     def critic(self):
         return self.critic_module
 
-    def reset(self, dones=None):
-        pass
-
-    def forward(self):
-        raise NotImplementedError
-
     @property
     def action_mean(self):
         return self.distribution.mean

@@ -75,12 +75,6 @@ class PPOActor(nn.Module):
     def actor(self):
         return self.actor_module
 
-    def reset(self, dones=None):
-        pass
-
-    def forward(self):
-        raise NotImplementedError
-
     @property
     def action_mean(self):
         return self.distribution.mean
@@ -117,9 +111,6 @@ class PPOCritic(nn.Module):
     def critic(self):
         return self.critic_module
 
-    def reset(self, dones=None):
-        pass
-
     def evaluate(self, critic_obs, **kwargs):
         return self.critic(critic_obs)
 
@@ -146,24 +137,13 @@ class RolloutStorage(nn.Module):
         self.register_buffer(key, buf, persistent=False)
         self.stored_keys.append(key)
 
-    def increment_step(self):
-        self.step += 1
-
     def update_key(self, key, data):
         assert not data.requires_grad
         assert self.step < self.num_transitions_per_env, "Rollout buffer overflow"
         getattr(self, key)[self.step].copy_(data)
 
-    def batch_update_data(self, key, data):
-        assert not data.requires_grad
-        getattr(self, key)[:] = data
-
     def clear(self):
         self.step = 0
-
-    def query_key(self, key):
-        assert hasattr(self, key), key
-        return getattr(self, key)
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8, keys=None, indices=None):
         """One permutation per call, the same contiguous slices every epoch (data_utils.py:134-152).

@@ -26,3 +26,32 @@ def test_bench_json_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "env-steps/s" and "sample" in cb
+
+
+def test_bench_secondary_object_is_configs_2():
+    """the default invocation appends BASELINE.json configs[2] (general tracking, 29-DoF, 256-clip library) as `secondary`"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--envs", "256", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    s = r["secondary"]
+    assert s["value"] > 0 and s["unit"] == "env-steps/s" and "29-DoF" in s["config"]["workload"] and "256 clips" in s["config"]["workload"]
+    assert s["roofline"]["bound"] == "hbm" and s["roofline"]["kernel_ms"] > 0 and s["roofline_update"]["bound"] == "mfma"
+
+
+def test_rccl_code_path_on_one_rank():
+    """PBHC_DIST_FORCE=1: a ONE-rank RCCL process group takes the data-parallel code path — broadcast of the initial weights, async gradient-
+    segment all-reduces overlapping the critic's backward, the advantage-moment and KL exchanges, the per-step 512-byte env-statistics
+    all-reduce + `pbhc_env_finalize`, all next to hipGraph replays of the policy forward.  What a one-GPU box can rehearse of the N-GPU run."""
+    env = dict(os.environ, PBHC_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--envs", "512", "--no-cpu-baseline", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = r["collectives"]
+    assert c["backend"] == "nccl" and r["n_gpus"] == 1
+    # per iteration: 20 optimiser steps x (2 gradient segments + 1 KL scalar) + 1 advantage-moment exchange + 24 env-statistics exchanges
+    assert c["all_reduces_per_iter"] == 20 * 3 + 1 + 24, c
+    assert c["grad_bucket_bytes"] == 4 * 1308995 and c["grad_allreduce_ms"] > 0
