@@ -15,6 +15,10 @@ cfg, env, _ = build(N, "cuda:0", 0)
 env.reset_all()
 env.simulator.set_replay(*make_replay_on_device(env, 130, 1))
 lib = _lib.lib()
+# experiments on the write traffic (PMC WRITE_SIZE): drop the optional state outputs / the observation noise
+if os.environ.get("PBHC_PROBE_NO_OPT", "0") == "1":
+    for k in ("rigid_body_state", "contact_forces", "ref_body_pos_extend", "ref_body_rot_extend", "episode_rew_out"):
+        setattr(env._io, k, None)
 act = torch.zeros(N, env.num_dof, device="cuda:0")
 for _ in range(20):
     env.step({"actions": act})
