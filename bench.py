@@ -234,7 +234,7 @@ def dry_run(a, world, rank):
     from pbhc_amd import dist as pdist
 
     pdist.reset_counters()
-    grads = torch.full((1_308_995,), float(rank + 1))             # the v1 actor+critic bucket (362 286 + 946 709 parameters)
+    grads = torch.full((1_308_995,), float(rank + 1))             # the size of the reference's v1 actor+critic bucket (362 286 + 946 709 parameters)
     pdist.allreduce_mean_(grads)
     assert abs(float(grads[0]) - (world + 1) / 2.0) < 1e-6
     adv = torch.arange(64.0) + 100.0 * rank

@@ -220,6 +220,7 @@ typedef struct PbhcEnvConfig {
   int32_t term_penalty[PBHC_MAX_TERMS];      /* in reward_penalty_reward_names and curriculum on */
   int32_t term_sum_col[PBHC_MAX_TERMS];      /* column in episode_sums */
   int32_t term_src[PBHC_MAX_TERMS];          /* filled by pbhc_env_create (kernel-internal slot of the term's raw value, or -1) */
+  int32_t sum_col_term[32];                  /* filled by pbhc_env_create: the term that accumulates into episode_sums column i, or -1 */
   int32_t has_termination, termination_sum_col, only_positive_rewards, num_sum_cols;
   float termination_scale;
   float body_pos_lower_weight, body_pos_upper_weight, desired_feet_air_time, max_contact_force;
@@ -441,6 +442,21 @@ typedef struct PbhcColsumJob {
 } PbhcColsumJob;
 int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int act, float* dz, float* scratch, int* num_row_blocks, void* stream);
 int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
+
+/* One Linear of a training-time Linear / activation stack on the fp32 matrix cores with its activation folded into the GEMM epilogue
+ * (agents/modules/modules.py:47-63: `nn.Linear` followed by `nn.ELU` / `nn.ReLU`; replaces torch.addmm + F.elu_):
+ *   y[M,N] = act(x[M,K] . w[N,K]^T + bias[N])        act: 0 none, 1 ELU (alpha 1), 3 ReLU;  bias may be NULL
+ * x, w row-major, contiguous (rows need 4-byte alignment only).  f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
+int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int act, void* stream);
+/* The input gradient of that Linear with the activation backward of the layer BELOW folded in (what autograd runs as mm + elu_backward +
+ * a column sum; replaces `dy @ w` + pbhc_act_bwd_partials):
+ *   dx[M,N] = (dy[M,K] . w[K,N]) * act'(saved[M,N])   N = in_features, K = out_features; saved = the lower layer's activation OUTPUT
+ *   scratch[b, :] = column sums of dx over row block b (*num_row_blocks of them, <= PBHC_ACT_MAX_BLOCKS; finish with pbhc_colsum_final)
+ * scratch may be NULL (no column sums); act 0: saved unused. */
+int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, float* dx, float* scratch, int* num_row_blocks, int M, int N, int K,
+                          int act, void* stream);
+/* diagnosis: force the tile shape of the two entries above (0: 128x128, 1: 96x128, 2: 64x128; -1: automatic) */
+void pbhc_gemm_debug_force_shape(int shape);
 
 /* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,
  * ppo_mimic.py:184-190,682-686) over ONE flat fp32 segment of n

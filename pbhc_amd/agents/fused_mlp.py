@@ -1,8 +1,11 @@
 """Training-time forward/backward of a Linear/activation stack (`BaseModule`, reference agents/modules/modules.py:47-63) arranged for
-MI355X: the GEMMs stay library GEMMs (hipBLASLt / rocBLAS through torch), everything around them is fused or removed:
+MI355X:
 
-* the activation backward and the bias gradient of the layer below are ONE pass (`pbhc_act_bwd_bias`) instead of an
-  `elu_backward` + a column-sum launch;
+* hidden layers run on the fp32 matrix cores in `pbhc_linear_act_fwd` — bias + ELU / ReLU applied to the accumulators, no separate
+  activation pass — and their input gradients in `pbhc_linear_dgrad_act`, which folds in the activation derivative of the layer below and
+  the row-block column sums of its bias gradient (csrc/pbhc_gemm.hip: LDS-DMA staged, `v_mfma_f32_32x32x2_f32`).  `PBHC_FUSED_GEMM=0`
+  returns to library GEMMs (hipBLASLt / rocBLAS through torch) + the `pbhc_act_bwd_bias` pass; SiLU stacks always take that path;
+* weight gradients and the narrow output layer stay library GEMMs (split-K batched form below);
 * weight / bias gradients are written by the GEMM (`out=`) and the fused kernel straight into the parameter's `.grad` — a view of
   the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear.  That store
   OVERWRITES, so it is opt-in: only a stack whose owner declared `grad_direct(seq)` — "I zero the gradient buffer before every backward"
@@ -14,6 +17,7 @@ Same arithmetic as autograd's (the column sums are two-stage fp32 in a fixed ord
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -23,6 +27,7 @@ import torch.nn.functional as F
 from .. import _lib
 
 _ACT_ID = {nn.ELU: 1, nn.SiLU: 2, nn.ReLU: 3}
+FUSED_GEMM = os.environ.get("PBHC_FUSED_GEMM", "1") != "0"
 
 
 class _Live:
@@ -71,8 +76,19 @@ class _FusedMLP(torch.autograd.Function):
         act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
         saved_in, saved_act = [], []
         h = x if x.is_contiguous() else x.contiguous()
+        fused = FUSED_GEMM and act in (1, 3) and h.is_cuda and h.dtype == torch.float32
+        if fused:
+            lib, st = _lib.lib(), _lib.current_stream()
         for i, l in enumerate(lin):
             saved_in.append(h)
+            if fused and i < len(lin) - 1 and l.weight.is_contiguous():
+                B = h.shape[0]
+                z = torch.empty(B, l.out_features, device=h.device)
+                _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(),
+                                                   B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
+                h = z
+                saved_act.append(h)
+                continue
             z = torch.addmm(l.bias, h, l.weight.t())
             if i == len(lin) - 1:
                 out = z
@@ -85,7 +101,7 @@ class _FusedMLP(torch.autograd.Function):
             else:
                 saved_act.append(z)                    # SiLU' needs the pre-activation
                 h = F.silu(z)
-        ctx.seq, ctx.act, ctx.n = seq, act, len(lin)
+        ctx.seq, ctx.act, ctx.n, ctx.fused = seq, act, len(lin), fused
         ctx.live = None
         if getattr(seq, "_grad_direct", False):
             ctx.live = _Live()
@@ -119,15 +135,20 @@ class _FusedMLP(torch.autograd.Function):
             if len(seq._fused_live) > 1:
                 seq._fused_shared = True
             may_direct = not seq._fused_shared
+        offs = []
+        for l in lin:
+            offs.append(off)
+            off += MAXB * l.out_features
+        have_partials = False                     # the fused input-gradient GEMM of the layer above already left d = dz and its column sums
         for i in reversed(range(L)):
             l = lin[i]
             n = l.out_features
             direct = may_direct and l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
-            part = scratch[off:off + MAXB * n]
-            off += MAXB * n
-            _lib.check(lib.pbhc_act_bwd_partials(d.data_ptr(), acts[i].data_ptr() if i < L - 1 else None, B, n, ctx.act if i < L - 1 else 0, d.data_ptr(),
-                                                 part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
+            part = scratch[offs[i]:offs[i] + MAXB * n]
+            if not have_partials:
+                _lib.check(lib.pbhc_act_bwd_partials(d.data_ptr(), acts[i].data_ptr() if i < L - 1 else None, B, n, ctx.act if i < L - 1 else 0, d.data_ptr(),
+                                                     part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
             j = jobs[L - 1 - i]
             j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
             if direct:
@@ -135,7 +156,16 @@ class _FusedMLP(torch.autograd.Function):
                 ret_w.append((None, None))
             else:
                 ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device)), gb))
-            if i > 0 or ctx.needs_input_grad[0]:
+            have_partials = False
+            if i > 0 and ctx.fused and l.weight.is_contiguous():
+                # d_below = (d W) * act'(output of the layer below) + its row-block column sums, in the GEMM's epilogue
+                k = l.in_features
+                dn = torch.empty(B, k, device=d.device)
+                _lib.check(lib.pbhc_linear_dgrad_act(d.data_ptr(), l.weight.data_ptr(), acts[i - 1].data_ptr(), dn.data_ptr(),
+                                                     scratch[offs[i - 1]:].data_ptr(), C.byref(nb), B, k, n, ctx.act, st), "pbhc_linear_dgrad_act")
+                d = dn
+                have_partials = True
+            elif i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
         _lib.check(lib.pbhc_colsum_final(jobs, L, st), "pbhc_colsum_final")
         if ctx.live is not None:

@@ -1,0 +1,592 @@
+// fp32 GEMMs of the PPO update's Linear / activation stacks on the gfx950 matrix cores, with the work the library GEMMs leave to extra
+// passes folded into the epilogue (reference: the nn.Sequential of Linear + ELU built by agents/modules/modules.py:47-63 and differentiated
+// by autograd in agents/ppo.py:391-410):
+//   forward   y = act(x W^T + b)                       — bias + ELU/ReLU applied to the accumulators (no separate in-place ELU pass)
+//   backward  dx = (dy W) * act'(saved), colsum(dx)    — the activation derivative of the layer below and the row-block column sums of
+//                                                         its bias gradient, taken from the accumulators (no `pbhc_act_bwd_bias` pass)
+// `v_mfma_f32_32x32x2_f32`: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain (64 FLOP/clk/SIMD = 157 TFLOP/s on 256 CUs).
+// It issues once per 64 cycles, so feeding it is cheap — one ds_read_b128 per operand tile per four MFMAs — and what matters is that
+// nothing stalls the issue: double-buffered LDS stages with ONE barrier per stage, next stage's global loads in flight during the
+// MFMAs, two workgroups per CU so that one's barrier / epilogue hides under the other's MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pbhc_hip.h"
+
+extern thread_local char g_pbhc_err[512];
+#define GEMM_FAIL(code, ...) do { snprintf(g_pbhc_err, sizeof(g_pbhc_err), __VA_ARGS__); return (code); } while (0)
+#define GEMM_ARG(cond) do { if (!(cond)) GEMM_FAIL(PBHC_EINVAL, "%s: argument check failed: %s", __func__, #cond); } while (0)
+#define GEMM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) GEMM_FAIL(PBHC_EHIP, "%s: %s: %s", __func__, #expr, hipGetErrorString(e_)); } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define GEMM_T 256
+
+__device__ __forceinline__ float gemm_act(int act, float v) {
+  if (act == 1) return v > 0.0f ? v : expf(v) - 1.0f;       // ATen's GPU ELU: exp(x) - 1 in f32 (ActivationEluKernel.cu)
+  if (act == 3) return v > 0.0f ? v : 0.0f;
+  return v;
+}
+__device__ __forceinline__ float gemm_act_grad(int act, float s) {      // from the activation OUTPUT (ELU alpha 1, ReLU)
+  if (act == 1) return s > 0.0f ? 1.0f : s + 1.0f;
+  if (act == 3) return s > 0.0f ? 1.0f : 0.0f;
+  return 1.0f;
+}
+
+// four consecutive floats of a row starting at column c (row length `len`), zeros beyond the row's end.  Rows are only 4-byte aligned in
+// general (630-wide critic observations, 23-wide action gradients): global_load_dwordx4 needs dword alignment only.
+struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, bool rowok, int c, int len) {
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  if (rowok && c + 4 <= len) {
+    t = reinterpret_cast<const F4U*>(p)->v;
+  } else if (rowok && c < len) {                           // the chunk that straddles the row's end (once per row, last K stage only)
+    t[0] = p[0];
+    if (c + 1 < len) t[1] = p[1];
+    if (c + 2 < len) t[2] = p[2];
+  }
+  return t;
+}
+
+// MODE 0 ("NT", forward):  C[M,N] = act(A[M,K] . B[N,K]^T + bias[N])
+// MODE 1 ("NN", backward): C[M,N] = (A[M,K] . B[K,N]) * act'(S[M,N]);  part[blockRow][N] = column sums of C over the block's rows
+// Workgroup = 4 waves as WM x WN, a wave owns TM x TN tiles of 32x32; BM = 32 WM TM, BN = 32 WN TN; BK floats of K per LDS stage.
+// K order inside a block of 8: lane (r, kk) holds k = 4 kk + s at MFMA step s for BOTH operands, so an operand tile is one 16-byte LDS read
+// per four steps (any k permutation common to A and B leaves the product unchanged; the fmaf order is fixed, hence deterministic).
+template <int MODE, int WM, int WN, int TM, int TN, int BK>
+__global__ __launch_bounds__(GEMM_T, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                                     const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ part,
+                                                     int M, int N, int K, int act, int tiles_n, int dbg) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int AS = BK + 4;                              // A row stride in LDS (floats): 16-byte aligned rows, conflict-free b128 reads
+  constexpr int BS = MODE == 0 ? BK + 4 : BN + 8;         // B: [BN][BK+4] (k-contiguous) or [BK][BN+8] (n-contiguous; 4 rows apart = 32 banks)
+  constexpr int A_STAGE = BM * AS, B_STAGE = MODE == 0 ? BN * BS : BK * BS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 (A_STAGE + B_STAGE) floats
+  float* As = lds;
+  float* Bs = lds + 2 * A_STAGE;
+
+  // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous run of row panels so that the
+  // column tiles of one row panel (which share the A panel) meet in one L2
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r = lane & 31, kk = lane >> 5;
+
+  // ---- global -> register staging of one K stage ----
+  constexpr int A_TPR = BK / 4;                           // threads per A row (16 bytes each)
+  constexpr int A_N = (BM * A_TPR + GEMM_T - 1) / GEMM_T;
+  constexpr int B_TPR = (MODE == 0 ? BK : BN) / 4;        // threads per B row (a row = one n for MODE 0, one k for MODE 1)
+  constexpr int B_ROWS = MODE == 0 ? BN : BK;
+  constexpr int B_N = (B_ROWS * B_TPR + GEMM_T - 1) / GEMM_T;
+  f32x4 ra[A_N], rb[B_N];
+
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int e = tid + i * GEMM_T, row = e / A_TPR, kq = (e - row * A_TPR) * 4;
+      const bool ok = (BM * A_TPR) % GEMM_T == 0 || e < BM * A_TPR;
+      const int gr = row0 + row, gk = k0 + kq;
+      ra[i] = load4(A + (size_t)gr * K + gk, ok && gr < M, gk, K);
+    }
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+      const int e = tid + i * GEMM_T, row = e / B_TPR, q = (e - row * B_TPR) * 4;
+      const bool ok = (B_ROWS * B_TPR) % GEMM_T == 0 || e < B_ROWS * B_TPR;
+      if (MODE == 0) {
+        const int gn = col0 + row, gk = k0 + q;
+        rb[i] = load4(B + (size_t)gn * K + gk, ok && gn < N, gk, K);
+      } else {
+        const int gk = k0 + row, gn = col0 + q;
+        rb[i] = load4(B + (size_t)gk * N + gn, ok && gk < K, gn, N);
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* as = As + buf * A_STAGE;
+    float* bs = Bs + buf * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int e = tid + i * GEMM_T, row = e / A_TPR, kq = (e - row * A_TPR) * 4;
+      if ((BM * A_TPR) % GEMM_T == 0 || e < BM * A_TPR) *reinterpret_cast<f32x4*>(as + row * AS + kq) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+      const int e = tid + i * GEMM_T, row = e / B_TPR, q = (e - row * B_TPR) * 4;
+      if ((B_ROWS * B_TPR) % GEMM_T == 0 || e < B_ROWS * B_TPR) *reinterpret_cast<f32x4*>(bs + row * BS + q) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int nk = (K + BK - 1) / BK;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = (dbg & 1) ? 0 : kb & 1;
+    if (kb + 1 < nk && !(dbg & 1)) load_stage((kb + 1) * BK);           // in flight during this stage's MFMAs
+    const float* as = As + cur * A_STAGE + (wm * TM * 32 + r) * AS + kk * 4;
+    const float* bs = MODE == 0 ? Bs + cur * B_STAGE + (wn * TN * 32 + r) * BS + kk * 4 : Bs + cur * B_STAGE + (kk * 4) * BS + wn * TN * 32 + r;
+#pragma unroll
+    for (int k8 = 0; k8 < BK / 8; ++k8) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * AS + k8 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (MODE == 0) {
+          b[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BS + k8 * 8);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[j][s] = bs[(k8 * 8 + s) * BS + j * 32];
+        }
+      }
+      if (!(dbg & 2))
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kb + 1 < nk && !(dbg & 1)) store_stage(cur ^ 1);                // the other buffer was last read before the previous barrier
+    if (!(dbg & 4)) __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 tile: element e of lane (r, kk) is row 8 (e / 4) + 4 kk + (e % 4), column r ----
+  float cs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + (wn * TN + j) * 32 + r;
+    const bool cok = col < N;
+    const float bv = (MODE == 0 && bias && cok) ? bias[col] : 0.0f;
+    cs[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rb0 = row0 + (wm * TM + i) * 32 + 4 * kk;
+      if (MODE == 1 && act) {
+        float sv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rb0 + 8 * (e >> 2) + (e & 3);
+          sv[e] = (cok && row < M) ? S[(size_t)row * N + col] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= gemm_act_grad(act, sv[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rb0 + 8 * (e >> 2) + (e & 3);
+        float v = acc[i][j][e];
+        if (MODE == 0) v = gemm_act(act, v + bv);
+        if (cok && row < M) Cout[(size_t)row * N + col] = v;
+        if (MODE == 1) cs[j] += v;                        // rows >= M hold zeros (their A rows were loaded as zeros)
+      }
+    }
+  }
+  if (MODE == 1 && part) {
+    // column sums over the block's BM rows in a fixed order: lane halves (kk), then the WM waves of a column through LDS
+    float* red = lds;                                     // every wave is past the last barrier of the K loop: the stages are free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs[j] += __shfl_xor(cs[j], 32);
+      if (kk == 0) red[wm * BN + (wn * TN + j) * 32 + r] = cs[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += GEMM_T) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) t += red[w * BN + c];
+      if (col0 + c < N) part[(size_t)tile_m * N + col0 + c] = t;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Version 2 of the same two GEMMs: the K stages go global -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no ds_write
+// pass), NS stages deep in a ring, ONE raw s_barrier per stage and a counted `s_waitcnt vmcnt` so that NS - 2 stages stay in flight across
+// the barrier.  An LDS-DMA wave-instruction fills 1 KiB lane-linearly, so the bank swizzle is applied to the per-lane SOURCE address and
+// again on the read (the same involution on both sides):
+//   k-contiguous operands (A; B of MODE 0): [row][BK] with the 16-byte chunk index XORed by (row >> 2) & 3 (BK 16) / (row >> 1) & 7 (BK 32)
+//   — conflict-free for ds_read_b128's four 16-lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32);
+//   n-contiguous B of MODE 1: [k][128] with the chunk index rotated by 8 for k rows with bit 2 set (the two k halves of a wave's read
+//   then sit 32 banks apart).
+// Rows / columns beyond the matrix are clamped to the last valid one (their results are never stored); K beyond the end reads a
+// 16-byte zero constant; the one chunk that straddles K (K % 4 != 0) is loaded from [K - 4, K) — inside the row — and rotated into place
+// in LDS by its owner before the last stage is used.  Needs K >= 4 and, for MODE 1, N % 4 == 0 (version 1 handles the rest).
+__device__ __attribute__((aligned(16))) float g_gemm_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)l, 16, 0, 0);
+}
+// the same with the address split as SGPR base + 32-bit VGPR byte offset, so that advancing the base per stage is scalar work; M0 (the
+// LDS destination) is written in the statement that reads it and restored (hipcc reserves it).  hipcc does not count an asm load in its
+// own s_waitcnt bookkeeping: the K loop retires them with explicit counted waits and ends on vmcnt(0).
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, const float* l) {
+  const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)l;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+__device__ __forceinline__ void lds_barrier_raw() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int V> struct IC { static constexpr int value = V; };
+
+// The fp32 MFMA moves 34 registers per lane in its 64 cycles (32x32x2: 16 accumulators in, 16 out, one A, one B), so it runs at the VGPR
+// file's pace and every other VALU instruction a co-resident wave issues displaces it: measured, a K stage with ~57 address / bookkeeping
+// VALU instructions per 32 MFMAs ran the matrix pipe at 67 %.  Hence the shape of this loop: per-lane addresses are stage-invariant 32-bit
+// offsets (the stage's advance lives in the SGPR base of `global_load_lds_dwordx4 v_off, s[base]`; LDS fragment addresses are constant
+// VGPRs + immediates because the ring position is a template constant), loop control is scalar, and nothing else touches the VALU.
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
+__global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                                      const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ part,
+                                                      int M, int N, int K, int act, int tiles_n, int dbg) {
+  const long long dbg_c0 = (dbg & 8) ? clock64() : 0, dbg_w0 = (dbg & 8) ? wall_clock64() : 0;
+  static_assert(WM * WN == 4, "four waves");
+  static_assert(BK == 16 || BK == 32, "BK");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static_assert(MODE == 0 || BN == 128, "MODE 1: 128 columns per tile");
+  constexpr int CPR = BK / 4;                              // 16-byte chunks per k-contiguous row
+  constexpr int RPP = 64 / CPR;                            // rows per 1 KiB piece
+  constexpr int A_PIECES = BM / RPP;
+  constexpr int B_PIECES = MODE == 0 ? BN / RPP : BK / 2;  // MODE 1: two k rows of 128 floats per piece
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  constexpr int LPW = (PIECES + 3) / 4;                    // LDS-DMA instructions per wave per stage (pieces wrap: a duplicate writes the same bytes)
+  constexpr int A_STAGE = BM * BK, STAGE = (BM + BN) * BK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // NS * STAGE floats
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it stays off the VALU
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r = lane & 31, kk = lane >> 5;
+  const int nk = (K + BK - 1) / BK;
+  const int ktail0 = (nk - 1) * BK;                        // first k of the last stage
+  const bool tail = (K - ktail0) < BK;                     // the last stage is partial
+
+  // ---- stage-invariant per-lane byte offsets of this wave's pieces (relative to A / B at the stage's first k) ----
+  auto piece_geom = [&](int i, int& prow_or_kr, int& c, bool& kcontig, bool& isA) {
+    const int p = (wave + 4 * i) % PIECES;
+    isA = p < A_PIECES;
+    kcontig = isA || MODE == 0;
+    if (kcontig) {
+      prow_or_kr = (isA ? p : p - A_PIECES) * RPP + lane / CPR;          // row inside the tile
+      const int sw = BK == 16 ? (prow_or_kr >> 2) & 3 : (prow_or_kr >> 1) & 7;
+      c = (lane % CPR) ^ sw;                                             // source chunk that lives in this lane's LDS slot
+    } else {
+      prow_or_kr = 2 * (p - A_PIECES) + (lane >> 5);                     // k row inside the stage
+      c = ((lane & 31) - 8 * ((prow_or_kr >> 2) & 1)) & 31;
+    }
+  };
+  unsigned voff[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    int q, c; bool kc, isA;
+    piece_geom(i, q, c, kc, isA);
+    if (kc) {
+      const int grow = min((isA ? row0 : col0) + q, (isA ? M : N) - 1);
+      voff[i] = ((unsigned)grow * (unsigned)K + 4u * c) * 4u;
+    } else {
+      voff[i] = ((unsigned)q * (unsigned)N + (unsigned)min(col0 + 4 * c, N - 4)) * 4u;
+    }
+  }
+  auto issue = [&](int st, auto slot_c) {                  // stage st -> ring slot
+    constexpr int SLOT = decltype(slot_c)::value;
+    const int k0 = st * BK;
+    if (tail && st == nk - 1) {                            // once per tile: per-lane pointers with the K edge handled
+#pragma unroll
+      for (int i = 0; i < LPW; ++i) {
+        const int p = (wave + 4 * i) % PIECES;
+        int q, c; bool kc, isA;
+        piece_geom(i, q, c, kc, isA);
+        const float* g;
+        if (kc) {
+          const int grow = min((isA ? row0 : col0) + q, (isA ? M : N) - 1);
+          const float* rowbase = (isA ? A : B) + (size_t)grow * K;
+          const int gk = k0 + 4 * c;
+          g = gk + 4 <= K ? rowbase + gk : gk < K ? rowbase + (K - 4) : g_gemm_zeros;
+        } else {
+          g = k0 + q < K ? B + (size_t)(k0 + q) * N + min(col0 + 4 * c, N - 4) : g_gemm_zeros;
+        }
+        glds16(g, &lds[SLOT * STAGE + p * 256]);
+      }
+    } else {
+      const char* sA = reinterpret_cast<const char*>(A + k0);
+      const char* sB = reinterpret_cast<const char*>(MODE == 0 ? B + k0 : B + (size_t)k0 * N);
+#pragma unroll
+      for (int i = 0; i < LPW; ++i) {
+        const int p = (wave + 4 * i) % PIECES;
+        const char* sbase = p < A_PIECES ? sA : sB;         // scalar select
+        glds16_sv(sbase, voff[i], &lds[SLOT * STAGE + p * 256]);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // constant per-lane fragment indices (floats) inside a stage; tile rows start at multiples of 32, so the row swizzle depends on r only
+  const int sw_r = BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7;
+  int fa[BK / 8], fb[MODE == 0 ? BK / 8 : TN];
+#pragma unroll
+  for (int k8 = 0; k8 < BK / 8; ++k8) {
+    fa[k8] = (wm * TM * 32 + r) * BK + 4 * ((2 * k8 + kk) ^ sw_r);
+    if (MODE == 0) fb[k8] = A_STAGE + (wn * TN * 32 + r) * BK + 4 * ((2 * k8 + kk) ^ sw_r);
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = A_STAGE + 4 * kk * BN + (((wn * TN + j) * 32 + r + 32 * kk) & 127);
+  }
+
+  auto stage_body = [&](auto slot_c, int kb) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    // stage kb has landed for this wave once at most the younger stages' DMAs are outstanding ...
+    if (kb + NS - 2 < nk) wait_vmcnt<(NS - 2) * LPW>(); else wait_vmcnt<0>();
+    lds_barrier_raw();                                     // ... and for every wave; every wave is also done reading stage kb - 1
+    if (kb + NS - 1 < nk && !(dbg & 1)) issue(kb + NS - 1, IC<(SLOT + NS - 1) % NS>{});
+    if (tail && kb == nk - 1 && (K & 3)) {                 // rotate the straddling chunk [K-4, K) into [K - K%4, ...) and zero its end
+      const int rem = K & 3, cst = (K - ktail0) >> 2;      // chunk index inside the stage row
+      const int nrows = MODE == 0 ? BM + BN : BM;
+      for (int t = tid; t < nrows; t += GEMM_T) {
+        const int sw = BK == 16 ? (t >> 2) & 3 : (t >> 1) & 7;    // BM is a multiple of 32: B rows (t - BM) swizzle like t
+        f32x4* q = reinterpret_cast<f32x4*>(&lds[SLOT * STAGE + t * BK + 4 * (cst ^ sw)]);
+        const f32x4 o = *q;
+        // (selects, not an if / else-if chain: hipcc 7.2 lowered the three-way chain to a flow whose rem == 3 arm stored unset registers)
+        f32x4 n;
+        n[0] = rem == 1 ? o[3] : rem == 2 ? o[2] : o[1];
+        n[1] = rem == 1 ? 0.0f : rem == 2 ? o[3] : o[2];
+        n[2] = rem == 3 ? o[3] : 0.0f;
+        n[3] = 0.0f;
+        *q = n;
+      }
+      lds_barrier_raw();
+    }
+    // fragments of k block k8 + 1 are read while the MFMAs of block k8 run (two register sets): one exposed LDS latency per stage, not per block
+    f32x4 a[2][TM], b[2][TN];
+    auto read_frags = [&](int k8, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&lds[SLOT * STAGE + i * 32 * BK + fa[k8]]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (MODE == 0) {
+          bf[j] = *reinterpret_cast<const f32x4*>(&lds[SLOT * STAGE + j * 32 * BK + fb[k8]]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = lds[SLOT * STAGE + (k8 * 8 + s) * BN + fb[j]];
+        }
+      }
+    };
+    read_frags(0, a[0], b[0]);
+#pragma unroll
+    for (int k8 = 0; k8 < BK / 8; ++k8) {
+      if (k8 + 1 < BK / 8) read_frags(k8 + 1, a[(k8 + 1) & 1], b[(k8 + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of this block's MFMAs (the scheduler sinks it otherwise)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k8 & 1][i][s], b[k8 & 1][j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (0 < nk) issue(0, IC<0>{});
+  if (NS > 2 && 1 < nk) issue(1, IC<1 % NS>{});
+  if (NS > 3 && 2 < nk) issue(2, IC<2 % NS>{});
+  for (int kb = 0; kb < nk; kb += NS) {
+    stage_body(IC<0>{}, kb);
+    if (kb + 1 < nk) stage_body(IC<1 % NS>{}, kb + 1);
+    if (NS > 2 && kb + 2 < nk) stage_body(IC<2 % NS>{}, kb + 2);
+    if (NS > 3 && kb + 3 < nk) stage_body(IC<3 % NS>{}, kb + 3);
+  }
+
+  // ---- epilogue (C/D map: element e of lane (r, kk) is row 8 (e / 4) + 4 kk + (e % 4), column r) ----
+  if ((dbg & 16) && acc[0][0][0] != 12345.678f) return;
+  float cs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + (wn * TN + j) * 32 + r;
+    const bool cok = col < N;
+    const float bv = (MODE == 0 && bias && cok) ? bias[col] : 0.0f;
+    cs[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rb0 = row0 + (wm * TM + i) * 32 + 4 * kk;
+      if (MODE == 1 && act) {
+        float sv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rb0 + 8 * (e >> 2) + (e & 3);
+          sv[e] = (cok && row < M) ? S[(size_t)row * N + col] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= gemm_act_grad(act, sv[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rb0 + 8 * (e >> 2) + (e & 3);
+        float v = acc[i][j][e];
+        if (MODE == 0) v = gemm_act(act, v + bv);
+        if (cok && row < M) {
+          Cout[(size_t)row * N + col] = v;
+          if (MODE == 1) cs[j] += v;
+        }
+      }
+    }
+  }
+  if ((dbg & 8) && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
+    __builtin_amdgcn_s_waitcnt(0);
+    Cout[0] = (float)(clock64() - dbg_c0);
+    Cout[1] = (float)(wall_clock64() - dbg_w0);
+  }
+  if (MODE == 1 && part) {
+    lds_barrier_raw();                                     // every wave is out of the K loop: the ring is free
+    float* red = lds;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs[j] += __shfl_xor(cs[j], 32);
+      if (kk == 0) red[wm * BN + (wn * TN + j) * 32 + r] = cs[j];
+    }
+    lds_barrier_raw();
+    for (int c = tid; c < BN; c += GEMM_T) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) t += red[w * BN + c];
+      if (col0 + c < N) part[(size_t)tile_m * N + col0 + c] = t;
+    }
+  }
+}
+
+static int g_dbg = 0;
+template <int MODE, int WM, int WN, int TM, int TN, int BK>
+static hipError_t gemm_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+                              hipStream_t st) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int LDS_BYTES = 2 * (BM * (BK + 4) + (MODE == 0 ? BN * (BK + 4) : BK * (BN + 8))) * 4;
+  static bool attr_set = false;                            // more than 64 KB of LDS per workgroup has to be granted once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, WM, WN, TM, TN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm<MODE, WM, WN, TM, TN, BK>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, part, M, N, K, act, tn, g_dbg);
+  return hipGetLastError();
+}
+
+// tile shapes: 0 = 128x128 (2x2 waves of 2x2 tiles), 1 = 96x128 (1x4 waves of 3x1 tiles: 24576 rows = 256 panels, one per CU when N = 128),
+// 2 = 64x128 (1x4 waves of 2x1)
+static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; }
+
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
+static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+                               hipStream_t st) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int LDS_BYTES = NS * (BM + BN) * BK * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, part, M, N, K, act, tn, g_dbg);
+  return hipGetLastError();
+}
+
+#ifndef PBHC_GEMM_BK
+#define PBHC_GEMM_BK 32
+#endif
+static int g_variant = 0;                                  // diagnosis: 0 automatic (version 2 where it applies); 1 force version 1 (register staging); 2 version 2 with BK 16 x 3 stages
+template <int MODE, int WM, int WN, int TM, int TN>
+static hipError_t gemm_variant(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+                               hipStream_t st) {
+  // version 2: 32-bit byte offsets into both operands, K >= 4, whole 16-byte chunks along n for MODE 1
+  const bool v2ok = K >= 4 && (MODE == 0 || (N & 3) == 0) && (size_t)M * K < (1u << 30) && (size_t)(MODE == 0 ? N : K) * (MODE == 0 ? K : N) < (1u << 30);
+  if (g_variant == 1 || !v2ok) return gemm_launch<MODE, WM, WN, TM, TN, PBHC_GEMM_BK>(A, B, bias, S, C, part, M, N, K, act, st);
+  if (g_variant == 2) return gemm2_launch<MODE, WM, WN, TM, TN, 16, 3>(A, B, bias, S, C, part, M, N, K, act, st);
+  return gemm2_launch<MODE, WM, WN, TM, TN, 32, 2>(A, B, bias, S, C, part, M, N, K, act, st);
+}
+template <int MODE>
+static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K,
+                                int act, hipStream_t st) {
+  if (shape == 0) return gemm_variant<MODE, 2, 2, 2, 2>(A, B, bias, S, C, part, M, N, K, act, st);
+  if (shape == 1) return gemm_variant<MODE, 1, 4, 3, 1>(A, B, bias, S, C, part, M, N, K, act, st);
+  return gemm_variant<MODE, 1, 4, 2, 1>(A, B, bias, S, C, part, M, N, K, act, st);
+}
+
+// Tile choice (measured on MI355X at the update's 24 576-row minibatch, tools/gemm_probe.py): 64 x 128 tiles, three workgroups per CU, are the
+// fastest for every N >= 256 (1 536 / 1 024 / 768 / 384 ... tiles fill 768 slots in whole rounds); a 128-column layer has one column tile, and
+// 96-row tiles then put exactly one tile on each of the 256 CUs (24 576 = 256 x 96).
+static int pick_shape(int M, int N, int forced) {
+  if (forced >= 0 && forced <= 2) return forced;
+  if (N <= 128 && M % 96 == 0 && (M / 96) % 256 == 0) return 1;
+  return 2;
+}
+static int g_force_shape = -1;
+
+extern "C" {
+
+void pbhc_gemm_debug_force_shape(int shape) {
+  if (shape < 0) { g_force_shape = -1; g_dbg = 0; g_variant = 0; return; }
+  g_force_shape = (shape & 0xff) == 0xff ? -1 : shape & 0xff;
+  g_dbg = (shape >> 8) & 0xff;
+  g_variant = (shape >> 16) & 0xff;
+}
+
+int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int act, void* stream) {
+  GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && (act == 0 || act == 1 || act == 3));
+  GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0);
+  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape), x, w, bias, nullptr, y, nullptr, M, N, K, act, (hipStream_t)stream));
+  return PBHC_OK;
+}
+
+int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, float* dx, float* scratch, int* num_row_blocks, int M, int N, int K,
+                          int act, void* stream) {
+  GEMM_ARG(dy && w && dx && M >= 1 && N >= 1 && K >= 1 && (act == 0 || act == 1 || act == 3) && (act == 0 || saved) && (!scratch || num_row_blocks));
+  GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)w & 3) == 0);
+  int shape = pick_shape(M, N, g_force_shape);
+  if ((M + tile_bm(shape) - 1) / tile_bm(shape) > PBHC_ACT_MAX_BLOCKS) shape = 0;
+  const int nb = (M + tile_bm(shape) - 1) / tile_bm(shape);
+  GEMM_ARG(!scratch || nb <= PBHC_ACT_MAX_BLOCKS);
+  if (num_row_blocks) *num_row_blocks = nb;
+  // A = dy [M, K] (K = out_features of the layer, the reduction), B = W [K, N] (N = in_features, contiguous)
+  GEMM_HIP(gemm_dispatch<1>(shape, dy, w, nullptr, saved, dx, scratch, M, N, K, act, (hipStream_t)stream));
+  return PBHC_OK;
+}
+
+}  // extern "C"

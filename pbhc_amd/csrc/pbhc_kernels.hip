@@ -565,7 +565,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
 
   // role-A registers that live across phases
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, etr_old = 0.0f;
-  int pf_tid = 0, pf_tpen = 0, pf_tcol = 0, pf_tsrc = -1;
+  int pf_tid = 0, pf_tpen = 0, pf_tsrc = -1, pf_colterm = -1;
   long long adelay = 0;
   // role-B registers that live across phases (loads issued in its prologue, consumed after bar1)
   float pf_last_act = 0.0f, pf_last_qd = 0.0f;
@@ -598,8 +598,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
       const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
-      pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tcol = c.term_sum_col[tl_]; pf_tsrc = c.term_src[tl_];
-      sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));   // a term's own column: shuffle in phase F
+      pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tsrc = c.term_src[tl_];
+      pf_colterm = c.sum_col_term[lane];                     // lane i <-> episode_sums column i: the term that accumulates into it
+      sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));
       pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
       pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE]; pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
       kpA = at(io.kp_scale, eDc + dc); kdA = at(io.kd_scale, eDc + dc);                // phase H (a reset replaces them in registers)
@@ -1083,8 +1084,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       red[R_EXP0 + lane] = expf(-e / pf_sigma);
     }
     WAVE_LDS_FENCE();
-    const float pf_sum = __shfl(sumrow, pf_tcol, PBHC_G);
-    const float pf_termsum = __shfl(sumrow, c.termination_sum_col, PBHC_G);
     if (valid) {
       const float pen_scale = pf_pen_scale;
       float myrew = 0.0f;
@@ -1138,7 +1137,21 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         }
         myrew = raw * pf_tscale;
         if (pf_tpen) myrew = myrew * pen_scale;
-        at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)pf_tcol) = pf_sum + myrew;   // pf_sum: shuffled from the row loaded in the prologue
+      }
+      // episode_sums (legged_robot_base.py:733-747): lane i owns COLUMN i — the row loaded in the prologue + the reward of the term that
+      // accumulates into it (one gather) + the termination reward in its column — and stores the whole row in one coalesced access; a
+      // terminated env stores zeros and hands the finished sums to extras["episode"] (reset_envs_idx :510-514) from the same registers
+      {
+        const float contrib = __shfl(myrew, max(pf_colterm, 0), PBHC_G);
+        const float tr_ = c.has_termination ? (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale : 0.0f;
+        float newsum = sumrow + (pf_colterm >= 0 ? contrib : 0.0f);
+        if (c.has_termination && lane == c.termination_sum_col) newsum = (c.use_vec_reward ? sumrow : newsum) + tr_;
+        if (lane < c.num_sum_cols) {
+          const bool rs = misc[M_RESET] != 0.0f;
+          const u32 so = (u32)env * (u32)c.num_sum_cols + (u32)lane;
+          at(io.episode_sums, so) = rs ? 0.0f : newsum;
+          if (rs && io.episode_rew_out) at(io.episode_rew_out, so) = newsum / c.max_episode_length_s;
+        }
       }
       if (c.use_vec_reward) {
         if (lane < c.num_rew_cols) {
@@ -1147,7 +1160,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
           if (c.has_termination && lane == c.num_terms - 1) {      // column of the last loop term, sic (:743-744)
             float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
             v += tr;
-            at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) = pf_termsum + tr;
           }
           at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane) = v;
           rew_total = v;
@@ -1160,7 +1172,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
           if (c.has_termination) {
             float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
             v += tr;
-            at(io.episode_sums, (u32)env * (u32)c.num_sum_cols + (u32)c.termination_sum_col) += tr;
           }
           io.rew_buf[env] = v;
         }
@@ -1179,7 +1190,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)adelay; }
     if (do_reset) {
       LOAD_CLIP_META();
-      __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0) expcnt(0) lgkmcnt(0): the wave's episode_sums stores of phase F have landed
       for (int dd = lane; dd < D; dd += PBHC_G) {
         act[dd] = 0.0f; actd[dd] = 0.0f;
         float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
@@ -1196,11 +1206,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
           at(io.rao_scale, eD + dd) = io.ovr_rao ? at(io.ovr_rao, eD + dd) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
         if (c.randomize_ctrl_delay)
           for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
-      }
-      const u32 sbase = (u32)env * (u32)c.num_sum_cols;
-      for (int i = lane; i < c.num_sum_cols; i += PBHC_G) {
-        if (io.episode_rew_out) at(io.episode_rew_out, sbase + (u32)i) = at(io.episode_sums, sbase + (u32)i) / c.max_episode_length_s;
-        at(io.episode_sums, sbase + (u32)i) = 0.0f;
       }
       if (lane == 0) {
         misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
@@ -1965,6 +1970,12 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   if (!e) return PBHC_ENOMEM;
   e->cfg = *cfg;
   for (int i = 0; i < PBHC_MAX_TERMS; ++i) e->cfg.term_src[i] = i < cfg->num_terms ? term_source(cfg->term_id[i]) : -1;
+  ARG_CHECK(cfg->num_sum_cols >= 1 && cfg->num_sum_cols <= 32);
+  for (int i = 0; i < 32; ++i) e->cfg.sum_col_term[i] = -1;
+  for (int i = 0; i < cfg->num_terms; ++i) {
+    ARG_CHECK(cfg->term_sum_col[i] >= 0 && cfg->term_sum_col[i] < cfg->num_sum_cols && e->cfg.sum_col_term[cfg->term_sum_col[i]] == -1);
+    e->cfg.sum_col_term[cfg->term_sum_col[i]] = i;
+  }
   e->tbl = *tbl;
   e->d_glob = globals;
   e->nblocks = (cfg->num_envs + PBHC_EPB - 1) / PBHC_EPB;
