@@ -444,13 +444,15 @@ int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int
 int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
 
 /* One Linear of a training-time Linear / activation stack on the fp32 matrix cores with its activation folded into the GEMM epilogue
- * (agents/modules/modules.py:47-63: `nn.Linear` followed by `nn.ELU` / `nn.ReLU`; replaces torch.addmm + F.elu_):
- *   y[M,N] = act(x[M,K] . w[N,K]^T + bias[N])        act: 0 none, 1 ELU (alpha 1), 3 ReLU;  bias may be NULL
+ * (agents/modules/modules.py:47-63: `nn.Linear` followed by `nn.ELU` / `nn.SiLU` / `nn.ReLU`; replaces torch.addmm + the activation pass):
+ *   y[M,N] = act(x[M,K] . w[N,K]^T + bias[N])        act: 0 none, 1 ELU (alpha 1), 2 SiLU, 3 ReLU;  bias may be NULL
+ *   pre[M,N] (may be NULL) = x . w^T + bias            the pre-activation, which SiLU's derivative needs
  * x, w row-major, contiguous (rows need 4-byte alignment only).  f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
-int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int act, void* stream);
-/* The input gradient of that Linear with the activation backward of the layer BELOW folded in (what autograd runs as mm + elu_backward +
- * a column sum; replaces `dy @ w` + pbhc_act_bwd_partials):
+int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream);
+/* The input gradient of that Linear with the activation backward of the layer BELOW folded in (what autograd runs as mm + elu_backward /
+ * silu_backward + a column sum; replaces `dy @ w` + pbhc_act_bwd_partials):
  *   dx[M,N] = (dy[M,K] . w[K,N]) * act'(saved[M,N])   N = in_features, K = out_features; saved = the lower layer's activation OUTPUT
+ *                                                     (ELU, ReLU) or PRE-activation (SiLU)
  *   scratch[b, :] = column sums of dx over row block b (*num_row_blocks of them, <= PBHC_ACT_MAX_BLOCKS; finish with pbhc_colsum_final)
  * scratch may be NULL (no column sums); act 0: saved unused. */
 int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, float* dx, float* scratch, int* num_row_blocks, int M, int N, int K,

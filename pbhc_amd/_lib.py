@@ -123,7 +123,7 @@ def _load():
     lib.pbhc_act_bwd_bias.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
     lib.pbhc_act_bwd_partials.argtypes = [vp, vp, i, i, i, vp, vp, C.POINTER(C.c_int), vp]
     lib.pbhc_colsum_final.argtypes = [vp, i, vp]
-    lib.pbhc_linear_act_fwd.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
+    lib.pbhc_linear_act_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
     lib.pbhc_linear_dgrad_act.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int), i, i, i, i, vp]
     lib.pbhc_gemm_debug_force_shape.argtypes = [i]
     lib.pbhc_gemm_debug_force_shape.restype = None

@@ -4,7 +4,7 @@ MI355X:
 * hidden layers run on the fp32 matrix cores in `pbhc_linear_act_fwd` — bias + ELU / ReLU applied to the accumulators, no separate
   activation pass — and their input gradients in `pbhc_linear_dgrad_act`, which folds in the activation derivative of the layer below and
   the row-block column sums of its bias gradient (csrc/pbhc_gemm.hip: LDS-DMA staged, `v_mfma_f32_32x32x2_f32`).  `PBHC_FUSED_GEMM=0`
-  returns to library GEMMs (hipBLASLt / rocBLAS through torch) + the `pbhc_act_bwd_bias` pass; SiLU stacks always take that path;
+  returns to library GEMMs (hipBLASLt / rocBLAS through torch) + the `pbhc_act_bwd_bias` pass;
 * weight gradients and the narrow output layer stay library GEMMs (split-K batched form below);
 * weight / bias gradients are written by the GEMM (`out=`) and the fused kernel straight into the parameter's `.grad` — a view of
   the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear.  That store
@@ -76,7 +76,7 @@ class _FusedMLP(torch.autograd.Function):
         act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
         saved_in, saved_act = [], []
         h = x if x.is_contiguous() else x.contiguous()
-        fused = FUSED_GEMM and act in (1, 3) and h.is_cuda and h.dtype == torch.float32
+        fused = FUSED_GEMM and act in (1, 2, 3) and h.is_cuda and h.dtype == torch.float32
         if fused:
             lib, st = _lib.lib(), _lib.current_stream()
         for i, l in enumerate(lin):
@@ -84,10 +84,11 @@ class _FusedMLP(torch.autograd.Function):
             if fused and i < len(lin) - 1 and l.weight.is_contiguous():
                 B = h.shape[0]
                 z = torch.empty(B, l.out_features, device=h.device)
+                pre = torch.empty_like(z) if act == 2 else None          # SiLU' needs the pre-activation; ELU' / ReLU' come from the output
                 _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(),
-                                                   B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
+                                                   pre.data_ptr() if pre is not None else None, B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
                 h = z
-                saved_act.append(h)
+                saved_act.append(pre if pre is not None else h)
                 continue
             z = torch.addmm(l.bias, h, l.weight.t())
             if i == len(lin) - 1:

@@ -27,11 +27,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float gemm_act(int act, float v) {
   if (act == 1) return v > 0.0f ? v : expf(v) - 1.0f;       // ATen's GPU ELU: exp(x) - 1 in f32 (ActivationEluKernel.cu)
+  if (act == 2) return v / (1.0f + expf(-v));             // SiLU as ATen computes it: x / (1 + exp(-x))
   if (act == 3) return v > 0.0f ? v : 0.0f;
   return v;
 }
-__device__ __forceinline__ float gemm_act_grad(int act, float s) {      // from the activation OUTPUT (ELU alpha 1, ReLU)
+__device__ __forceinline__ float gemm_act_grad(int act, float s) {      // ELU (alpha 1), ReLU: from the activation OUTPUT; SiLU: from the PRE-activation
   if (act == 1) return s > 0.0f ? 1.0f : s + 1.0f;
+  if (act == 2) { const float sg = 1.0f / (1.0f + expf(-s)); return sg * (1.0f + s * (1.0f - sg)); }
   if (act == 3) return s > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
 }
@@ -58,7 +60,7 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, bool rowok, 
 // per four steps (any k permutation common to A and B leaves the product unchanged; the fmaf order is fixed, hence deterministic).
 template <int MODE, int WM, int WN, int TM, int TN, int BK>
 __global__ __launch_bounds__(GEMM_T, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-                                                     const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ part,
+                                                     const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ Pre, float* __restrict__ part,
                                                      int M, int N, int K, int act, int tiles_n, int dbg) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -193,7 +195,11 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm(const float* __restrict__ A,
       for (int e = 0; e < 16; ++e) {
         const int row = rb0 + 8 * (e >> 2) + (e & 3);
         float v = acc[i][j][e];
-        if (MODE == 0) v = gemm_act(act, v + bv);
+        if (MODE == 0) {
+          v += bv;
+          if (Pre && cok && row < M) Pre[(size_t)row * N + col] = v;
+          v = gemm_act(act, v);
+        }
         if (cok && row < M) Cout[(size_t)row * N + col] = v;
         if (MODE == 1) cs[j] += v;                        // rows >= M hold zeros (their A rows were loaded as zeros)
       }
@@ -263,7 +269,7 @@ template <int V> struct IC { static constexpr int value = V; };
 // VGPRs + immediates because the ring position is a template constant), loop control is scalar, and nothing else touches the VALU.
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-                                                      const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ part,
+                                                      const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ Pre, float* __restrict__ part,
                                                       int M, int N, int K, int act, int tiles_n, int dbg) {
   const long long dbg_c0 = (dbg & 8) ? clock64() : 0, dbg_w0 = (dbg & 8) ? wall_clock64() : 0;
   static_assert(WM * WN == 4, "four waves");
@@ -460,7 +466,11 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
       for (int e = 0; e < 16; ++e) {
         const int row = rb0 + 8 * (e >> 2) + (e & 3);
         float v = acc[i][j][e];
-        if (MODE == 0) v = gemm_act(act, v + bv);
+        if (MODE == 0) {
+          v += bv;
+          if (Pre && cok && row < M) Pre[(size_t)row * N + col] = v;
+          v = gemm_act(act, v);
+        }
         if (cok && row < M) {
           Cout[(size_t)row * N + col] = v;
           if (MODE == 1) cs[j] += v;
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
 
 static int g_dbg = 0;
 template <int MODE, int WM, int WN, int TM, int TN, int BK>
-static hipError_t gemm_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+static hipError_t gemm_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
                               hipStream_t st) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int LDS_BYTES = 2 * (BM * (BK + 4) + (MODE == 0 ? BN * (BK + 4) : BK * (BN + 8))) * 4;
@@ -504,7 +514,7 @@ static hipError_t gemm_launch(const float* A, const float* B, const float* bias,
     attr_set = true;
   }
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_gemm<MODE, WM, WN, TM, TN, BK>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, part, M, N, K, act, tn, g_dbg);
+  hipLaunchKernelGGL((k_gemm<MODE, WM, WN, TM, TN, BK>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, pre, part, M, N, K, act, tn, g_dbg);
   return hipGetLastError();
 }
 
@@ -513,7 +523,7 @@ static hipError_t gemm_launch(const float* A, const float* B, const float* bias,
 static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; }
 
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
-static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
                                hipStream_t st) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int LDS_BYTES = NS * (BM + BN) * BK * 4;
@@ -524,7 +534,7 @@ static hipError_t gemm2_launch(const float* A, const float* B, const float* bias
     attr_set = true;
   }
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, part, M, N, K, act, tn, g_dbg);
+  hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, pre, part, M, N, K, act, tn, g_dbg);
   return hipGetLastError();
 }
 
@@ -533,20 +543,20 @@ static hipError_t gemm2_launch(const float* A, const float* B, const float* bias
 #endif
 static int g_variant = 0;                                  // diagnosis: 0 automatic (version 2 where it applies); 1 force version 1 (register staging); 2 version 2 with BK 16 x 3 stages
 template <int MODE, int WM, int WN, int TM, int TN>
-static hipError_t gemm_variant(const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K, int act,
+static hipError_t gemm_variant(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
                                hipStream_t st) {
   // version 2: 32-bit byte offsets into both operands, K >= 4, whole 16-byte chunks along n for MODE 1
   const bool v2ok = K >= 4 && (MODE == 0 || (N & 3) == 0) && (size_t)M * K < (1u << 30) && (size_t)(MODE == 0 ? N : K) * (MODE == 0 ? K : N) < (1u << 30);
-  if (g_variant == 1 || !v2ok) return gemm_launch<MODE, WM, WN, TM, TN, PBHC_GEMM_BK>(A, B, bias, S, C, part, M, N, K, act, st);
-  if (g_variant == 2) return gemm2_launch<MODE, WM, WN, TM, TN, 16, 3>(A, B, bias, S, C, part, M, N, K, act, st);
-  return gemm2_launch<MODE, WM, WN, TM, TN, 32, 2>(A, B, bias, S, C, part, M, N, K, act, st);
+  if (g_variant == 1 || !v2ok) return gemm_launch<MODE, WM, WN, TM, TN, PBHC_GEMM_BK>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  if (g_variant == 2) return gemm2_launch<MODE, WM, WN, TM, TN, 16, 3>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  return gemm2_launch<MODE, WM, WN, TM, TN, 32, 2>(A, B, bias, S, C, pre, part, M, N, K, act, st);
 }
 template <int MODE>
-static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const float* bias, const float* S, float* C, float* part, int M, int N, int K,
+static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K,
                                 int act, hipStream_t st) {
-  if (shape == 0) return gemm_variant<MODE, 2, 2, 2, 2>(A, B, bias, S, C, part, M, N, K, act, st);
-  if (shape == 1) return gemm_variant<MODE, 1, 4, 3, 1>(A, B, bias, S, C, part, M, N, K, act, st);
-  return gemm_variant<MODE, 1, 4, 2, 1>(A, B, bias, S, C, part, M, N, K, act, st);
+  if (shape == 0) return gemm_variant<MODE, 2, 2, 2, 2>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  if (shape == 1) return gemm_variant<MODE, 1, 4, 3, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  return gemm_variant<MODE, 1, 4, 2, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
 }
 
 // Tile choice (measured on MI355X at the update's 24 576-row minibatch, tools/gemm_probe.py): 64 x 128 tiles, three workgroups per CU, are the
@@ -568,16 +578,16 @@ void pbhc_gemm_debug_force_shape(int shape) {
   g_variant = (shape >> 16) & 0xff;
 }
 
-int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int act, void* stream) {
-  GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && (act == 0 || act == 1 || act == 3));
+int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream) {
+  GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3);
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0);
-  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape), x, w, bias, nullptr, y, nullptr, M, N, K, act, (hipStream_t)stream));
+  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
   return PBHC_OK;
 }
 
 int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, float* dx, float* scratch, int* num_row_blocks, int M, int N, int K,
                           int act, void* stream) {
-  GEMM_ARG(dy && w && dx && M >= 1 && N >= 1 && K >= 1 && (act == 0 || act == 1 || act == 3) && (act == 0 || saved) && (!scratch || num_row_blocks));
+  GEMM_ARG(dy && w && dx && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3 && (act == 0 || saved) && (!scratch || num_row_blocks));
   GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)w & 3) == 0);
   int shape = pick_shape(M, N, g_force_shape);
   if ((M + tile_bm(shape) - 1) / tile_bm(shape) > PBHC_ACT_MAX_BLOCKS) shape = 0;
@@ -585,7 +595,7 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
   GEMM_ARG(!scratch || nb <= PBHC_ACT_MAX_BLOCKS);
   if (num_row_blocks) *num_row_blocks = nb;
   // A = dy [M, K] (K = out_features of the layer, the reduction), B = W [K, N] (N = in_features, contiguous)
-  GEMM_HIP(gemm_dispatch<1>(shape, dy, w, nullptr, saved, dx, scratch, M, N, K, act, (hipStream_t)stream));
+  GEMM_HIP(gemm_dispatch<1>(shape, dy, w, nullptr, saved, dx, nullptr, scratch, M, N, K, act, (hipStream_t)stream));
   return PBHC_OK;
 }
 

@@ -1,0 +1,119 @@
+"""Fused fp32-MFMA Linear kernels (`pbhc_linear_act_fwd`, `pbhc_linear_dgrad_act`, csrc/pbhc_gemm.hip) through the C ABI against an fp64
+PyTorch reference of the same op (agents/modules/modules.py:47-63: nn.Linear + ELU / SiLU / ReLU and its autograd backward).
+
+Tolerance: the kernels are f32-in / f32-accumulate k-ordered fmaf chains; against fp64 the error of an O(1) output at K <= 1024 is a few
+1e-6 (same as the library GEMM they replace) — the tests allow 3e-5 absolute on outputs of magnitude O(1)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-5
+
+
+def _act_ref(act, z):
+    return {0: z, 1: F.elu(z), 2: F.silu(z), 3: F.relu(z)}[act]
+
+
+def _act_grad_ref(act, z):
+    z = z.detach().clone().requires_grad_(True)
+    _act_ref(act, z).sum().backward()
+    return z.grad
+
+
+# (M, N, K): whole tiles; ragged rows / columns; K with every remainder mod 4 and below one stage; the update's and the rollout's shapes
+FWD_SHAPES = [(256, 128, 64), (200, 130, 37), (96, 128, 23), (97, 23, 630), (1, 1, 5), (130, 257, 3), (64, 128, 1), (4096, 512, 380), (24576, 128, 256)]
+
+
+@pytest.mark.parametrize("shape", FWD_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_linear_act_fwd_matches_fp64(shape, act):
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(1000 * act + M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    for forced in (-1, 0, 1, 2, 0x10000 | 0xff, 0x20000 | 2):          # automatic; each tile shape; register-staged version; BK 16 x 3 stages
+        lib.pbhc_gemm_debug_force_shape(forced if forced >= 0 else -1)
+        y = torch.full((M, N), float("nan"), device="cuda")
+        pre = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), pre.data_ptr(), M, N, K, act, _lib.current_stream()), "fwd")
+        z = x.double() @ w.double().t() + b.double()
+        assert (pre.double() - z).abs().max().item() < TOL, forced
+        assert (y.double() - _act_ref(act, z)).abs().max().item() < TOL, forced
+    lib.pbhc_gemm_debug_force_shape(-1)
+    # no bias, no pre-activation output
+    y = torch.empty(M, N, device="cuda")
+    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, M, N, K, act, _lib.current_stream()), "fwd")
+    assert (y.double() - _act_ref(act, x.double() @ w.double().t())).abs().max().item() < TOL
+
+
+# (M, N = in_features, K = out_features)
+DGRAD_SHAPES = [(256, 128, 64), (200, 132, 37), (96, 128, 23), (97, 128, 1), (130, 256, 3), (77, 130, 40), (4096, 256, 128), (24576, 128, 23)]
+
+
+@pytest.mark.parametrize("shape", DGRAD_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_linear_dgrad_act_matches_fp64(shape, act):
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(7000 * act + M + N + K)
+    dy = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+    zpre = torch.randn(M, N, device="cuda", generator=g)
+    saved = zpre if act == 2 else _act_ref(act, zpre)                     # SiLU: pre-activation; ELU / ReLU: the activation output
+    ref = (dy.double() @ w.double()) * (_act_grad_ref(act, zpre.double()) if act else 1.0)
+    MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
+    for forced in (-1, 0, 1, 2, 0x10000 | 0xff, 0x20000 | 2):
+        lib.pbhc_gemm_debug_force_shape(forced if forced >= 0 else -1)
+        dx = torch.full((M, N), float("nan"), device="cuda")
+        part = torch.full((MAXB * N,), float("nan"), device="cuda")
+        nb = C.c_int(0)
+        _lib.check(lib.pbhc_linear_dgrad_act(dy.data_ptr(), w.data_ptr(), saved.data_ptr() if act else None, dx.data_ptr(), part.data_ptr(), C.byref(nb),
+                                             M, N, K, act, _lib.current_stream()), "dgrad")
+        assert (dx.double() - ref).abs().max().item() < TOL, forced
+        cs = part[:nb.value * N].view(nb.value, N).double().sum(0)
+        assert 1 <= nb.value <= MAXB and (cs - ref.sum(0)).abs().max().item() < TOL * max(1.0, M ** 0.5), forced
+    lib.pbhc_gemm_debug_force_shape(-1)
+    dx = torch.empty(M, N, device="cuda")                                  # no column sums requested
+    _lib.check(lib.pbhc_linear_dgrad_act(dy.data_ptr(), w.data_ptr(), saved.data_ptr() if act else None, dx.data_ptr(), None, None, M, N, K, act,
+                                         _lib.current_stream()), "dgrad")
+    assert (dx.double() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("act_cls", [nn.ELU, nn.SiLU, nn.ReLU])
+def test_fused_mlp_with_and_without_the_fused_gemms(act_cls, monkeypatch):
+    """fused_mlp.forward (training path of BaseModule): outputs, input gradient and every parameter gradient agree between the MFMA kernels,
+    the library-GEMM path they replace and plain autograd over the nn.Sequential."""
+    from pbhc_amd.agents import fused_mlp
+
+    torch.manual_seed(3)
+    seq = nn.Sequential(nn.Linear(77, 96), act_cls(), nn.Linear(96, 64), act_cls(), nn.Linear(64, 128), act_cls(), nn.Linear(128, 5)).cuda()
+    x = torch.randn(300, 77, device="cuda", requires_grad=True)
+    dout = torch.randn(300, 5, device="cuda")
+
+    def run(fn):
+        for p in seq.parameters():
+            p.grad = None
+        x.grad = None
+        y = fn(x)
+        y.backward(dout)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in seq.parameters()]
+
+    ref = run(seq)
+    monkeypatch.setattr(fused_mlp, "FUSED_GEMM", True)
+    new = run(lambda t: fused_mlp.forward(seq, t))
+    monkeypatch.setattr(fused_mlp, "FUSED_GEMM", False)
+    old = run(lambda t: fused_mlp.forward(seq, t))
+    for a, b, c in zip(ref, new, old):
+        scale = max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() < 2e-5 * scale and (a - c).abs().max().item() < 2e-5 * scale

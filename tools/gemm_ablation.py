@@ -9,7 +9,7 @@ from pbhc_amd import _lib   # noqa: E402
 
 lib = _lib.lib()
 M = 24576
-VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 
 
 def timeit(fn, n=40, warm=20):
@@ -31,13 +31,13 @@ for N, K in [(512, 768), (768, 630), (128, 512)]:
     b = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda")
     st = _lib.current_stream()
-    for shape in (0, 1):
-        for dbg, name in [(0, "full"), (1, "no LDS-DMA in the loop")]:
+    for shape in (2, 1):
+        for dbg, name in [(0, "full"), (1, "no LDS-DMA in the loop"), (16, "no epilogue"), (17, "no DMA, no epilogue")]:
             lib.pbhc_gemm_debug_force_shape(shape | (dbg << 8) | (VARIANT << 16))
-            t = timeit(lambda: lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 1, st))
-            lib.pbhc_gemm_debug_force_shape(shape | ((dbg | 8 | 32) << 8) | (VARIANT << 16))
-            lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 1, st)
+            t = timeit(lambda: lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st))
+            lib.pbhc_gemm_debug_force_shape(shape | ((dbg | 8) << 8) | (VARIANT << 16))
+            lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st)
             torch.cuda.synchronize()
             cw = y.view(-1)[:6].tolist()
-            print(f"{N}x{K} shape {shape} {name:32s} {t:7.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF/s-equivalent   one tile: {cw[1] / 100:.1f} us at {cw[0] / max(cw[1], 1) * 100:.0f} MHz; cycles: total {cw[0]:.0f} vmcnt-wait {cw[2]:.0f} barrier {cw[3]:.0f} DMA issue {cw[4]:.0f} compute {cw[5]:.0f}")
+            print(f"{N}x{K} shape {shape} {name:32s} {t:7.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF/s-equivalent   one tile: {cw[1] / 100:.1f} us at {cw[0] / max(cw[1], 1) * 100:.0f} MHz")
 lib.pbhc_gemm_debug_force_shape(-1)

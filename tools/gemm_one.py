@@ -18,5 +18,5 @@ y = torch.empty(M, N, device="cuda")
 st = _lib.current_stream()
 lib.pbhc_gemm_debug_force_shape((shape & 0xff) | (variant << 16))
 for _ in range(30):
-    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 1, st), "fwd")
+    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st), "fwd")
 torch.cuda.synchronize()

@@ -53,7 +53,7 @@ def main():
             st = _lib.current_stream()
 
             def new():
-                _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, 1, st), "fwd")
+                _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st), "fwd")
 
             def old():
                 return F.elu_(torch.addmm(b, x, w.t()))

@@ -24,5 +24,5 @@ for K in (23, 22, 21, 24, 20, 36, 39):
 for K in (23, 630, 37):
     lib.pbhc_gemm_debug_force_shape(2 | (2 << 16))
     x = torch.randn(M, K, device="cuda"); w = torch.randn(128, K, device="cuda"); y = torch.empty(M, 128, device="cuda")
-    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), M, 128, K, 0, _lib.current_stream()), "f")
+    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, M, 128, K, 0, _lib.current_stream()), "f")
     print("fwd K", K, "err", (y.double() - x.double() @ w.double().t()).abs().max().item())
