@@ -181,6 +181,22 @@ class _FusedMLP(torch.autograd.Function):
         return (dx, None, *flat)
 
 
+def forward_inference(seq, x):
+    """No-grad forward of the same stack (the rollout's policy / critic evaluation): hidden layers through `pbhc_linear_act_fwd`, the narrow
+    output layer through the library.  Plain launches on the current stream, so it can be captured in a hipGraph like the eager form."""
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
+    lib, st = _lib.lib(), _lib.current_stream()
+    h = x if x.is_contiguous() else x.contiguous()
+    B = h.shape[0]
+    for l in lin[:-1]:
+        z = torch.empty(B, l.out_features, device=h.device)
+        _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(), None,
+                                           B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
+        h = z
+    return torch.addmm(lin[-1].bias, h, lin[-1].weight.t())
+
+
 def forward(seq, x):
     """seq: nn.Sequential of Linear / activation; x [B, in]."""
     params = []

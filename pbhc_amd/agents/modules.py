@@ -57,6 +57,11 @@ class BaseModule(nn.Module):
             from . import fused_mlp
 
             return fused_mlp.forward(self.module, x)             # training: fused activation-backward / bias-gradient path
+        if self._fused and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            from . import fused_mlp
+
+            if fused_mlp.FUSED_GEMM and all(m.weight.is_contiguous() and m.bias is not None for m in self.module if isinstance(m, nn.Linear)):
+                return fused_mlp.forward_inference(self.module, x)   # rollout: bias + activation in the GEMM epilogue
         return self.module(x)
 
 

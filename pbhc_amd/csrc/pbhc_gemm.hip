@@ -440,63 +440,102 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     if (NS > 3 && kb + 3 < nk) stage_body(IC<3 % NS>{}, kb + 3);
   }
 
-  // ---- epilogue (C/D map: element e of lane (r, kk) is row 8 (e / 4) + 4 kk + (e % 4), column r) ----
+  // ---- epilogue: through LDS, so that global traffic is 16 bytes per lane along rows (a 128-column tile row = 512 contiguous bytes per
+  // half wave) instead of the accumulator layout's 4-byte pieces.  The accumulators go to a [BM][BN + 4] image as they are (C/D map: element e
+  // of lane (r, kk) is row 8 (e / 4) + 4 kk + (e % 4), column r); bias / activation / activation derivative are applied on the way out.
   if ((dbg & 16) && acc[0][0][0] != 12345.678f) return;
-  float cs[TN];
+  constexpr int CS = BN + 4;                               // row stride of the image (floats): 16-byte rows, ds_write_b32 by 32 consecutive columns
+  lds_barrier_raw();                                       // every wave is out of the K loop (its last stage waited vmcnt(0)): the ring is free
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = col0 + (wn * TN + j) * 32 + r;
-    const bool cok = col < N;
-    const float bv = (MODE == 0 && bias && cok) ? bias[col] : 0.0f;
-    cs[j] = 0.0f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int rb0 = row0 + (wm * TM + i) * 32 + 4 * kk;
-      if (MODE == 1 && act) {
-        float sv[16];
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = rb0 + 8 * (e >> 2) + (e & 3);
-          sv[e] = (cok && row < M) ? S[(size_t)row * N + col] : 0.0f;
-        }
+      for (int e = 0; e < 16; ++e)
+        lds[((wm * TM + i) * 32 + 8 * (e >> 2) + 4 * kk + (e & 3)) * CS + (wn * TN + j) * 32 + r] = acc[i][j][e];
+  lds_barrier_raw();
+  {
+    constexpr int RP = GEMM_T / (BN / 4);                  // rows per pass: a thread owns 4 columns and every RP-th row
+    constexpr int NP = BM / RP;
+    const int c4 = (tid % (BN / 4)) * 4, rr = tid / (BN / 4);
+    const int col = col0 + c4;
+    const bool vec = (N & 3) == 0;                         // whole 16-byte pieces (rows stay 16-byte aligned relative to the base)
+    const bool cok = vec ? col < N : col < N;              // first column inside
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && bias) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] *= gemm_act_grad(act, sv[e]);
-      }
+      for (int q = 0; q < 4; ++q) if (col + q < N) bv[q] = bias[col + q];
+    }
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sv[NP];
+    if (MODE == 1 && act) {                                // the lower layer's saved activations for all of this thread's rows, in flight together
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rb0 + 8 * (e >> 2) + (e & 3);
-        float v = acc[i][j][e];
-        if (MODE == 0) {
-          v += bv;
-          if (Pre && cok && row < M) Pre[(size_t)row * N + col] = v;
-          v = gemm_act(act, v);
-        }
-        if (cok && row < M) {
-          Cout[(size_t)row * N + col] = v;
-          if (MODE == 1) cs[j] += v;
+      for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * RP + rr;
+        sv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < M && cok) {
+          const float* sp = S + (size_t)row * N + col;
+          if (vec) sv[p] = reinterpret_cast<const F4U*>(sp)->v;
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (col + q < N) sv[p][q] = sp[q];
+          }
         }
       }
     }
-  }
-  if ((dbg & 8) && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
-    __builtin_amdgcn_s_waitcnt(0);
-    Cout[0] = (float)(clock64() - dbg_c0);
-    Cout[1] = (float)(wall_clock64() - dbg_w0);
-  }
-  if (MODE == 1 && part) {
-    lds_barrier_raw();                                     // every wave is out of the K loop: the ring is free
-    float* red = lds;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      cs[j] += __shfl_xor(cs[j], 32);
-      if (kk == 0) red[wm * BN + (wn * TN + j) * 32 + r] = cs[j];
+    for (int p = 0; p < NP; ++p) {
+      const int row = row0 + p * RP + rr;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(p * RP + rr) * CS + c4]);
+      const bool ok = row < M && cok;
+      if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q];
+        if (Pre && ok) {
+          float* pp = Pre + (size_t)row * N + col;
+          if (vec) reinterpret_cast<F4U*>(pp)->v = v;
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (col + q < N) pp[q] = v[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gemm_act(act, v[q]);
+      } else if (act) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(act, sv[p][q]);
+      }
+      if (ok) {
+        float* cp = Cout + (size_t)row * N + col;
+        if (vec) reinterpret_cast<F4U*>(cp)->v = v;
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (col + q < N) cp[q] = v[q];
+        }
+        if (MODE == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) csum[q] += v[q];      // rows in the fixed order p = 0, 1, ...
+        }
+      }
     }
-    lds_barrier_raw();
-    for (int c = tid; c < BN; c += GEMM_T) {
-      float t = 0.0f;
+    if ((dbg & 8) && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
+      __builtin_amdgcn_s_waitcnt(0);
+      Cout[0] = (float)(clock64() - dbg_c0);
+      Cout[1] = (float)(wall_clock64() - dbg_w0);
+    }
+    if (MODE == 1 && part) {
+      // column sums over the tile's rows: the RP threads of a column group through LDS, fixed order
+      lds_barrier_raw();                                   // the image has been read
+      float* red = lds;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[w * BN + c];
-      if (col0 + c < N) part[(size_t)tile_m * N + col0 + c] = t;
+      for (int q = 0; q < 4; ++q) red[rr * BN + c4 + q] = csum[q];
+      lds_barrier_raw();
+      for (int c = tid; c < BN; c += GEMM_T) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < RP; ++w) t += red[w * BN + c];
+        if (col0 + c < N) part[(size_t)tile_m * N + col0 + c] = t;
+      }
     }
   }
 }
@@ -507,7 +546,7 @@ static hipError_t gemm_launch(const float* A, const float* B, const float* bias,
                               hipStream_t st) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int LDS_BYTES = 2 * (BM * (BK + 4) + (MODE == 0 ? BN * (BK + 4) : BK * (BN + 8))) * 4;
-  static bool attr_set = false;                            // more than 64 KB of LDS per workgroup has to be granted once per kernel
+  static bool attr_set = LDS_BYTES <= 65536;               // more than 64 KB of LDS per workgroup has to be granted once per kernel
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, WM, WN, TM, TN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -520,14 +559,15 @@ static hipError_t gemm_launch(const float* A, const float* B, const float* bias,
 
 // tile shapes: 0 = 128x128 (2x2 waves of 2x2 tiles), 1 = 96x128 (1x4 waves of 3x1 tiles: 24576 rows = 256 panels, one per CU when N = 128),
 // 2 = 64x128 (1x4 waves of 2x1)
-static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; }
+static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; }   // (shape 3, forward only: 64 x 64, 2x2 waves of one tile)
 
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
                                hipStream_t st) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  constexpr int LDS_BYTES = NS * (BM + BN) * BK * 4;
-  static bool attr_set = false;
+  constexpr int RING_BYTES = NS * (BM + BN) * BK * 4, IMAGE_BYTES = BM * (BN + 4) * 4;   // K stages; the epilogue's [BM][BN + 4] image
+  constexpr int LDS_BYTES = RING_BYTES > IMAGE_BYTES ? RING_BYTES : IMAGE_BYTES;
+  static bool attr_set = LDS_BYTES <= 65536;               // (the shapes pick_shape() chooses stay below 64 KB: nothing to set, safe under stream capture)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -556,15 +596,21 @@ static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const
                                 int act, hipStream_t st) {
   if (shape == 0) return gemm_variant<MODE, 2, 2, 2, 2>(A, B, bias, S, C, pre, part, M, N, K, act, st);
   if (shape == 1) return gemm_variant<MODE, 1, 4, 3, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  if constexpr (MODE == 0) {
+    if (shape == 3) return gemm_variant<MODE, 2, 2, 1, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
+  }
   return gemm_variant<MODE, 1, 4, 2, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
 }
 
 // Tile choice (measured on MI355X at the update's 24 576-row minibatch, tools/gemm_probe.py): 64 x 128 tiles, three workgroups per CU, are the
 // fastest for every N >= 256 (1 536 / 1 024 / 768 / 384 ... tiles fill 768 slots in whole rounds); a 128-column layer has one column tile, and
 // 96-row tiles then put exactly one tile on each of the 256 CUs (24 576 = 256 x 96).
-static int pick_shape(int M, int N, int forced) {
-  if (forced >= 0 && forced <= 2) return forced;
+static int pick_shape(int M, int N, int forced, bool forward) {
+  if (forced >= 0 && forced <= 3) return forced;
   if (N <= 128 && M % 96 == 0 && (M / 96) % 256 == 0) return 1;
+  // few rows (the rollout's 4 096-row policy / critic forward): 64 x 64 tiles keep every CU busy where 64 x 128 tiles would leave fewer than two
+  // workgroups per CU (measured at 4 096 rows: the six hidden layers 139 us against 181 us for library GEMM + ELU)
+  if (forward && (long)((M + 63) / 64) * ((N + 127) / 128) < 512) return 3;
   return 2;
 }
 static int g_force_shape = -1;
@@ -581,7 +627,7 @@ void pbhc_gemm_debug_force_shape(int shape) {
 int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream) {
   GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3);
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0);
-  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
+  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape, true), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
   return PBHC_OK;
 }
 
@@ -589,7 +635,8 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
                           int act, void* stream) {
   GEMM_ARG(dy && w && dx && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3 && (act == 0 || saved) && (!scratch || num_row_blocks));
   GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)w & 3) == 0);
-  int shape = pick_shape(M, N, g_force_shape);
+  int shape = pick_shape(M, N, g_force_shape, false);
+  if (shape == 3) shape = 2;
   if ((M + tile_bm(shape) - 1) / tile_bm(shape) > PBHC_ACT_MAX_BLOCKS) shape = 0;
   const int nb = (M + tile_bm(shape) - 1) / tile_bm(shape);
   GEMM_ARG(!scratch || nb <= PBHC_ACT_MAX_BLOCKS);
