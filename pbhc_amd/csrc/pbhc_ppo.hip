@@ -35,8 +35,12 @@ __device__ __forceinline__ float gsum32(float v) {
 }
 
 // One row per 32-lane group: lane a < A <-> action dim a, lane r < R <-> value head r.
-// partial[blk][0..2] = sum over the block's rows of (max(s1,s2), sum_r max(l1,l2), kl);
-// gstd_part[blk][a] = sum over the block's rows of d(surrogate)/d(sigma_a) (before the 1/B).
+// Every 32-lane group keeps its own running sums over the tiles it visits (no barrier inside the tile loop: the loads of consecutive tiles
+// overlap); at the end of the block the eight groups are summed in a fixed order into
+//   partial[blk][0..2] = sum over the block's rows of (max(s1,s2), sum_r max(l1,l2), kl)
+//   gstd_part[blk][a]  = sum over the block's rows of d(surrogate)/d(sigma_a) (before the 1/B).
+// (A "last block finishes the job" ticket was tried instead of the second launch: the device-scope release / acquire it needs is an L2
+// write-back + invalidate per block on this 8-XCD part — 73 us for the pair against 25 us as two launches.)
 __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, const float* __restrict__ stdp, const float* __restrict__ value,
                                                   const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ old_mu,
                                                   const float* __restrict__ old_sigma, const float* __restrict__ adv, const float* __restrict__ returns,
@@ -45,133 +49,152 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
                                                   float* __restrict__ partial, float* __restrict__ gstd_part) {
   __shared__ float sh_s[LOSS_ROWS][4];
   __shared__ float sh_g[LOSS_ROWS][32];
-  const int lane = threadIdx.x & 31, lr = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 31, lr_ = threadIdx.x >> 5;
   const float invB = 1.0f / (float)B;
   const int ntiles = (B + LOSS_ROWS - 1) / LOSS_ROWS;
-  float acc = 0.0f;                                  // thread < 3: scalar partial; thread 32..32+A: d sigma partial (fixed tile order)
+  const float sigma = lane < A ? stdp[lane] : 1.0f;            // Normal(mean, mean*0 + std): sigma is the parameter itself
+  const float var = sigma * sigma, lsig = logf(sigma);
+  float a_surr = 0.0f, a_vl = 0.0f, a_kl = 0.0f, a_sig = 0.0f;  // lane 0: the group's scalar sums; lane a < A: its d sigma sum
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int row = tile * LOSS_ROWS + lr;
-  const bool valid = row < B;
-  float lp = 0.0f, kl = 0.0f, dmu_c = 0.0f, dsig_c = 0.0f;     // per-lane pieces
-  float sigma = 1.0f;
-  if (valid && lane < A) {
-    sigma = stdp[lane];                                          // Normal(mean, mean*0 + std): sigma is the parameter itself
-    const size_t i = (size_t)row * A + lane;
-    const float m = mu[i], x = actions[i], om = old_mu[i], os = old_sigma[i];
-    const float var = sigma * sigma;
-    const float d = x - m;
-    // torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(sigma) - log(sqrt(2 pi))
-    lp = -(d * d) / (2.0f * var) - logf(sigma) - 0.9189385332046727f;
-    // mh_ppo.py:453 adds the 1e-5 to the ratio, ppo_mimic.py:624 to the old sigma
-    kl = (kl_v2 ? logf(sigma / (os + 1.0e-5f)) : logf(sigma / os + 1.0e-5f)) + (os * os + (om - m) * (om - m)) / (2.0f * sigma * sigma) - 0.5f;
-    dmu_c = d / var;                       // d logp / d mu
-    dsig_c = d * d / (var * sigma) - 1.0f / sigma;   // d logp / d sigma
-  }
-  const float logp = gsum32(lp);
-  const float klrow = gsum32(kl);
-  float surr = 0.0f, coef = 0.0f;
-  if (valid) {
-    const float a = adv[row];
-    const float ratio = expf(logp - old_logp[row]);
-    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-    const float s1 = -a * ratio, s2 = -a * rc;
-    surr = fmaxf(s1, s2);
-    // d max(s1,s2)/d logp : torch.max splits ties evenly; inside the clip range s2 == s1 and d s2 = d s1
-    const bool inrange = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
-    float g;
-    if (s1 > s2) g = -a * ratio;
-    else if (s1 < s2) g = inrange ? -a * ratio : 0.0f;
-    else g = 0.5f * (-a * ratio) + 0.5f * (inrange ? -a * ratio : 0.0f);
-    coef = g * invB;
-  }
-  if (valid && lane < A) grad_mu[(size_t)row * A + lane] = coef * dmu_c;
-  // value loss (summed over heads, mean over rows) and its gradient
-  float vl = 0.0f;
-  if (valid && lane < R) {
-    const size_t i = (size_t)row * R + lane;
-    const float v = value[i], ov = old_values[i], ret = returns[i];
-    float g;
-    if (clipped_value) {
-      const float dv = v - ov;
-      const float dc = fminf(fmaxf(dv, -clip), clip);
-      const float vc = ov + dc;
-      const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
-      vl = fmaxf(l1, l2);
-      const float g1 = 2.0f * (v - ret);
-      const float g2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - ret) : 0.0f;
-      g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
-    } else {
-      vl = (ret - v) * (ret - v);
-      g = 2.0f * (v - ret);
+    const int row = tile * LOSS_ROWS + lr_;
+    const bool valid = row < B;
+    float lp = 0.0f, kl = 0.0f, dmu_c = 0.0f, dsig_c = 0.0f;     // per-lane pieces
+    if (valid && lane < A) {
+      const size_t i = (size_t)row * A + lane;
+      const float m = mu[i], x = actions[i], om = old_mu[i], os = old_sigma[i];
+      const float d = x - m;
+      // torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(sigma) - log(sqrt(2 pi))
+      lp = -(d * d) / (2.0f * var) - lsig - 0.9189385332046727f;
+      // mh_ppo.py:453 adds the 1e-5 to the ratio, ppo_mimic.py:624 to the old sigma
+      kl = (kl_v2 ? logf(sigma / (os + 1.0e-5f)) : logf(sigma / os + 1.0e-5f)) + (os * os + (om - m) * (om - m)) / (2.0f * sigma * sigma) - 0.5f;
+      dmu_c = d / var;                       // d logp / d mu
+      dsig_c = d * d / (var * sigma) - 1.0f / sigma;   // d logp / d sigma
     }
-    grad_value[i] = value_coef * g * invB;
+    const float logp = gsum32(lp);
+    const float klrow = gsum32(kl);
+    float surr = 0.0f, coef = 0.0f;
+    if (valid) {
+      const float a = adv[row];
+      const float ratio = expf(logp - old_logp[row]);
+      const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+      const float s1 = -a * ratio, s2 = -a * rc;
+      surr = fmaxf(s1, s2);
+      // d max(s1,s2)/d logp : torch.max splits ties evenly; inside the clip range s2 == s1 and d s2 = d s1
+      const bool inrange = (ratio >= 1.0f - clip) && (ratio <= 1.0f + clip);
+      float g;
+      if (s1 > s2) g = -a * ratio;
+      else if (s1 < s2) g = inrange ? -a * ratio : 0.0f;
+      else g = 0.5f * (-a * ratio) + 0.5f * (inrange ? -a * ratio : 0.0f);
+      coef = g * invB;
+    }
+    if (valid && lane < A) grad_mu[(size_t)row * A + lane] = coef * dmu_c;
+    // value loss (summed over heads, mean over rows) and its gradient
+    float vl = 0.0f;
+    if (valid && lane < R) {
+      const size_t i = (size_t)row * R + lane;
+      const float v = value[i], ov = old_values[i], ret = returns[i];
+      float g;
+      if (clipped_value) {
+        const float dv = v - ov;
+        const float dc = fminf(fmaxf(dv, -clip), clip);
+        const float vc = ov + dc;
+        const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+        vl = fmaxf(l1, l2);
+        const float g1 = 2.0f * (v - ret);
+        const float g2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - ret) : 0.0f;
+        g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
+      } else {
+        vl = (ret - v) * (ret - v);
+        g = 2.0f * (v - ret);
+      }
+      grad_value[i] = value_coef * g * invB;
+    }
+    const float vlrow = gsum32(vl);
+    if (valid) {
+      a_surr += surr;
+      a_vl += vlrow;
+      a_kl += klrow;
+      if (lane < A) a_sig += coef * dsig_c;
+    }
   }
-  const float vlrow = gsum32(vl);
-  if (lane == 0) { sh_s[lr][0] = valid ? surr : 0.0f; sh_s[lr][1] = valid ? vlrow : 0.0f; sh_s[lr][2] = valid ? klrow : 0.0f; }
-  sh_g[lr][lane] = (valid && lane < A) ? coef * dsig_c : 0.0f;
+  if (lane == 0) { sh_s[lr_][0] = a_surr; sh_s[lr_][1] = a_vl; sh_s[lr_][2] = a_kl; }
+  sh_g[lr_][lane] = lane < A ? a_sig : 0.0f;
   __syncthreads();
   if (threadIdx.x < 3) {
-    float s = 0.0f;
-    for (int r = 0; r < LOSS_ROWS; ++r) s += sh_s[r][threadIdx.x];
-    acc += s;
+    float t = 0.0f;
+    for (int g = 0; g < LOSS_ROWS; ++g) t += sh_s[g][threadIdx.x];
+    partial[(size_t)blockIdx.x * LOSS_NP + threadIdx.x] = t;
   }
-  if (threadIdx.x >= 32 && threadIdx.x < 32 + A) {
+  if (threadIdx.x >= 32 && threadIdx.x < 64) {
     const int a = threadIdx.x - 32;
-    float s = 0.0f;
-    for (int r = 0; r < LOSS_ROWS; ++r) s += sh_g[r][a];
-    acc += s;
+    float t = 0.0f;
+    for (int g = 0; g < LOSS_ROWS; ++g) t += sh_g[g][a];
+    gstd_part[(size_t)blockIdx.x * 32 + a] = t;
   }
-  __syncthreads();
-  }
-  if (threadIdx.x < 3) partial[(size_t)blockIdx.x * LOSS_NP + threadIdx.x] = acc;
-  if (threadIdx.x >= 32 && threadIdx.x < 32 + A) gstd_part[(size_t)blockIdx.x * 32 + (threadIdx.x - 32)] = acc;
 }
 
-// Fixed-order second stage: loss scalars, d(loss)/d(std) (surrogate part + entropy bonus), and the adaptive-KL
-// learning-rate rule (mh_ppo.py:455-466) on the device.
+// Fixed-order second stage: loss scalars, d(loss)/d(std) (surrogate part + entropy bonus), and the adaptive-KL learning-rate rule
+// (mh_ppo.py:455-466) on the device.  One block of 1024 threads = 32 chunks of blocks x 32 columns.  The partials were written by the previous
+// launch on all eight XCDs and arrive through memory (~2 us a trip), so a thread issues ALL its loads (<= 16 with the entry's 512-block cap)
+// before the first add, and sums them in block order.
 #define RED_T 1024
+#define RED_CH (RED_T / 32)
 __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ partial, const float* __restrict__ gstd_part, const float* __restrict__ stdp,
                                                       int nblocks, int B, int A, float entropy_coef, float desired_kl, int adapt_lr,
                                                       float* __restrict__ grad_std, float* __restrict__ scalars, float* __restrict__ lr) {
-  __shared__ double acc[RED_T / 32][33];
-  const int col = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 32 chunks
-  // columns 0..A-1: gstd ; then 3 scalar columns handled by chunk-strided threads with col < 3 on `partial`
-  double s = 0.0;
-  if (col < A)
-    for (int b = chunk; b < nblocks; b += RED_T / 32) s += (double)gstd_part[(size_t)b * 32 + col];
-  acc[chunk][col] = s;
+  __shared__ double sh_g[RED_CH][33];
+  __shared__ double sh_s[RED_CH][4];
+  __shared__ float sh_e[32];
+  __shared__ float sh_m[4];
+  const int col = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+  const float lr0 = threadIdx.x < 2 ? lr[threadIdx.x] : 0.0f;       // in flight with the partials
+  const float sig = col < A ? stdp[col] : 1.0f;
+  float gq[16], sq[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int b = chunk + u * RED_CH;
+    gq[u] = b < nblocks ? gstd_part[(size_t)b * 32 + col] : 0.0f;
+    sq[u] = (b < nblocks && col < 3) ? partial[(size_t)b * LOSS_NP + col] : 0.0f;
+  }
+  double sg = 0.0, ss = 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { sg += (double)gq[u]; ss += (double)sq[u]; }
+  for (int b = chunk + 16 * RED_CH; b < nblocks; b += RED_CH) {            // (not reached with the entry's 512-block cap)
+    sg += (double)gstd_part[(size_t)b * 32 + col];
+    if (col < 3) ss += (double)partial[(size_t)b * LOSS_NP + col];
+  }
+  sh_g[chunk][col] = sg;
+  if (col < 3) sh_s[chunk][col] = ss;
+  if (chunk == 0) sh_e[col] = col < A ? 0.5f + 0.9189385332046727f + logf(sig) : 0.0f;   // entropy terms (mean over rows of identical values)
   __syncthreads();
   if (threadIdx.x < A) {
     double t = 0.0;
-    for (int ch = 0; ch < RED_T / 32; ++ch) t += acc[ch][threadIdx.x];
+    for (int ch = 0; ch < RED_CH; ++ch) t += sh_g[ch][threadIdx.x];
     // actor_loss = surrogate - entropy_coef * entropy ; entropy = sum_a (0.5 + 0.5 log(2 pi) + log sigma_a)
-    grad_std[threadIdx.x] = (float)t - entropy_coef / stdp[threadIdx.x];
+    grad_std[threadIdx.x] = (float)t - entropy_coef / sig;
+  }
+  if (threadIdx.x >= 32 && threadIdx.x < 35) {              // wave 0's upper half: the three scalar columns, each its own lane
+    const int k = threadIdx.x - 32;
+    double t = 0.0;
+    for (int ch = 0; ch < RED_CH; ++ch) t += sh_s[ch][k];
+    const float mean = (float)(t / (double)B);
+    if (k == 0) scalars[0] = mean;                          // surrogate loss
+    if (k == 1) scalars[1] = mean;                          // value loss
+    if (k == 2) scalars[3] = mean;                          // kl
+    sh_m[k] = mean;
   }
   __syncthreads();
-  s = 0.0;
-  if (col < 3)
-    for (int b = chunk; b < nblocks; b += RED_T / 32) s += (double)partial[(size_t)b * LOSS_NP + col];
-  acc[chunk][col] = s;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    double t[3] = {0.0, 0.0, 0.0};
-    for (int k = 0; k < 3; ++k)
-      for (int ch = 0; ch < RED_T / 32; ++ch) t[k] += acc[ch][k];
     float ent = 0.0f;
-    for (int a = 0; a < A; ++a) ent += 0.5f + 0.9189385332046727f + logf(stdp[a]);
-    const float kl_mean = (float)(t[2] / (double)B);
-    scalars[0] = (float)(t[0] / (double)B);      // surrogate loss
-    scalars[1] = (float)(t[1] / (double)B);      // value loss
-    scalars[2] = ent;                            // entropy (mean over rows of identical values)
-    scalars[3] = kl_mean;
-    if (adapt_lr) {
-      for (int k = 0; k < 2; ++k) {
-        float l = lr[k];
-        if (kl_mean > desired_kl * 2.0f) l = fmaxf(1e-5f, l / 1.5f);
-        else if (kl_mean < desired_kl / 2.0f && kl_mean > 0.0f) l = fminf(1e-2f, l * 1.5f);
-        lr[k] = l;
-      }
-    }
+    for (int a = 0; a < A; ++a) ent += sh_e[a];
+    scalars[2] = ent;
+  }
+  if (threadIdx.x < 2 && adapt_lr) {
+    const float kl_mean = sh_m[2];
+    float l = lr0;
+    if (kl_mean > desired_kl * 2.0f) l = fmaxf(1e-5f, l / 1.5f);
+    else if (kl_mean < desired_kl / 2.0f && kl_mean > 0.0f) l = fminf(1e-2f, l * 1.5f);
+    lr[threadIdx.x] = l;
   }
 }
 
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(ACT_T) void k_act_bwd_bias(const float* __restrict_
     part[(size_t)blockIdx.x * n + blockIdx.y * ACT_T + threadIdx.x] = t;
   }
 }
-// second stage: 64 columns x 4 slices per block, fixed order
+// second stage: 32 columns x 8 slices per block, fixed order
 __device__ __forceinline__ void colsum_final_block(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int block);
 __global__ __launch_bounds__(ACT_T) void k_colsum_final(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out) {
   colsum_final_block(part, nblocks, n, out, blockIdx.x);
@@ -240,23 +263,30 @@ __global__ __launch_bounds__(ACT_T) void k_colsum_final_multi(ColsumJobs J, int 
   colsum_final_block(J.job[j].part, J.job[j].num_row_blocks, J.job[j].n, J.job[j].out, (int)blockIdx.x - J.first_block[j]);
 }
 __device__ __forceinline__ void colsum_final_block(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int block) {
-  __shared__ double sh[4][64];
-  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6, c = block * 64 + col;
+  // 32 columns x 8 row slices per block (a slice reads rows slice, slice + 8, ...: eight independent loads in flight per thread), then the
+  // slices in order 0..7: fixed order, deterministic
+  __shared__ double sh[8][32];
+  const int col = threadIdx.x & 31, slice = threadIdx.x >> 5, c = block * 32 + col;
   double s = 0.0;
   if (c < n) {
     int b = slice;
-    for (; b + 28 < nblocks; b += 32) {
+    for (; b + 56 < nblocks; b += 64) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * n + c];
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 8 * u) * n + c];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; b < nblocks; b += 4) s += (double)part[(size_t)b * n + c];
+    for (; b < nblocks; b += 8) s += (double)part[(size_t)b * n + c];
   }
   sh[slice][col] = s;
   __syncthreads();
-  if (slice == 0 && c < n) out[c] = (float)(sh[0][col] + sh[1][col] + sh[2][col] + sh[3][col]);
+  if (slice == 0 && c < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][col];
+    out[c] = (float)t;
+  }
 }
 
 // ---- global-norm clipping + Adam over a flat parameter segment ---------------------------------
@@ -272,6 +302,7 @@ struct AdamSegs {
   int n[ADAM_MAX_SEGS], nparts[ADAM_MAX_SEGS], first_norm_block[ADAM_MAX_SEGS + 1], first_adam_block[ADAM_MAX_SEGS + 1];
   int num;
 };
+struct __attribute__((packed, aligned(4))) AdamF4 { float v[4]; };
 __global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(AdamSegs S) {
   __shared__ double sh[ADAM_T];
   const int seg = (S.num > 1 && (int)blockIdx.x >= S.first_norm_block[1]) ? 1 : 0;
@@ -279,9 +310,14 @@ __global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(AdamSegs S) {
   const float* __restrict__ g = S.g[seg];
   const size_t n = (size_t)S.n[seg];
   double s = 0.0;
-  for (size_t i = (size_t)b * ADAM_T + threadIdx.x; i < n; i += (size_t)nb * ADAM_T) {
-    const float v = g[i];
-    s += (double)v * (double)v;
+  // 16 bytes per lane (the flat segments are only 4-byte aligned relative to each other: dword-aligned dwordx4 accesses)
+  for (size_t i = ((size_t)b * ADAM_T + threadIdx.x) * 4; i < n; i += (size_t)nb * ADAM_T * 4) {
+    if (i + 4 <= n) {
+      const AdamF4 q = *reinterpret_cast<const AdamF4*>(g + i);
+      s += (double)q.v[0] * (double)q.v[0] + (double)q.v[1] * (double)q.v[1] + (double)q.v[2] * (double)q.v[2] + (double)q.v[3] * (double)q.v[3];
+    } else {
+      for (size_t j = i; j < n; ++j) s += (double)g[j] * (double)g[j];
+    }
   }
   sh[threadIdx.x] = s;
   __syncthreads();
@@ -332,14 +368,26 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(AdamSegs S, float max_norm
   const size_t n = (size_t)S.n[seg];
   const float clipc = s_clip, step_size = s_lr / s_bc1, bc2s = s_bc2s;
   const float decay = 1.0f - s_lr * weight_decay;              // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
-  for (size_t i = (size_t)b * ADAM_T + threadIdx.x; i < n; i += (size_t)nb * ADAM_T) {
-    const float gi = g[i] * clipc;
-    g[i] = gi;                                        // clip_grad_norm_ scales .grad in place
-    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
+  auto one = [&](float& pi, float& gi_, float& mi_, float& vi_) {
+    const float gi = gi_ * clipc;
+    gi_ = gi;                                         // clip_grad_norm_ scales .grad in place
+    const float mi = mi_ + (gi - mi_) * (1.0f - b1);
+    const float vi = vi_ * b2 + (1.0f - b2) * gi * gi;
+    mi_ = mi; vi_ = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] = p[i] * decay - step_size * (mi / denom);
+    pi = pi * decay - step_size * (mi / denom);
+  };
+  for (size_t i = ((size_t)b * ADAM_T + threadIdx.x) * 4; i < n; i += (size_t)nb * ADAM_T * 4) {
+    if (i + 4 <= n) {
+      AdamF4 qp = *reinterpret_cast<const AdamF4*>(p + i), qg = *reinterpret_cast<const AdamF4*>(g + i);
+      AdamF4 qm = *reinterpret_cast<const AdamF4*>(m + i), qv = *reinterpret_cast<const AdamF4*>(v + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(qp.v[u], qg.v[u], qm.v[u], qv.v[u]);
+      *reinterpret_cast<AdamF4*>(p + i) = qp; *reinterpret_cast<AdamF4*>(g + i) = qg;
+      *reinterpret_cast<AdamF4*>(m + i) = qm; *reinterpret_cast<AdamF4*>(v + i) = qv;
+    } else {
+      for (size_t j = i; j < n; ++j) one(p[j], g[j], m[j], v[j]);
+    }
   }
 }
 
@@ -458,7 +506,7 @@ int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act
   ARG_CHECK(dy && dz && grad_bias && scratch && B >= 1 && n >= 1 && act >= 0 && act <= 3 && (act == 0 || saved));
   hipStream_t st = (hipStream_t)stream;
   const int nb = act_bwd_launch(dy, saved, B, n, act, dz, scratch, st);
-  hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(ACT_T), 0, st, scratch, nb, n, grad_bias);
+  hipLaunchKernelGGL(k_colsum_final, dim3((n + 31) / 32), dim3(ACT_T), 0, st, scratch, nb, n, grad_bias);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
@@ -478,13 +526,13 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream) {
     if (j < num_jobs) {
       ARG_CHECK(jobs[j].part && jobs[j].out && jobs[j].num_row_blocks >= 1 && jobs[j].n >= 1);
       J.job[j] = jobs[j];
-      blocks += (jobs[j].n + 63) / 64;
+      blocks += (jobs[j].n + 31) / 32;
     } else {
       J.job[j] = PbhcColsumJob{nullptr, nullptr, 0, 0};
     }
   }
   int acc = 0;
-  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) { J.first_block[j] = acc; acc += (J.job[j].n + 63) / 64; }
+  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) { J.first_block[j] = acc; acc += (J.job[j].n + 31) / 32; }
   hipLaunchKernelGGL(k_colsum_final_multi, dim3(blocks), dim3(ACT_T), 0, (hipStream_t)stream, J, num_jobs);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
