@@ -232,6 +232,11 @@ typedef struct PbhcEnvConfig {
   float adaptive_alpha;
   int32_t penalty_curriculum;
   float penalty_degree, penalty_down, penalty_up, penalty_min, penalty_max;
+  /* obs.add_noise_currculum (legged_robot_base.py:591-592,1117-1126): PBHC_G_NOISE_CURRICULUM scales every observation noise amplitude and
+   * moves by (1 -/+ degree) when the average episode length is below `noise_down` / above `noise_up` (the reference reads the latter from
+   * rewards.reward_penalty_level_up_threshold), clipped to [noise_min, noise_max] */
+  int32_t noise_curriculum;
+  float noise_degree, noise_down, noise_up, noise_min, noise_max;
   int32_t num_compute_average_epl;
   int32_t soft_pos_curriculum, soft_vel_curriculum, soft_tau_curriculum;
   float soft_dof_vel_limit, soft_torque_limit;

@@ -116,6 +116,8 @@ class MotionTrackingOracle:
         self.adaptive = bool(rw.get("adaptive_tracking_sigma", {}).get("enable", False))
         self.ema = dict(self.sigma)
         self.penalty_scale = rw.reward_initial_penalty_scale
+        self.noise_curriculum = bool(ob.get("add_noise_currculum", False))          # legged_robot_base.py:119-124
+        self.noise_cur = float(ob.noise_initial_value) if self.noise_curriculum else 1.0
         self.avg_ep_len = 0.0
         tc = ec.termination_curriculum
         self.motion_far_thr = tc.terminate_when_motion_far_initial_threshold if (ec.termination.terminate_when_motion_far and tc.terminate_when_motion_far_curriculum) else ec.termination_scales.termination_motion_far_threshold
@@ -160,6 +162,8 @@ class MotionTrackingOracle:
             if "ema__" + k in st:
                 self.ema[k] = float(st["ema__" + k])
         self.penalty_scale = float(st["reward_penalty_scale"])
+        if "noise_curriculum_value" in st:
+            self.noise_cur = float(st["noise_curriculum_value"])
         self.avg_ep_len = torch.tensor(float(st["average_episode_length"]), dtype=torch.float32)
         self.motion_far_thr = float(st["motion_far_threshold"])
 
@@ -372,6 +376,13 @@ class MotionTrackingOracle:
                 elif self.avg_ep_len > lc[pre + "_curriculum_level_up_threshold"]:
                     v *= 1 - lc[pre + "_curriculum_degree"]
                 setattr(self, attr, float(np.clip(v, lc[pre + "_min_limit"], lc[pre + "_max_limit"])))
+        if self.noise_curriculum:                            # _update_obs_noise_curriculum, legged_robot_base.py:1117-1126
+            if self.avg_ep_len < cfg.obs.soft_dof_pos_curriculum_level_down_threshold:
+                self.noise_cur *= 1 - cfg.obs.soft_dof_pos_curriculum_degree
+            elif self.avg_ep_len > rw.reward_penalty_level_up_threshold:
+                self.noise_cur *= 1 + cfg.obs.soft_dof_pos_curriculum_degree
+            self.noise_cur = float(np.clip(self.noise_cur, cfg.obs.noise_value_min, cfg.obs.noise_value_max))
+            self.log["current_noise_curriculum_value"] = torch.tensor(self.noise_cur, dtype=torch.float)
         # tracking part (motion_tracking.py:265-287)
         end_time = s["last_episode_length_buf"][ids] * self.dt + s["motion_start_times"][ids]
         s["end_time_ratio_buf"][ids] = end_time / s["motion_len"][ids]
@@ -424,7 +435,7 @@ class MotionTrackingOracle:
         out = {}
         for key in keys:
             k = key[:-4] if key.endswith("_raw") else key
-            noise = 0.0 if key.endswith("_raw") else ob.noise_scales[k] * 1.0
+            noise = 0.0 if key.endswith("_raw") else ob.noise_scales[k] * self.noise_cur      # noise_extra_scale, legged_robot_base.py:760-763
             x = self._get(k).clone()
             u = torch.full_like(x, 0.5) if noise_u is None else noise_u[k]
             out[k] = (x + (u * 2.0 - 1.0) * noise) * ob.obs_scales[k]

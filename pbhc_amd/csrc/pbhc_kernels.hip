@@ -1562,6 +1562,12 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
       else if (avg > c.penalty_up) p *= (1.0 + (double)c.penalty_degree);
       glob[PBHC_G_PENALTY_SCALE] = fmin(fmax(p, (double)c.penalty_min), (double)c.penalty_max);
     }
+    if (c.noise_curriculum) {             // _update_obs_noise_curriculum, legged_robot_base.py:1117-1126 (after the penalty / limit curricula)
+      double v = glob[PBHC_G_NOISE_CURRICULUM];
+      if (avg < c.noise_down) v *= (1.0 - (double)c.noise_degree);
+      else if (avg > c.noise_up) v *= (1.0 + (double)c.noise_degree);
+      glob[PBHC_G_NOISE_CURRICULUM] = fmin(fmax(v, (double)c.noise_min), (double)c.noise_max);
+    }
     if (c.terminate_when_motion_far && c.motion_far_curriculum) {   // motion_tracking.py:309-317
       double t = glob[PBHC_G_MOTION_FAR_THR];
       if (avg < c.motion_far_down) t *= (1.0 + (double)c.motion_far_degree);

@@ -294,6 +294,13 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     c.penalty_up = float(rw.reward_penalty_level_up_threshold)
     c.penalty_min = float(rw.reward_min_penalty_scale)
     c.penalty_max = float(rw.reward_max_penalty_scale)
+    c.noise_curriculum = int(bool(ob.get("add_noise_currculum", False)))
+    if c.noise_curriculum:                                   # legged_robot_base.py:1117-1126 (the up-threshold is the penalty curriculum's)
+        c.noise_degree = float(ob.soft_dof_pos_curriculum_degree)
+        c.noise_down = float(ob.soft_dof_pos_curriculum_level_down_threshold)
+        c.noise_up = float(rw.reward_penalty_level_up_threshold)
+        c.noise_min = float(ob.noise_value_min)
+        c.noise_max = float(ob.noise_value_max)
     c.num_compute_average_epl = int(rw.num_compute_average_epl)
     lc = rw.reward_limit.reward_limits_curriculum
     c.soft_pos_curriculum = int(bool(lc.soft_dof_pos_curriculum))
@@ -572,8 +579,6 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     g[K["PBHC_G_SOFT_VEL_VAL"]] = float(lc.soft_dof_vel_initial_limit)
     g[K["PBHC_G_SOFT_TAU_VAL"]] = float(lc.soft_torque_initial_limit)
     g[K["PBHC_G_NOISE_CURRICULUM"]] = float(ob.noise_initial_value) if ob.get("add_noise_currculum", False) else 1.0
-    if ob.get("add_noise_currculum", False):
-        raise NotImplementedError("obs.add_noise_currculum")
     if "noise_process" in ob and ob.noise_process.get("enable", False):
         raise NotImplementedError("obs.noise_process")
     L.globals0 = g

@@ -382,6 +382,10 @@ class LeggedRobotMotionTracking:
             p = float(g[K["PBHC_G_PENALTY_SCALE"]])
             p *= (1 - c.penalty_degree) if avg_f < c.penalty_down else ((1 + c.penalty_degree) if avg_f > c.penalty_up else 1.0)
             g[K["PBHC_G_PENALTY_SCALE"]] = float(np.clip(p, c.penalty_min, c.penalty_max))
+        if c.noise_curriculum:
+            v = float(g[K["PBHC_G_NOISE_CURRICULUM"]])
+            v *= (1 - c.noise_degree) if avg_f < c.noise_down else ((1 + c.noise_degree) if avg_f > c.noise_up else 1.0)
+            g[K["PBHC_G_NOISE_CURRICULUM"]] = float(np.clip(v, c.noise_min, c.noise_max))
         end_time = self.last_episode_length_buf * self.dt + self.motion_start_times
         self.end_time_ratio_buf.copy_(end_time / self.motion_len.clamp(min=1e-9))
         self._resample_motion_times(ids)
@@ -476,7 +480,7 @@ class LeggedRobotMotionTracking:
             "action_clip_frac": g[L0 + K["PBHC_L_ACTION_CLIP_FRAC"]], "terminate_by_gravity": g[L0 + K["PBHC_L_TERM_GRAVITY"]],
             "terminate_by_motion_far": g[L0 + K["PBHC_L_TERM_MOTION_FAR"]], "terminate_by_time_out": g[L0 + K["PBHC_L_TERM_TIME_OUT"]],
             "terminate_by_motion_end": g[L0 + K["PBHC_L_TERM_MOTION_END"]], "end_time_ratio": g[L0 + K["PBHC_L_END_TIME_RATIO"]],
-            "end_time_ratio_std": g[L0 + K["PBHC_L_END_TIME_RATIO_STD"]], "penalty_scale": g[K["PBHC_G_PENALTY_SCALE"]],
+            "end_time_ratio_std": g[L0 + K["PBHC_L_END_TIME_RATIO_STD"]], "penalty_scale": g[K["PBHC_G_PENALTY_SCALE"]], **({"current_noise_curriculum_value": g[K["PBHC_G_NOISE_CURRICULUM"]]} if self._c.noise_curriculum else {}),
             "average_episode_length": g[K["PBHC_G_AVG_EP_LEN"]], "terminate_when_motion_far_threshold": g[K["PBHC_G_MOTION_FAR_THR"]],
             "reward_mean": g[L0 + K["PBHC_L_REW_MEAN"]],
         }
