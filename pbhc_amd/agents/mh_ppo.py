@@ -260,7 +260,7 @@ class MHPPO:
         self._n_critic = sum(p.numel() for p in pc)
         n = self._n_actor + self._n_critic
         self._pflat = torch.zeros(n, device=dev)
-        self._gflat = torch.zeros(n, device=dev)
+        self._gflat = torch.zeros(n + 1, device=dev)         # + one slot behind the critic's segment: the minibatch KL rides in its all-reduce
         self._mflat = torch.zeros(n, device=dev)
         self._vflat = torch.zeros(n, device=dev)
         o = 0
@@ -513,11 +513,14 @@ class MHPPO:
             torch.autograd.backward([mu], [self._grad_mu])
             h_a = pdist.all_reduce(self._gflat[:na], async_op=True)
             torch.autograd.backward([value], [self._grad_value])
-            h_c = pdist.all_reduce(self._gflat[na:na + nc], async_op=True)
-            if adapt:
-                pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
+            # the minibatch KL mean sits in the slot behind the critic's segment: one collective carries both (the adaptive learning-rate
+            # rule, mh_ppo.py:455-466, needs the mean over ALL ranks' samples before the optimiser step)
+            self._gflat[na + nc:na + nc + 1].copy_(self._loss_scalars[3:4])
+            h_c = pdist.all_reduce(self._gflat[na:na + nc + 1], async_op=True)
             h_a.wait(); h_c.wait()
             self._gflat.div_(self.world_size)
+            if adapt:
+                pdist.kl_lr_rule_(self._lr, self._gflat[na + nc], self.desired_kl, reduced=True)
         else:
             if two:
                 br.wait_stream(cur)                      # the loss kernel's gradients are ready for the critic's backward on its stream

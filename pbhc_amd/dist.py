@@ -110,10 +110,11 @@ def global_normalize_(raw: torch.Tensor):
     return raw
 
 
-def kl_lr_rule_(lr: torch.Tensor, kl_mean_local: torch.Tensor, desired_kl: float):
-    """lr: device tensor of learning rates (updated in place); kl_mean_local: this rank's minibatch KL mean."""
+def kl_lr_rule_(lr: torch.Tensor, kl_mean_local: torch.Tensor, desired_kl: float, reduced: bool = False):
+    """lr: device tensor of learning rates (updated in place); kl_mean_local: this rank's minibatch KL mean — or, with `reduced`, the mean over
+    all ranks already (the agents carry it inside a gradient bucket's all-reduce)."""
     kl = kl_mean_local.clone()
-    if active():
+    if active() and not reduced:
         all_reduce(kl)
         kl = kl / world()
     up = kl > desired_kl * 2.0

@@ -52,7 +52,7 @@ def test_rccl_code_path_on_one_rank():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     c = r["collectives"]
     assert c["backend"] == "nccl" and r["n_gpus"] == 1
-    # per iteration: 20 optimiser steps x (2 gradient segments + 1 KL scalar) + 1 advantage-moment exchange + 24 env-statistics exchanges
-    assert c["all_reduces_per_iter"] == 20 * 3 + 1 + 24, c
+    # per iteration: 20 optimiser steps x 2 gradient segments (the KL scalar rides in the critic's) + 1 advantage-moment exchange + 24 env-statistics exchanges
+    assert c["all_reduces_per_iter"] == 20 * 2 + 1 + 24, c
     # actor 380-512-256-128-23 (+ std) and critic 630-768-512-128-R, R = reward columns of the walk config (19 terms + termination = 20)
     assert c["grad_bucket_bytes"] == 4 * (362286 + 944000 + 129 * 20) and c["grad_allreduce_ms"] > 0
