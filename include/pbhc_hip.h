@@ -462,6 +462,11 @@ int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float
  * scratch may be NULL (no column sums); act 0: saved unused. */
 int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, float* dx, float* scratch, int* num_row_blocks, int M, int N, int K,
                           int act, void* stream);
+/* The weight gradient of that Linear (autograd's `dy.t() @ x`): dw[N,K] = sum over the M rows of dy[m,N]^T x[m,K], N = out_features,
+ * K = in_features.  The rows are split over pbhc_linear_wgrad_parts(M, N, K) workgroup groups (0: shape not supported — N % 4, M % 32, K < 4 —
+ * use the library) whose partial images go to `scratch` (parts * N * K floats) and are summed in a fixed order. */
+int pbhc_linear_wgrad_parts(int M, int N, int K);
+int pbhc_linear_wgrad(const float* dy, const float* x, float* dw, float* scratch, int M, int N, int K, void* stream);
 /* diagnosis: force the tile shape of the two entries above (0: 128x128, 1: 96x128, 2: 64x128; -1: automatic) */
 void pbhc_gemm_debug_force_shape(int shape);
 

@@ -5,7 +5,9 @@ MI355X:
   activation pass — and their input gradients in `pbhc_linear_dgrad_act`, which folds in the activation derivative of the layer below and
   the row-block column sums of its bias gradient (csrc/pbhc_gemm.hip: LDS-DMA staged, `v_mfma_f32_32x32x2_f32`).  `PBHC_FUSED_GEMM=0`
   returns to library GEMMs (hipBLASLt / rocBLAS through torch) + the `pbhc_act_bwd_bias` pass;
-* weight gradients and the narrow output layer stay library GEMMs (split-K batched form below);
+* weight gradients and the narrow output layer stay library GEMMs (split-K batched form below); a split-rows MFMA weight-gradient kernel
+  (`pbhc_linear_wgrad`) exists and is pinned by tests, but measured 104-107 TFLOP/s against the library's 115-123 and is opt-in
+  (`PBHC_FUSED_WGRAD=1`);
 * weight / bias gradients are written by the GEMM (`out=`) and the fused kernel straight into the parameter's `.grad` — a view of
   the agent's flat gradient buffer — so autograd's per-parameter `grad += tmp` launches and temporaries disappear.  That store
   OVERWRITES, so it is opt-in: only a stack whose owner declared `grad_direct(seq)` — "I zero the gradient buffer before every backward"
@@ -28,6 +30,7 @@ from .. import _lib
 
 _ACT_ID = {nn.ELU: 1, nn.SiLU: 2, nn.ReLU: 3}
 FUSED_GEMM = os.environ.get("PBHC_FUSED_GEMM", "1") != "0"
+FUSED_WGRAD = os.environ.get("PBHC_FUSED_WGRAD", "0") == "1"        # measured slower than the library's split-K form: opt-in
 
 
 class _Live:
@@ -56,6 +59,20 @@ def supported(module_seq):
 
 
 def _wgrad(d, x, out):
+    """out[n, k] = d^T[n, B] x[B, k]: the split-rows MFMA kernel (`pbhc_linear_wgrad`) where its shape rules allow, else the library form."""
+    n, k = out.shape
+    B = d.shape[0]
+    if FUSED_GEMM and FUSED_WGRAD and d.is_cuda and d.dtype == torch.float32 and out.is_contiguous() and d.is_contiguous() and x.is_contiguous():
+        lib = _lib.lib()
+        P = lib.pbhc_linear_wgrad_parts(B, n, k)
+        if P > 0:
+            scratch = torch.empty(P * n * k, device=d.device)
+            _lib.check(lib.pbhc_linear_wgrad(d.data_ptr(), x.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, n, k, _lib.current_stream()), "pbhc_linear_wgrad")
+            return out
+    return _wgrad_library(d, x, out)
+
+
+def _wgrad_library(d, x, out):
     """out[n, k] = d^T[n, B] x[B, k].  With B (minibatch rows, 24 576) >> n, k the single GEMM has few output tiles and a very long K loop:
     rocBLAS / hipBLASLt run it on part of the chip (128 x 256: 53 us = 30 TFLOP/s on MI355X).  Split over P row chunks it is a batched GEMM that
     fills the 256 CUs, followed by a [P, n, k] sum (23 us for the same shape); measured with tools/wgrad_splitk_probe.py."""

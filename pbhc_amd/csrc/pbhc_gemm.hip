@@ -540,6 +540,157 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a Linear: dW[n, k] = sum_m dy[m, n] x[m, k] (autograd's `dy.t() @ x`, agents/modules/modules.py:47-63 under torch.autograd).
+// The reduction runs over the minibatch rows (24 576) and the output is small, so the rows are split over P workgroup groups that each write a
+// partial [N, K] image, summed in a fixed order by k_wgrad_sum (what the library path does as a split-K batched GEMM + torch.sum).
+// Tile: 64 (n) x 128 (k) per workgroup = 4 waves x (two 32x32 tiles); both operands are m-major, so both are staged as [m][cols] pieces by
+// LDS-DMA (A: 4 m rows x 64 n per 1 KiB piece, B: 2 m rows x 128 k) with the column chunk rotated by half a row for m rows with bit 2 set —
+// the two k halves of a wave's ds_read_b32 then sit 32 banks apart — and read with four ds_read_b32 per operand tile and k block.
+// Same VALU-free K loop as k_gemm2 (scalar stage advance, constant fragment addresses).  K % 4 != 0 (380- / 630-wide inputs): the chunk that
+// straddles a row's end is fetched from [K-4, K) and its columns are rotated back when the partial image is written.
+#define WG_BK 32
+#define WG_BM 64
+#define WG_BN 128
+__global__ __launch_bounds__(GEMM_T, 2) void k_wgrad(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
+                                                      int N, int K, int rows_per_part, int tiles_k) {
+  constexpr int A_STAGE = WG_BK * WG_BM, STAGE = WG_BK * (WG_BM + WG_BN);     // floats
+  constexpr int A_PIECES = A_STAGE / 256, PIECES = STAGE / 256, LPW = PIECES / 4;   // 8 + 16 pieces, 6 per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];                // 2 stages; reused by the epilogue image [64][132]
+  const int tile = blockIdx.x, p_idx = blockIdx.y;
+  const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+  const int n0 = tile_n * WG_BM, k0c = tile_k * WG_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, kk = lane >> 5;
+  const int nk = rows_per_part / WG_BK;
+  const float* dYp = dY + (size_t)p_idx * rows_per_part * N;
+  const float* Xp = X + (size_t)p_idx * rows_per_part * K;
+
+  unsigned voff[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int p = wave + 4 * i;                            // 24 pieces over 4 waves: no wrap
+    if (p < A_PIECES) {
+      const int row = p * 4 + (lane >> 4);                 // m row inside the stage
+      const int c = ((lane & 15) - 8 * ((row >> 2) & 1)) & 15;
+      const int col = min(n0 + 4 * c, N - 4);
+      voff[i] = ((unsigned)row * (unsigned)N + (unsigned)col) * 4u;
+    } else {
+      const int row = (p - A_PIECES) * 2 + (lane >> 5);
+      const int c = ((lane & 31) - 8 * ((row >> 2) & 1)) & 31;
+      const int col = min(k0c + 4 * c, K - 4);             // beyond the row's end (incl. the straddling chunk): [K-4, K), rotated back in the epilogue
+      voff[i] = ((unsigned)row * (unsigned)K + (unsigned)col) * 4u;
+    }
+  }
+  auto issue = [&](int st, auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    const char* sA = reinterpret_cast<const char*>(dYp + (size_t)st * WG_BK * N);
+    const char* sB = reinterpret_cast<const char*>(Xp + (size_t)st * WG_BK * K);
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int p = wave + 4 * i;
+      glds16_sv(p < A_PIECES ? sA : sB, voff[i], &lds[SLOT * STAGE + p * 256]);
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+  // constant per-lane fragment indices inside a stage (floats): m row part 4 kk, column rotated by 32 for the kk = 1 half
+  int fa[2], fb;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = 4 * kk * WG_BM + ((i * 32 + r + 32 * kk) & (WG_BM - 1));
+  fb = A_STAGE + 4 * kk * WG_BN + ((wave * 32 + r + 32 * kk) & (WG_BN - 1));
+
+  auto stage_body = [&](auto slot_c, int kb) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    wait_vmcnt<0>();
+    lds_barrier_raw();
+    if (kb + 1 < nk) issue(kb + 1, IC<(SLOT + 1) % 2>{});
+    f32x4 a[2][2], b[2];
+    auto read_frags = [&](int k8, f32x4 (&af)[2], f32x4& bf) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        af[0][s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BM + fa[0]];
+        af[1][s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BM + fa[1]];
+        bf[s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BN + fb];
+      }
+    };
+    read_frags(0, a[0], b[0]);
+#pragma unroll
+    for (int k8 = 0; k8 < WG_BK / 8; ++k8) {
+      if (k8 + 1 < WG_BK / 8) read_frags(k8 + 1, a[(k8 + 1) & 1], b[(k8 + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k8 & 1][i][s], b[k8 & 1][s], acc[i], 0, 0, 0);
+    }
+  };
+  issue(0, IC<0>{});
+  for (int kb = 0; kb < nk; kb += 2) {
+    stage_body(IC<0>{}, kb);
+    if (kb + 1 < nk) stage_body(IC<1>{}, kb + 1);
+  }
+
+  // ---- epilogue: accumulators -> [64][132] image -> partial[p][n][k] with 16-byte stores ----
+  constexpr int CS = WG_BN + 4;
+  lds_barrier_raw();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[(i * 32 + 8 * (e >> 2) + 4 * kk + (e & 3)) * CS + wave * 32 + r] = acc[i][e];
+  lds_barrier_raw();
+  float* out = part + (size_t)p_idx * N * K;
+  const int c4 = (tid & 31) * 4, rr = tid >> 5;            // 8 rows per pass
+  const int col = k0c + c4;
+  const int rem = K & 3;
+  const bool straddle = rem != 0 && col < K && col + 4 > K;
+#pragma unroll
+  for (int p = 0; p < WG_BM / 8; ++p) {
+    const int row = n0 + p * 8 + rr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(p * 8 + rr) * CS + c4]);
+    if (row < N && col < K) {
+      float* cp = out + (size_t)row * K + col;
+      if (!straddle) {
+        reinterpret_cast<F4U*>(cp)->v = v;
+      } else {                                             // this chunk was computed on x[:, K-4 .. K): column col + q sits at slot q + 4 - rem
+        cp[0] = rem == 1 ? v[3] : rem == 2 ? v[2] : v[1];
+        if (rem >= 2) cp[1] = rem == 2 ? v[3] : v[2];
+        if (rem == 3) cp[2] = v[3];
+      }
+    }
+  }
+}
+
+// dW[i] = sum_p part[p][i], p in order (deterministic); 16 bytes per lane
+__global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ part, float* __restrict__ dW, int n, int P) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {
+      f32x4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = reinterpret_cast<const F4U*>(part + (size_t)(p + u) * n + i)->v;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += q[u];
+    }
+    for (; p < P; ++p) s += reinterpret_cast<const F4U*>(part + (size_t)p * n + i)->v;
+    reinterpret_cast<F4U*>(dW + i)->v = s;
+  } else {
+    for (int j = i; j < n; ++j) {
+      float s = 0.0f;
+      for (int p = 0; p < P; ++p) s += part[(size_t)p * n + j];
+      dW[j] = s;
+    }
+  }
+}
+
 static int g_dbg = 0;
 template <int MODE, int WM, int WN, int TM, int TN, int BK>
 static hipError_t gemm_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
@@ -643,6 +794,38 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
   if (num_row_blocks) *num_row_blocks = nb;
   // A = dy [M, K] (K = out_features of the layer, the reduction), B = W [K, N] (N = in_features, contiguous)
   GEMM_HIP(gemm_dispatch<1>(shape, dy, w, nullptr, saved, dx, nullptr, scratch, M, N, K, act, (hipStream_t)stream));
+  return PBHC_OK;
+}
+
+
+int pbhc_linear_wgrad_parts(int M, int N, int K) {
+  // number of row groups: as many workgroups as fill 768 slots (3 per CU) in whole rounds, every group a multiple of 32 rows
+  if (M < 32 || (M & 31) || N < 4 || (N & 3) || K < 4) return 0;
+  const int tiles = ((N + WG_BM - 1) / WG_BM) * ((K + WG_BN - 1) / WG_BN);
+  const int stages = M / WG_BK;
+  int best = 0;
+  for (int P = 1; P <= 128 && P <= stages; ++P) {
+    if (stages % P) continue;
+    if ((long)tiles * P > 768 && best) break;
+    if (stages / P < 4) break;                             // at least four K stages per workgroup
+    best = P;
+    if ((long)tiles * P >= 768) break;
+  }
+  return best;
+}
+
+int pbhc_linear_wgrad(const float* dy, const float* x, float* dw, float* scratch, int M, int N, int K, void* stream) {
+  GEMM_ARG(dy && x && dw && scratch && M >= 1 && N >= 1 && K >= 1);
+  GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)x & 3) == 0);
+  const int P = pbhc_linear_wgrad_parts(M, N, K);
+  GEMM_ARG(P >= 1 && (size_t)M * (size_t)(N > K ? N : K) < (1u << 30));
+  hipStream_t st = (hipStream_t)stream;
+  const int tn = (N + WG_BM - 1) / WG_BM, tk = (K + WG_BN - 1) / WG_BN;
+  constexpr int LDS_BYTES = 2 * WG_BK * (WG_BM + WG_BN) * 4;     // 48 KB (the [64][132] image fits inside)
+  hipLaunchKernelGGL(k_wgrad, dim3(tn * tk, P), dim3(GEMM_T), LDS_BYTES, st, dy, x, scratch, N, K, M / P, tk);
+  const int n = N * K;
+  hipLaunchKernelGGL(k_wgrad_sum, dim3((n / 4 + 256) / 256), dim3(256), 0, st, scratch, dw, n, P);
+  GEMM_HIP(hipGetLastError());
   return PBHC_OK;
 }
 

@@ -117,3 +117,36 @@ def test_fused_mlp_with_and_without_the_fused_gemms(act_cls, monkeypatch):
     for a, b, c in zip(ref, new, old):
         scale = max(1.0, a.abs().max().item())
         assert (a - b).abs().max().item() < 2e-5 * scale and (a - c).abs().max().item() < 2e-5 * scale
+
+
+# (M, N = out_features, K = in_features): whole tiles; K with every remainder mod 4 (the rotated straddling chunk); N not a multiple of 64;
+# the update's shapes
+WGRAD_SHAPES = [(256, 64, 128), (512, 128, 37), (384, 72, 630), (1024, 128, 23), (640, 4, 5), (24576, 512, 380), (24576, 128, 256), (4096, 256, 130)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_linear_wgrad_matches_fp64(shape):
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    P = lib.pbhc_linear_wgrad_parts(M, N, K)
+    assert P >= 1 and (M // 32) % P == 0
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    scratch = torch.full((P * N * K,), float("nan"), device="cuda")
+    _lib.check(lib.pbhc_linear_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), scratch.data_ptr(), M, N, K, _lib.current_stream()), "wgrad")
+    ref = dy.double().t() @ x.double()
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6 * max(1.0, (M / 1024) ** 0.5)
+
+
+def test_linear_wgrad_parts_rejects_what_the_kernel_cannot_take():
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.pbhc_linear_wgrad_parts(24576, 23, 128) == 0          # out_features % 4
+    assert lib.pbhc_linear_wgrad_parts(1000, 64, 64) == 0            # rows % 32
+    assert lib.pbhc_linear_wgrad_parts(24576, 64, 3) == 0            # in_features < 4
+    assert lib.pbhc_linear_wgrad_parts(24576, 768, 630) == 12 and lib.pbhc_linear_wgrad_parts(24576, 512, 768) == 16

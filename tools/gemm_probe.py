@@ -97,6 +97,31 @@ def main():
             tot_lib += t_old
             tot_new += t_new
             print(f"dgrad {Kout:4d} -> {Nin:4d}: fused {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF/s)  library+actbwd {t_old:7.1f} us   err {err_new:.2e} / {err_old:.2e}  colsum rel {cs_err:.1e} ({nb.value} blocks)")
+        # wgrad: dW[out, in] = dy^T x over the M rows (library: the split-K batched form of fused_mlp._wgrad)
+        from pbhc_amd.agents.fused_mlp import _wgrad_library
+        for Nout, Kin in [(512, 380), (256, 512), (128, 256), (768, 630), (512, 768), (128, 512)]:
+            dy = torch.randn(M, Nout, device=dev)
+            x = torch.randn(M, Kin, device=dev)
+            dw = torch.empty(Nout, Kin, device=dev)
+            dw2 = torch.empty(Nout, Kin, device=dev)
+            P = lib.pbhc_linear_wgrad_parts(M, Nout, Kin)
+            scratch = torch.empty(max(P, 1) * Nout * Kin, device=dev)
+            st = _lib.current_stream()
+
+            def new():
+                _lib.check(lib.pbhc_linear_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), scratch.data_ptr(), M, Nout, Kin, st), "wgrad")
+
+            def old():
+                return _wgrad_library(dy, x, dw2)
+            new(); old()
+            ref = dy.double().t() @ x.double()
+            err_new = ((dw - ref).abs().max() / ref.abs().max()).item()
+            err_old = ((dw2 - ref).abs().max() / ref.abs().max()).item()
+            t_new, t_old = timeit(new), timeit(old)
+            fl = 2.0 * M * Nout * Kin
+            tot_lib += t_old
+            tot_new += t_new
+            print(f"wgrad {Nout:4d} x {Kin:4d}: fused {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF/s, {P} parts)  library {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF/s)   rel err {err_new:.2e} / {err_old:.2e}")
         print(f"sum: fused {tot_new:.0f} us   library {tot_lib:.0f} us")
         tot_lib = tot_new = 0.0
 
