@@ -329,7 +329,7 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase (GEMMs via rocBLAS + gather + Adam), fp32"},
+                                "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase, fp32: fused MFMA forward / input-gradient Linear kernels + library weight-gradient GEMMs + loss + gather + Adam"},
         }
         if dp:
             out["collectives"] = {"backend": backend, "all_reduces_per_iter": coll["all_reduce"] / K, "all_reduce_bytes_per_iter": coll["all_reduce_bytes"] / K,

@@ -19,3 +19,8 @@ find gpurun_out/prof2 -name "*kernel_stats.csv" | head
 find gpurun_out/prof2 -name "*kernel_trace.csv" -size +8M -delete
 find gpurun_out/prof2 -name "*counter_collection.csv" -size +8M -delete
 du -sh gpurun_out/prof2
+# fused fp32-MFMA Linear kernels against the library path, the K-loop ablation and the sustained MFMA peak of the box
+python3 tools/gemm_probe.py 24576 > gpurun_out/prof2/gemm_probe_24576.txt 2>&1
+python3 tools/gemm_probe.py 4096 > gpurun_out/prof2/gemm_probe_4096.txt 2>&1
+python3 tools/gemm_ablation.py 0 > gpurun_out/prof2/gemm_ablation.txt 2>&1
+python3 tools/mfma_peak_probe.py > gpurun_out/prof2/mfma_peak.txt 2>&1
