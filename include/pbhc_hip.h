@@ -198,6 +198,10 @@ typedef struct PbhcEnvConfig {
   float rfi_lim;
   /* domain randomisation ranges used on reset (legged_robot_base.py:599-635) */
   int32_t randomize_pd_gain, randomize_rfi_lim;
+  /* domain_rand.randomize_default_dof_pos (legged_robot_base.py:632-635): at every reset default_dof_pos[env] = raw default + U(dof_pos_range);
+   * needs PbhcStepIO.default_dof_pos (the per-env defaults, read by the torques and the dof_pos observation) */
+  int32_t randomize_default_dof_pos;
+  float dof_pos_range[2];
   float kp_range[2], kd_range[2], rfi_lim_range[2], rao_lim;
   int32_t ctrl_delay_range[2];
   /* body index sets (base_task.py:169-205, motion_tracking.py:203-232) */
@@ -306,6 +310,7 @@ typedef struct PbhcStepIO {
   const float* u_rfi;             /* [N,D] uniforms of the torque RFI noise                    */
   const float* ovr_start_time;    /* [N]   values consumed by resetting envs                   */
   const float* ovr_kp; const float* ovr_kd; const float* ovr_rfi_lim; const float* ovr_rao; /* [N,D] */
+  const float* ovr_dof_pos_bias;                                                          /* [N,D] the U(dof_pos_range) draw of randomize_default_dof_pos */
   const int64_t* ovr_delay;       /* [N]                                                       */
   /* simulator-surface state (reference names; simulator/isaacgym/isaacgym.py:574-618) */
   float* root_states;             /* [N,13] */
@@ -317,6 +322,7 @@ typedef struct PbhcStepIO {
   float* last_dof_pos; float* last_dof_vel; float* torques;                              /* [N,D] */
   float* feet_air_time; float* contacts; float* contacts_filt; float* last_contacts; float* last_contacts_filt; /* [N,F] */
   float* kp_scale; float* kd_scale; float* rfi_lim_scale; float* rao_scale;              /* [N,D] */
+  float* default_dof_pos;                                                                 /* [N,D] or NULL: per-env default joint angles (randomize_default_dof_pos); NULL -> PbhcEnvConfig.default_dof_pos */
   float* motion_start_times; float* motion_len; float* end_time_ratio_buf;               /* [N] */
   float* episode_sums;            /* [N,num_sum_cols] */
   float* hist;                    /* [N,hist_dim] */

@@ -172,7 +172,7 @@ class MotionTrackingOracle:
         s = self.s
         dr = self.cfg.domain_rand
         a = actions * self.action_scale
-        tq = s["kp_scale"] * self.p_gains * (a + self.default_dof_pos - s["dof_pos"]) - s["kd_scale"] * self.d_gains * s["dof_vel"]
+        tq = s["kp_scale"] * self.p_gains * (a + self._default(s) - s["dof_pos"]) - s["kd_scale"] * self.d_gains * s["dof_vel"]
         if dr.randomize_torque_rfi:
             tq = tq + (u_rfi * 2.0 - 1.0) * dr.rfi_lim * s["rfi_lim_scale"] * self.torque_limits
         if dr.use_rao:
@@ -360,6 +360,10 @@ class MotionTrackingOracle:
         if dr.randomize_ctrl_delay:
             s["action_queue"][ids] *= 0.0
             s["action_delay_idx"][ids] = samp["action_delay_idx"][ids]
+        if dr.get("randomize_default_dof_pos", False):          # legged_robot_base.py:632-635: default = raw default + U(dof_pos_range)
+            if "default_dof_pos" not in s:
+                s["default_dof_pos"] = self.default_dof_pos.repeat(self.N, 1).clone()
+            s["default_dof_pos"][ids] = samp["dof_pos_bias"][ids] + self.default_dof_pos
         rw = cfg.rewards
         if rw.reward_penalty_curriculum:                    # legged_robot_base.py:882-900
             if self.avg_ep_len < rw.reward_penalty_level_down_threshold:
@@ -412,6 +416,10 @@ class MotionTrackingOracle:
             self.sums[k][ids] = 0.0
 
     # ------------------------------------------------------------------------------------
+    def _default(self, s):
+        """default joint angles: per env once randomize_default_dof_pos has drawn them (legged_robot_base.py:632-635), else the config's"""
+        return s["default_dof_pos"] if "default_dof_pos" in s else self.default_dof_pos
+
     def _get(self, key):
         s = self.s
         if key.startswith("history_"):
@@ -419,7 +427,7 @@ class MotionTrackingOracle:
             return torch.cat([self.hist[k][:, : aux[k]].reshape(self.N, -1) for k in sorted(aux.keys())], dim=1)
         table = dict(
             base_lin_vel=lambda: self.base_lin_vel, base_ang_vel=lambda: self.base_ang_vel,
-            projected_gravity=lambda: self.projected_gravity, dof_pos=lambda: s["dof_pos"] - self.default_dof_pos,
+            projected_gravity=lambda: self.projected_gravity, dof_pos=lambda: s["dof_pos"] - self._default(s),
             dof_vel=lambda: s["dof_vel"], actions=lambda: s["actions"], ref_motion_phase=lambda: self.ref_motion_phase,
             dif_local_rigid_body_pos=lambda: self.obs_dif_local_rigid_body_pos,
             local_ref_rigid_body_pos=lambda: self.obs_local_ref_rigid_body_pos, vr_3point_pos=lambda: self.obs_vr_3point_pos,

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const float start = io.motion_start_times[envc];
 
   // role-A registers that live across phases
-  float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, etr_old = 0.0f;
+  float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, dpA = 0.0f, etr_old = 0.0f;
   int pf_tid = 0, pf_tpen = 0, pf_tsrc = -1, pf_colterm = -1;
   long long adelay = 0;
   // role-B registers that live across phases (loads issued in its prologue, consumed after bar1)
@@ -699,6 +699,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
       pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE]; pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
       kpA = at(io.kp_scale, eDc + dc); kdA = at(io.kd_scale, eDc + dc);                // phase H (a reset replaces them in registers)
+      dpA = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
     }
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
     }
     // per-dof constants of the config: one batch of loads at the head of the interval
-    k_tl = c.torque_limits[dc]; k_dp = c.default_dof_pos[dc];
+    k_tl = c.torque_limits[dc]; k_dp = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
     const float k_pg = c.p_gains[dc], k_dg = c.d_gains[dc], k_as = c.action_scale[dc];
     // ---- _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
     if (c.randomize_torque_rfi && io.u_rfi) u_rfi = u_inj;
@@ -1305,6 +1306,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
           at(io.rao_scale, eD + dd) = io.ovr_rao ? at(io.ovr_rao, eD + dd) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
         if (c.randomize_ctrl_delay)
           for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
+        if (c.randomize_default_dof_pos && io.default_dof_pos) {    // legged_robot_base.py:632-635 (its own Philox stream: off in the shipped yamls)
+          float ub[4];
+          pbhc::rng_uniform4(rt.seed, env, step_ctr, 9, dd, ub);
+          const float bias = io.ovr_dof_pos_bias ? at(io.ovr_dof_pos_bias, eD + dd) : (c.dof_pos_range[1] - c.dof_pos_range[0]) * ub[0] + c.dof_pos_range[0];
+          dpA = bias + c.default_dof_pos[dd];
+          at(io.default_dof_pos, eD + dd) = dpA;
+        }
       }
       if (lane == 0) {
         misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
@@ -1357,7 +1365,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
       const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
       for (int dd = lane; dd < D; dd += PBHC_G) {
-        feat[o_q + dd] = q[dd] - c.default_dof_pos[dd];
+        feat[o_q + dd] = q[dd] - dpA;                            // (a reset replaced it in registers, like kpA)
         feat[o_qd + dd] = qd[dd];
         feat[o_a + dd] = act[dd];
         feat[o_kp + dd] = kpA;                                   // D <= 32: lane dd owns dof dd in the prologue load and in the reset path alike

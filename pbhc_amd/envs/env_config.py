@@ -159,8 +159,9 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     for unsupported in ("parallel_serial_pd", "parallel_serial_tau"):
         if unsupported in dr and dr[unsupported].get("enable", False):
             raise NotImplementedError(f"domain_rand.{unsupported}")
-    if dr.get("randomize_default_dof_pos", False):
-        raise NotImplementedError("domain_rand.randomize_default_dof_pos")
+    c.randomize_default_dof_pos = int(bool(dr.get("randomize_default_dof_pos", False)))     # legged_robot_base.py:632-635
+    if c.randomize_default_dof_pos:
+        c.dof_pos_range[0], c.dof_pos_range[1] = float(dr.dof_pos_range[0]), float(dr.dof_pos_range[1])
     # ---- body index sets
     names = skel.body_names
     ext = skel.body_names_ext

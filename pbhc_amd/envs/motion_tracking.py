@@ -202,6 +202,7 @@ class LeggedRobotMotionTracking:
         Bx = self.skeleton.num_bodies_ext
         self.ref_body_pos_extend, self.ref_body_rot_extend = f(N, Bx, 3), f(N, Bx, 4)
         self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(D)], device=dev).repeat(N, 1)
+        self.raw_default_dof_pos = self.default_dof_pos.clone()                    # legged_robot_base.py:81-93
         self.p_gains = torch.tensor([self._c.p_gains[i] for i in range(D)], device=dev)
         self.d_gains = torch.tensor([self._c.d_gains[i] for i in range(D)], device=dev)
 
@@ -257,6 +258,7 @@ class LeggedRobotMotionTracking:
         io.feet_air_time, io.contacts, io.contacts_filt = p(self.feet_air_time), p(self.contacts), p(self.contacts_filt)
         io.last_contacts, io.last_contacts_filt = p(self.last_contacts), p(self.last_contacts_filt)
         io.kp_scale, io.kd_scale, io.rfi_lim_scale, io.rao_scale = p(self._kp_scale), p(self._kd_scale), p(self._rfi_lim_scale), p(self._rao_scale)
+        io.default_dof_pos = p(self.default_dof_pos) if self._c.randomize_default_dof_pos else None      # per-env defaults only when they are randomised
         io.motion_start_times, io.motion_len, io.end_time_ratio_buf = p(self.motion_start_times), p(self.motion_len), p(self.end_time_ratio_buf)
         io.episode_sums, io.hist = p(self._episode_sums), p(self._hist)
         io.episode_length_buf, io.last_episode_length_buf = p(self._episode_length_buf), p(self.last_episode_length_buf)
@@ -293,9 +295,10 @@ class LeggedRobotMotionTracking:
             self._io.obs_pitch[i] = t.stride(0)
 
     # ---- test / replay hooks: inject the random draws instead of the in-kernel Philox ---------
-    def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None):
+    def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None, dof_pos_bias=None):
         """Keeps the tensors alive and points the kernel at them (None -> in-kernel RNG)."""
-        self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay)
+        self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay,
+                               ovr_dof_pos_bias=dof_pos_bias)
         for k, v in self._overrides.items():
             setattr(self._io, k, None if v is None else v.data_ptr())
 
@@ -421,6 +424,8 @@ class LeggedRobotMotionTracking:
         if dr.randomize_ctrl_delay:
             self.action_queue.zero_()
             self.action_delay_idx.copy_(torch.randint(dr.ctrl_delay_step_range[0], dr.ctrl_delay_step_range[1] + 1, (N,), device=dev, generator=self._gen))
+        if dr.get("randomize_default_dof_pos", False):                            # legged_robot_base.py:632-635
+            self.default_dof_pos.copy_(u(dr.dof_pos_range[0], dr.dof_pos_range[1]) + self.raw_default_dof_pos)
 
     def step(self, actor_state):
         """legged_robot_base.py:239-265 — one fused launch."""

@@ -305,6 +305,13 @@ def test_env_step_noise_curriculum_follows_the_oracle():
     _env_step_vs_oracle(512, 4, overrides=ov, noise_curriculum=True)
 
 
+def test_env_step_randomized_default_dof_pos_matches_oracle():
+    """domain_rand.randomize_default_dof_pos (legged_robot_base.py:632-635; off in the shipped yamls): per-env default joint angles redrawn at
+    every reset; the torques of the following steps and the dof_pos observation use them."""
+    ov = {"domain_rand.randomize_default_dof_pos": True, "domain_rand.dof_pos_range": [-0.05, 0.05]}
+    _env_step_vs_oracle(512, 4, overrides=ov, default_bias=True)
+
+
 def test_observation_noise_scales_with_the_noise_curriculum():
     """With the curriculum on, every noisy element's amplitude is noise * scale * current_noise_curriculum_value (0.05 initially)."""
     N = 2048
@@ -338,7 +345,7 @@ def _lib_K():
     return _lib.K
 
 
-def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False):
+def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
@@ -389,11 +396,14 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         samp = dict(motion_start_times=torch.rand(N, generator=gen) * float(oml.motion_len[0]), kp_scale=0.9 + 0.2 * torch.rand(N, 23, generator=gen),
                     kd_scale=0.9 + 0.2 * torch.rand(N, 23, generator=gen), rfi_lim_scale=0.5 + torch.rand(N, 23, generator=gen),
                     rao_scale=0.1 * (torch.rand(N, 23, generator=gen) - 0.5), action_delay_idx=torch.randint(0, 3, (N,), generator=gen))
+        if default_bias:
+            samp["dof_pos_bias"] = 0.1 * (torch.rand(N, 23, generator=gen) - 0.5)
         frame = dict(root=root[k + 1], dof_pos=qp[k + 1], dof_vel=qv[k + 1], contact=cf[k + 1])
         body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
         o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp)
         env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
-                               rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]))
+                               rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]),
+                               dof_pos_bias=tg(samp["dof_pos_bias"]) if default_bias else None)
         obs, rew, reset, extras = env.step({"actions": tg(act)})
         torch.cuda.synchronize()
         w = f"step {k}: "
@@ -405,6 +415,9 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
+        if default_bias and "default_dof_pos" in orc.s:
+            close(env.default_dof_pos, orc.s["default_dof_pos"], 1e-7, w + "default_dof_pos")
+            assert float((orc.s["default_dof_pos"] - orc.default_dof_pos).abs().max()) > 0.01
         if noise_curriculum:
             assert orc.noise_curriculum and 0.0 < orc.noise_cur < 0.05
             close(torch.tensor(float(env.read_log()["current_noise_curriculum_value"])), torch.tensor(orc.noise_cur), 1e-9, w + "noise curriculum value")
