@@ -240,7 +240,9 @@ class MHPPO:
     def _setup_models_and_optimizer(self):
         c = self.config
         if "phase_embed" in c and c.phase_embed.type != "Original":
-            raise NotImplementedError("phase_embed actors are outside the hot path")
+            # the reference's branch (mh_ppo.py:127-142) constructs `PhaseAwareActorV2` / `PhaseAwareCriticV2`, which no file of the reference
+            # defines or imports: it raises NameError there, so there is no behaviour to reproduce
+            raise NotImplementedError("phase_embed.type != 'Original': the reference's PhaseAwareActorV2 / PhaseAwareCriticV2 do not exist (mh_ppo.py:127-142)")
         c.module_dict.critic["output_dim"][-1] = self.num_rew_fn
         self.actor = PPOActor(obs_dim_dict=self.algo_obs_dim_dict, module_config_dict=c.module_dict.actor, num_actions=self.num_act,
                               init_noise_std=c.init_noise_std).to(self.device)
