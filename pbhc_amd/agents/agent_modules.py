@@ -59,9 +59,14 @@ class _WindowConv1d(torch.autograd.Function):
         O = w.shape[0]
         L = (T - k) // s + 1
         wp = w.permute(0, 2, 1).reshape(O, k * Cin)                    # [O, (k, C)]
-        out = torch.empty(B, L, O, device=x.device, dtype=x.dtype)
+        # every window's GEMM writes a CONTIGUOUS [B, O] slab (an `out=` row-slice of [B, L, O] makes addmm broadcast-copy the bias into it
+        # first: one extra launch per window, 36 per optimiser step in the teacher); the bias is added once, in the pass that lays the
+        # slabs out time-major
+        buf = torch.empty(L, B, O, device=x.device, dtype=x.dtype)
+        wt = wp.t()
         for l in range(L):
-            torch.addmm(b, x[:, l * s:l * s + k, :].reshape(B, k * Cin), wp.t(), out=out[:, l, :])
+            torch.mm(x[:, l * s:l * s + k, :].reshape(B, k * Cin), wt, out=buf[l])
+        out = torch.add(buf.permute(1, 0, 2), b)                        # [B, L, O] contiguous
         ctx.save_for_backward(x, w)
         ctx.k, ctx.s = k, s
         return out
