@@ -175,7 +175,7 @@ class _FusedMLP(torch.autograd.Function):
             else:
                 ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device)), gb))
             have_partials = False
-            if i > 0 and ctx.fused and l.weight.is_contiguous():
+            if i > 0 and ctx.fused and l.weight.is_contiguous() and B <= 128 * MAXB:      # (row blocks of 128 at most: the column-sum scratch holds MAXB of them)
                 # d_below = (d W) * act'(output of the layer below) + its row-block column sums, in the GEMM's epilogue
                 k = l.in_features
                 dn = torch.empty(B, k, device=d.device)

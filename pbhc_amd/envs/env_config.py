@@ -549,7 +549,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     # already writes — stays with role 1.
     fut_lo = min([feat_off[n_] for n_ in feat_off if n_.startswith("FUT_")] or [1 << 30])
     fut_hi = max([feat_off[n_] + fdim[n_] for n_ in feat_off if n_.startswith("FUT_")] or [-1])
-    load = [0.1 * sum(len(m[2]) for m in maps), 0.0]
+    load = [float(_os.environ.get("PBHC_ROLE0_HANDICAP", "0.1")) * sum(len(m[2]) for m in maps), 0.0]    # (env var: measurement aid)
     for i in sorted(range(len(maps)), key=lambda i_: -len(maps[i_][2])):
         reads_future = any(fut_lo <= s_ < fut_hi for s_ in maps[i][2])
         r_ = 1 if (reads_future or load[1] <= load[0]) else 0
