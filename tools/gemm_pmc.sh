@@ -1,3 +1,4 @@
+# PMC counters (SQ wait / busy, LDS conflicts, TA, L2 hits) of one fused-GEMM configuration: bash tools/gemm_pmc.sh N K shape variant
 set -e
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
