@@ -44,6 +44,53 @@ def _linear(x, lin):
     return F.linear(x, lin.weight, lin.bias)
 
 
+class _TallSkinnyLinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) for the encoders' per-time-step Linear (x: [rows x time steps, d], ~5e5 rows): the forward is ONE fp32-MFMA GEMM with bias
+    + ReLU in its epilogue (`pbhc_linear_act_fwd`; the library ran GEMM, then a clamp pass over the [5e5, 60] output), the backward masks the
+    incoming gradient and sums the bias gradient in one pass (`pbhc_act_bwd_bias`; autograd ran threshold_backward + a column sum), the weight
+    gradient keeps the split-K batched form of _TallSkinnyLinear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from .. import _lib
+
+        K, n = x.shape[0], w.shape[0]
+        y = torch.empty(K, n, device=x.device)
+        _lib.check(_lib.lib().pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, K, n, x.shape[1], 3, _lib.current_stream()),
+                   "pbhc_linear_act_fwd")
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+
+        x, w, y = ctx.saved_tensors
+        K, n = y.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)                                          # out of place: the incoming gradient stays the caller's
+        gb = torch.empty(n, device=y.device)
+        scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * n, device=y.device)
+        _lib.check(_lib.lib().pbhc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), K, n, 3, dz.data_ptr(), gb.data_ptr(), scratch.data_ptr(), _lib.current_stream()),
+                   "pbhc_act_bwd_bias")
+        dx = dz @ w if ctx.needs_input_grad[0] else None
+        P = 1
+        while P < 512 and K % (2 * P) == 0 and K // (2 * P) >= 256:
+            P *= 2
+        dw = torch.bmm(dz.view(P, K // P, -1).transpose(1, 2), x.view(P, K // P, -1)).sum(0)
+        return dx, dw, gb
+
+
+def _linear_relu(x, lin):
+    """F.relu(lin(x)) for a tall input."""
+    from . import fused_mlp
+
+    if fused_mlp.FUSED_GEMM and x.is_cuda and x.dtype == torch.float32 and lin.bias is not None and lin.weight.is_contiguous():
+        if x.requires_grad or lin.weight.requires_grad:
+            return _TallSkinnyLinearReLU.apply(x.contiguous(), lin.weight, lin.bias)
+    return F.relu(_linear(x, lin))
+
+
 class _WindowConv1d(torch.autograd.Function):
     """nn.Conv1d(C -> O, kernel k, stride s, no padding) on x [B, T, C] (time-major rows, the layout the per-step Linear produces) -> [B, L, O].
 
@@ -140,7 +187,7 @@ class ConvEncoder(nn.Module):
         if not (x.is_cuda if self.unfold_gemm is None else self.unfold_gemm):
             h = self.encoder(x.reshape(-1, self.input_dim)).view(B, self.time_steps, self.hidden_dim).permute(0, 2, 1)
             return self.output_layer(self.conv_module(h).flatten(start_dim=1))
-        x = F.relu(_linear(x.reshape(-1, self.input_dim), self.encoder[0])).view(B, self.time_steps, self.hidden_dim)   # [B, T, H]: x.view(-1, input_dim) chunks, sic
+        x = _linear_relu(x.reshape(-1, self.input_dim), self.encoder[0]).view(B, self.time_steps, self.hidden_dim)   # [B, T, H]: x.view(-1, input_dim) chunks, sic
         for i, s in enumerate(self._strides):
             conv = self.conv_module[2 * i]
             k = conv.kernel_size[0]

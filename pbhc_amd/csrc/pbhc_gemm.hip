@@ -758,6 +758,7 @@ static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const
 // 96-row tiles then put exactly one tile on each of the 256 CUs (24 576 = 256 x 96).
 static int pick_shape(int M, int N, int forced, bool forward) {
   if (forced >= 0 && forced <= 3) return forced;
+  if (forward && N <= 64) return 3;                        // one 64-column tile holds every output column (the encoders' 60- / 30-wide per-step Linear)
   if (N <= 128 && M % 96 == 0 && (M / 96) % 256 == 0) return 1;
   // few rows (the rollout's 4 096-row policy / critic forward): 64 x 64 tiles keep every CU busy where 64 x 128 tiles would leave fewer than two
   // workgroups per CU (measured at 4 096 rows: the six hidden layers 139 us against 181 us for library GEMM + ELU)
