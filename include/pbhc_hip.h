@@ -460,6 +460,12 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
  *   pre[M,N] (may be NULL) = x . w^T + bias            the pre-activation, which SiLU's derivative needs
  * x, w row-major, contiguous (rows need 4-byte alignment only).  f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
 int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream);
+/* The same with row strides and a batch: batch b computes y[b] = act(x[b] . w^T + bias) with x[b] = x + b * x_batch_stride (rows lda floats
+ * apart, lda >= K), y[b] = y + b * y_batch_stride (rows ldc floats apart, ldc >= N), one weight matrix for all — e.g. the L output positions of
+ * nn.Conv1d(C -> O, kernel k, stride s) on time-major activations [B, T, C] (encoder_modules.py:60-107): window l is the [B, k*C] matrix at
+ * x + l*s*C with lda = T*C, written to out[:, l, :] of [B, L, O] (y + l*O, ldc = L*O).  K >= 4. */
+int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_stride, const float* w, const float* bias, float* y, float* pre, int ldc,
+                                long long y_batch_stride, int batches, int M, int N, int K, int act, void* stream);
 /* The input gradient of that Linear with the activation backward of the layer BELOW folded in (what autograd runs as mm + elu_backward /
  * silu_backward + a column sum; replaces `dy @ w` + pbhc_act_bwd_partials):
  *   dx[M,N] = (dy[M,K] . w[K,N]) * act'(saved[M,N])   N = in_features, K = out_features; saved = the lower layer's activation OUTPUT

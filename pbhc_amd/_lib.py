@@ -87,7 +87,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
-           "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts"]
+           "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided"]
 
 
 class PbhcError(RuntimeError):
@@ -127,6 +127,7 @@ def _load():
     lib.pbhc_linear_dgrad_act.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int), i, i, i, i, vp]
     lib.pbhc_gemm_debug_force_shape.argtypes = [i]
     lib.pbhc_linear_wgrad_parts.argtypes = [i, i, i]
+    lib.pbhc_linear_act_fwd_strided.argtypes = [vp, i, C.c_longlong, vp, vp, vp, vp, i, C.c_longlong, i, i, i, i, i, vp]
     lib.pbhc_linear_wgrad.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.pbhc_gemm_debug_force_shape.restype = None
     lib.pbhc_adam_clip.argtypes = [vp, vp, vp, vp, i, vp, vp, f, f, f, f, f, vp, vp, vp]

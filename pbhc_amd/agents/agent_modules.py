@@ -144,6 +144,62 @@ class _WindowConv1d(torch.autograd.Function):
         return dx, dw, dy.sum((0, 1)), None, None
 
 
+class _WindowConv1dAct(torch.autograd.Function):
+    """act(nn.Conv1d(C -> O, k, s)(x)) on time-major x [B, T, C] -> [B, L, O] with the L window GEMMs of _WindowConv1d in ONE launch of the fused
+    fp32-MFMA kernel (`pbhc_linear_act_fwd_strided`: window l is the strided matrix x + l*s*C with row stride T*C, written straight into
+    out[:, l, :]; bias + ReLU / SiLU in the epilogue) — instead of L library GEMMs, a bias / layout pass and an activation pass.  Backward: the
+    activation derivative and the bias gradient in one pass (`pbhc_act_bwd_bias` over the [B*L, O] rows), then _WindowConv1d's window loops."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, s, act):
+        from .. import _lib
+
+        B, T, Cin = x.shape
+        O = w.shape[0]
+        L = (T - k) // s + 1
+        wp = w.permute(0, 2, 1).reshape(O, k * Cin).contiguous()        # [O, (k, C)]
+        out = torch.empty(B, L, O, device=x.device)
+        pre = torch.empty_like(out) if act == 2 else None               # SiLU' needs the pre-activation
+        _lib.check(_lib.lib().pbhc_linear_act_fwd_strided(x.data_ptr(), T * Cin, s * Cin, wp.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                          pre.data_ptr() if pre is not None else None, L * O, O, L, B, O, k * Cin, act,
+                                                          _lib.current_stream()), "pbhc_linear_act_fwd_strided")
+        ctx.save_for_backward(x, w, pre if pre is not None else out)
+        ctx.k, ctx.s, ctx.act = k, s, act
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+
+        x, w, saved = ctx.saved_tensors
+        k, s = ctx.k, ctx.s
+        B, T, Cin = x.shape
+        O = w.shape[0]
+        L = dy.shape[1]
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)
+        gb = torch.empty(O, device=dy.device)
+        scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * O, device=dy.device)
+        _lib.check(_lib.lib().pbhc_act_bwd_bias(dy.data_ptr(), saved.data_ptr(), B * L, O, ctx.act, dz.data_ptr(), gb.data_ptr(), scratch.data_ptr(),
+                                                _lib.current_stream()), "pbhc_act_bwd_bias")
+        wp = w.permute(0, 2, 1).reshape(O, k * Cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            for l in range(L):                                           # overlapping windows: sequential accumulation
+                dx[:, l * s:l * s + k, :].reshape(B, k * Cin).addmm_(dz[:, l, :], wp)
+        P = 1
+        while P < 64 and B % (2 * P) == 0 and B // (2 * P) >= 256:
+            P *= 2
+        part = None
+        for l in range(L):
+            a = x[:, l * s:l * s + k, :].reshape(B, k * Cin).view(P, B // P, k * Cin)
+            g = dz[:, l, :].view(P, B // P, O).transpose(1, 2)
+            part = torch.bmm(g, a) if part is None else torch.baddbmm(part, g, a, out=part)
+        dw = part.sum(0).view(O, k, Cin).permute(0, 2, 1)
+        return dx, dw, gb, None, None, None
+
+
 _CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
 
 
@@ -192,6 +248,13 @@ class ConvEncoder(nn.Module):
             conv = self.conv_module[2 * i]
             k = conv.kernel_size[0]
             if torch.is_grad_enabled():
+                from . import fused_mlp
+
+                act_id = fused_mlp._ACT_ID.get(type(self._act), 0)
+                if fused_mlp.FUSED_GEMM and x.is_cuda and act_id in (1, 2, 3) and x.dtype == torch.float32 and conv.bias is not None and k * x.shape[2] >= 4 \
+                        and not (act_id == 1 and self._act.alpha != 1.0):
+                    x = _WindowConv1dAct.apply(x.contiguous(), conv.weight, conv.bias, k, s, act_id)   # [B, L, O], activation included
+                    continue
                 x = self._act(_WindowConv1d.apply(x.contiguous(), conv.weight, conv.bias, k, s))       # [B, L, O]
             else:
                 # rollout (4096 rows, inside a captured graph): one GEMM over the unfolded copy beats L small ones

@@ -270,7 +270,12 @@ template <int V> struct IC { static constexpr int value = V; };
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                       const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ Pre, float* __restrict__ part,
-                                                      int M, int N, int K, int act, int tiles_n, int dbg) {
+                                                      int M, int N, int K, int act, int tiles_n, int dbg, int lda, int ldc, long long a_batch, long long c_batch) {
+  // MODE 0 only: row strides of A / of the outputs (floats; lda >= K, ldc >= N) and a batch over blockIdx.y with element strides a_batch / c_batch
+  // — the L output positions of a Conv1d window GEMM in one launch (agents/agent_modules.py).  MODE 1 is launched with lda = K, ldc = N, one batch.
+  A += (size_t)blockIdx.y * a_batch;
+  Cout += (size_t)blockIdx.y * c_batch;
+  if (Pre) Pre += (size_t)blockIdx.y * c_batch;
   const long long dbg_c0 = (dbg & 8) ? clock64() : 0, dbg_w0 = (dbg & 8) ? wall_clock64() : 0;
   static_assert(WM * WN == 4, "four waves");
   static_assert(BK == 16 || BK == 32, "BK");
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     piece_geom(i, q, c, kc, isA);
     if (kc) {
       const int grow = min((isA ? row0 : col0) + q, (isA ? M : N) - 1);
-      voff[i] = ((unsigned)grow * (unsigned)K + 4u * c) * 4u;
+      voff[i] = ((unsigned)grow * (unsigned)(isA ? lda : K) + 4u * c) * 4u;
     } else {
       voff[i] = ((unsigned)q * (unsigned)N + (unsigned)min(col0 + 4 * c, N - 4)) * 4u;
     }
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         const float* g;
         if (kc) {
           const int grow = min((isA ? row0 : col0) + q, (isA ? M : N) - 1);
-          const float* rowbase = (isA ? A : B) + (size_t)grow * K;
+          const float* rowbase = (isA ? A : B) + (size_t)grow * (isA ? lda : K);
           const int gk = k0 + 4 * c;
           g = gk + 4 <= K ? rowbase + gk : gk < K ? rowbase + (K - 4) : g_gemm_zeros;
         } else {
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     constexpr int NP = BM / RP;
     const int c4 = (tid % (BN / 4)) * 4, rr = tid / (BN / 4);
     const int col = col0 + c4;
-    const bool vec = (N & 3) == 0;                         // whole 16-byte pieces (rows stay 16-byte aligned relative to the base)
+    const bool vec = (N & 3) == 0;                         // whole 16-byte pieces inside the row (dword-aligned 16-byte accesses)
     const bool cok = vec ? col < N : col < N;              // first column inside
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 0 && bias) {
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += bv[q];
         if (Pre && ok) {
-          float* pp = Pre + (size_t)row * N + col;
+          float* pp = Pre + (size_t)row * ldc + col;
           if (vec) reinterpret_cast<F4U*>(pp)->v = v;
           else {
 #pragma unroll
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(act, sv[p][q]);
       }
       if (ok) {
-        float* cp = Cout + (size_t)row * N + col;
+        float* cp = Cout + (size_t)row * ldc + col;
         if (vec) reinterpret_cast<F4U*>(cp)->v = v;
         else {
 #pragma unroll
@@ -714,7 +719,7 @@ static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; 
 
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
-                               hipStream_t st) {
+                               hipStream_t st, int lda = 0, int ldc = 0, long long a_batch = 0, long long c_batch = 0, int batches = 1) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int RING_BYTES = NS * (BM + BN) * BK * 4, IMAGE_BYTES = BM * (BN + 4) * 4;   // K stages; the epilogue's [BM][BN + 4] image
   constexpr int LDS_BYTES = RING_BYTES > IMAGE_BYTES ? RING_BYTES : IMAGE_BYTES;
@@ -725,7 +730,8 @@ static hipError_t gemm2_launch(const float* A, const float* B, const float* bias
     attr_set = true;
   }
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, pre, part, M, N, K, act, tn, g_dbg);
+  hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn, batches), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, pre, part, M, N, K, act, tn, g_dbg,
+                     lda ? lda : K, ldc ? ldc : N, a_batch, c_batch);
   return hipGetLastError();
 }
 
@@ -798,6 +804,22 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
   return PBHC_OK;
 }
 
+
+int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_stride, const float* w, const float* bias, float* y, float* pre, int ldc,
+                                long long y_batch_stride, int batches, int M, int N, int K, int act, void* stream) {
+  GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 4 && act >= 0 && act <= 3 && lda >= K && ldc >= N && batches >= 1 && batches <= 65535);
+  GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0 && x_batch_stride >= 0 && y_batch_stride >= 0);
+  GEMM_ARG((size_t)M * (size_t)lda < (1u << 30) && (size_t)N * (size_t)K < (1u << 30));      // 32-bit byte offsets inside one batch
+  hipStream_t st = (hipStream_t)stream;
+  const int shape = pick_shape(M, N, g_force_shape, true);
+  hipError_t e;
+  if (shape == 3) e = gemm2_launch<0, 2, 2, 1, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);
+  else if (shape == 1) e = gemm2_launch<0, 1, 4, 3, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);
+  else if (shape == 0) e = gemm2_launch<0, 2, 2, 2, 2, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);
+  else e = gemm2_launch<0, 1, 4, 2, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);
+  GEMM_HIP(e);
+  return PBHC_OK;
+}
 
 int pbhc_linear_wgrad_parts(int M, int N, int K) {
   // number of row groups: as many workgroups as fill 768 slots (3 per CU) in whole rounds, every group a multiple of 32 rows

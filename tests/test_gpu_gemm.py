@@ -150,3 +150,29 @@ def test_linear_wgrad_parts_rejects_what_the_kernel_cannot_take():
     assert lib.pbhc_linear_wgrad_parts(1000, 64, 64) == 0            # rows % 32
     assert lib.pbhc_linear_wgrad_parts(24576, 64, 3) == 0            # in_features < 4
     assert lib.pbhc_linear_wgrad_parts(24576, 768, 630) == 12 and lib.pbhc_linear_wgrad_parts(24576, 512, 768) == 16
+
+
+@pytest.mark.parametrize("cfg", [(257, 20, 60, 40, 6, 2), (300, 10, 30, 20, 4, 2), (64, 8, 40, 20, 4, 2), (130, 6, 20, 10, 2, 1)])
+@pytest.mark.parametrize("act_cls", [nn.ReLU, nn.SiLU, nn.ELU])
+def test_window_conv_strided_batch_matches_conv1d(cfg, act_cls):
+    """agents/agent_modules._WindowConv1dAct (one `pbhc_linear_act_fwd_strided` launch for the L output positions of an encoder Conv1d,
+    encoder_modules.py:60-107) against act(nn.Conv1d) under autograd: output, input gradient, weight and bias gradients."""
+    from pbhc_amd.agents import agent_modules as am
+    from pbhc_amd.agents import fused_mlp
+
+    B, T, C, O, k, s = cfg
+    torch.manual_seed(B + T)
+    conv = nn.Conv1d(C, O, k, s).cuda()
+    act = act_cls()
+    x = torch.randn(B, T, C, device="cuda", requires_grad=True)
+    L = (T - k) // s + 1
+    dout = torch.randn(B, L, O, device="cuda")
+    y_ref = act(conv(x.permute(0, 2, 1))).permute(0, 2, 1)
+    y_ref.backward(dout)
+    ref = [y_ref.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()]
+    x.grad = None; conv.weight.grad = None; conv.bias.grad = None
+    y = am._WindowConv1dAct.apply(x.contiguous(), conv.weight, conv.bias, k, s, fused_mlp._ACT_ID[act_cls])
+    y.backward(dout)
+    new = [y.detach(), x.grad, conv.weight.grad, conv.bias.grad]
+    for a, b in zip(ref, new):
+        assert a.shape == b.shape and (a - b).abs().max().item() < 3e-5 * max(1.0, a.abs().max().item())
