@@ -62,6 +62,9 @@ if hasattr(lib, "pbhc_debug_read_wg_times"):
     print(f"  workgroups {nwg}: entry  min {starts[0]:.2f} median {q(starts, .5):.2f} p99 {q(starts, .99):.2f} max {starts[-1]:.2f} us after the first")
     print(f"                  exit   min {ends[0]:.2f} median {q(ends, .5):.2f} p99 {q(ends, .99):.2f} max {ends[-1]:.2f} us")
     print(f"                  in-kernel time per workgroup: min {durs[0]:.2f} median {q(durs, .5):.2f} p99 {q(durs, .99):.2f} max {durs[-1]:.2f} us")
+    if hasattr(lib, "pbhc_debug_read_stamps"):
+        d0 = (wt[1] - wt[0]) / 100.0
+        print(f"                  workgroup 0 (the one with the cycle stamps): {d0:.2f} us in the kernel for {st[12] - st[0]} shader cycles between its first and last stamp -> shader clock >= {(st[12] - st[0]) / d0:.0f} MHz")
     rb = env.reset_buf.cpu().view(-1)
     has = [bool(rb[4 * i:4 * i + 4].any()) for i in range(nwg)]
     d_all = [(wt[2 * i + 1] - wt[2 * i]) / 100.0 for i in range(nwg)]
