@@ -151,6 +151,7 @@ enum PbhcLog {
   PBHC_L_KEY_BODY_DIFF_NORM, PBHC_L_LOCAL_UPPER_BODY_DIFF_NORM, PBHC_L_LOCAL_LOWER_BODY_DIFF_NORM, PBHC_L_LOCAL_VR_3POINT_DIFF_NORM,
   PBHC_L_LOCAL_KEY_BODY_DIFF_NORM, PBHC_L_TERM_REF_POS_Z, PBHC_L_TERM_REF_ORI, PBHC_L_TERM_BODY_Z,
   PBHC_L_TERM_CONTACT, PBHC_L_TERM_LOW_HEIGHT,
+  PBHC_L_TERM_DOF_POS_LIMIT, PBHC_L_TERM_DOF_VEL_LIMIT, PBHC_L_TERM_TORQUE_LIMIT,
   PBHC_L_NUM
 };
 
@@ -272,6 +273,12 @@ typedef struct PbhcEnvConfig {
   int32_t terminate_by_contact, terminate_by_low_height;
   int32_t num_term_contact, term_contact[PBHC_MAX_IDX];
   float termination_min_base_height;
+  /* legged_robot_base.py:449-479: with probability term_close_prob[g] PER STEP (one draw for all envs) an env terminates when any joint is beyond
+   * its termination position limit (isaacgym.py:387-388), |dof_vel| > dof_vel_limits * term_close_vel_scale, |torque| > torque_limits * term_close_tau_scale */
+  int32_t terminate_close_pos, terminate_close_vel, terminate_close_tau;
+  float term_close_prob[3];
+  float dof_pos_limits_termination[PBHC_MAX_DOF][2];
+  float term_close_vel_scale, term_close_tau_scale;
   int32_t pad2_;
   uint64_t seed;
 } PbhcEnvConfig;
@@ -312,6 +319,7 @@ typedef struct PbhcStepIO {
   const float* ovr_kp; const float* ovr_kd; const float* ovr_rfi_lim; const float* ovr_rao; /* [N,D] */
   const float* ovr_dof_pos_bias;                                                          /* [N,D] the U(dof_pos_range) draw of randomize_default_dof_pos */
   const int64_t* ovr_delay;       /* [N]                                                       */
+  const float* ovr_gate_u;        /* [3]   the per-step uniforms of the terminate_when_close_to_* gates (pos, vel, torque) */
   /* simulator-surface state (reference names; simulator/isaacgym/isaacgym.py:574-618) */
   float* root_states;             /* [N,13] */
   float* dof_state;               /* [N,D,2] (pos, vel) */

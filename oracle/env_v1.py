@@ -193,7 +193,7 @@ class MotionTrackingOracle:
         self.sigma[key] = min(self.ema[key], self.sigma[key])        # type "origin" (motion_tracking.py:1046-1048)
 
     # ------------------------------------------------------------------------------------
-    def step(self, actions, frame, body_state, u_rfi=None, reset_samples=None):
+    def step(self, actions, frame, body_state, u_rfi=None, reset_samples=None, gate_u=None):
         """actions [N,D]; frame: dict(root[N,13], dof_pos, dof_vel, contact[N,B,3]) = the replay
         frame the sim switches to at the end of the physics step; body_state: (pos,rot,vel,ang)
         of the B bodies for that frame (oracle.fk.sim_fk of the frame); reset_samples: dict of
@@ -289,6 +289,25 @@ class MotionTrackingOracle:
             by["motion_far"] = torch.any(torch.norm(self.dif_pos, dim=-1) > self.motion_far_thr, dim=-1)
             reset |= by["motion_far"]
             log["terminate_when_motion_far_threshold"] = torch.tensor(self.motion_far_thr, dtype=torch.float)
+        # probabilistic terminations near the joint limits (legged_robot_base.py:449-479): one uniform per gate and step (`gate_u`), the same for
+        # all envs; position limits m -/+ 0.5 r scale from the hard limits (isaacgym.py:380-388)
+        TS, TP = ec.termination_scales, ec.get("termination_probality", {})
+        gu = [0.0, 0.0, 0.0] if gate_u is None else [float(v) for v in gate_u]
+        if T.get("terminate_when_close_to_dof_pos_limit", False):
+            lo = torch.tensor([float(v) for v in self.cfg.robot.dof_pos_lower_limit_list]); hi = torch.tensor([float(v) for v in self.cfg.robot.dof_pos_upper_limit_list])
+            m_, r_ = (lo + hi) / 2, hi - lo
+            lo_t, hi_t = m_ - 0.5 * r_ * TS.termination_close_to_dof_pos_limit, m_ + 0.5 * r_ * TS.termination_close_to_dof_pos_limit
+            out = (-(frame["dof_pos"] - lo_t).clip(max=0.0) + (frame["dof_pos"] - hi_t).clip(min=0.0)).sum(dim=1)
+            by["dof_pos_limit"] = (out > 0.0) if gu[0] < TP.terminate_when_close_to_dof_pos_limit else torch.zeros(N, dtype=torch.bool)
+            reset |= by["dof_pos_limit"]
+        if T.get("terminate_when_close_to_dof_vel_limit", False):
+            out = (frame["dof_vel"].abs() - self.dof_vel_limits * TS.termination_close_to_dof_vel_limit).clip(min=0.0, max=1.0).sum(dim=1)
+            by["dof_vel_limit"] = (out > 0.0) if gu[1] < TP.terminate_when_close_to_dof_vel_limit else torch.zeros(N, dtype=torch.bool)
+            reset |= by["dof_vel_limit"]
+        if T.get("terminate_when_close_to_torque_limit", False):
+            out = (s["torques"].abs() - self.torque_limits * TS.termination_close_to_torque_limit).clip(min=0.0, max=1.0).sum(dim=1)
+            by["torque_limit"] = (out > 0.0) if gu[2] < TP.terminate_when_close_to_torque_limit else torch.zeros(N, dtype=torch.bool)
+            reset |= by["torque_limit"]
         tout = s["episode_length_buf"] > self.max_episode_length
         by["time_out"] = tout
         if T.terminate_when_motion_end:

@@ -69,7 +69,7 @@ enum {
   P_UPPER_NORM = PBHC_NUM_SIGMA, P_LOWER_NORM, P_VR_NORM, P_JOINT_NORM, P_CLIP_CNT, P_RESET_CNT, P_TERM_GRAVITY, P_TERM_FAR,
   P_TERM_TIMEOUT, P_TERM_END, P_RESET_EPLEN, P_ETR_SUM, P_ETR_SQ, P_REW_SUM,
   P_KEY_NORM, P_LUP_NORM, P_LLO_NORM, P_LVR_NORM, P_LKEY_NORM, P_TERM_REFZ, P_TERM_REFORI, P_TERM_BODYZ,      // general tracking
-  P_TERM_CONTACT, P_TERM_LOWH,
+  P_TERM_CONTACT, P_TERM_LOWH, P_TERM_POSLIM, P_TERM_VELLIM, P_TERM_TAULIM,
   P_NUM
 };
 static_assert(P_NUM <= PBHC_NP, "partials");
@@ -120,9 +120,10 @@ enum {
   M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ,
   M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI,                     // general tracking: termination causes, anchor z / gravity-z differences
   M_CLIPCNT,                                                    // clipped actions of this step (role B -> reduction row)
-  M_TCONTACT, M_TLOWH                                           // termination causes: contact on a terminating body, low base height
+  M_TCONTACT, M_TLOWH,                                          // termination causes: contact on a terminating body, low base height
+  M_TPOSLIM, M_TVELLIM, M_TTAULIM, M_TGATE                      // ... close to a joint position / velocity / torque limit (role B), any of them
 };
-static_assert(M_TLOWH < 48, "MISC region");
+static_assert(M_TGATE < 48, "MISC region");
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
 // flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
@@ -671,6 +672,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   uint32_t nzb[4];
   float a_in = 0, qp = 0, qv = 0, kp = 1, kd = 1, rfs = 1, ras = 0, u_inj = 0, bmass = 1, lmreg = 0, combias = 0, fric = 0;
   float u_rfi = 0.5f, k_tl = 0.0f, k_dp = 0.0f, clipcnt = 0.0f;
+  // terminate_when_close_to_{dof_pos,dof_vel,torque}_limit (legged_robot_base.py:449-479; off in the shipped yamls): role B owns the joint-space
+  // quantities, so it raises these causes before bar2; role A folds them into the reset flag right after bar2, role B keeps its own copy
+  const bool close_any = c.terminate_close_pos || c.terminate_close_vel || c.terminate_close_tau;
+  bool gateB = false;
   long long adelayB = 0;
   int didx = 0;
   const u32 qoff = (u32)envc * (u32)(Q * D) + (u32)dc;
@@ -1056,6 +1061,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     const float k_lo = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][0] : c.soft_dof_pos_limits[dc][0];
     const float k_hi = c.soft_pos_curriculum ? c.hard_dof_pos_limits[dc][1] : c.soft_dof_pos_limits[dc][1];
     float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
+    float g_pos = 0.0f, g_vel = 0.0f, g_tau = 0.0f;
     if (valid) {
       // outputs of the PRE-reset reference (a reset rewrites the root entries of rp / rq after bar2)
       if (io.ref_body_pos_extend)
@@ -1088,6 +1094,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         s_lvel += clampf(fabsf(qd[dd]) - vlim, 0.0f, 1.0f);
         if (c.soft_tau_curriculum) s_ltau += clampf(fabsf(tau[dd]) - k_tl * soft_tau, 0.0f, 1.0f);
         else s_ltau += fmaxf(fabsf(tau[dd]) - k_tl * c.soft_torque_limit, 0.0f);
+        if (close_any) {                                      // legged_robot_base.py:449-479 (the gates' per-step draws: below)
+          if (c.terminate_close_pos && (q[dd] < c.dof_pos_limits_termination[dd][0] || q[dd] > c.dof_pos_limits_termination[dd][1])) g_pos = 1.0f;
+          if (c.terminate_close_vel && fabsf(qd[dd]) - k_vl * c.term_close_vel_scale > 0.0f) g_vel = 1.0f;
+          if (c.terminate_close_tau && fabsf(tau[dd]) - k_tl * c.term_close_tau_scale > 0.0f) g_tau = 1.0f;
+        }
       }
       for (int i = lane; i < c.num_penalised; i += PBHC_G)
         if (norm3(ld3(cf + 3 * c.penalised[i])) > 0.1f) s_coll += 1.0f;
@@ -1104,6 +1115,19 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     }
     GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
     s_maxjp = group_max(s_maxjp);
+    if (close_any) {
+      // one uniform per gate and STEP (torch.rand(1) < p on the host in the reference): keyed on the step counter only, the same for every env
+      float ug[4];
+      pbhc::rng_uniform4(rt.seed, 0xFFFFFFFFu, step_ctr, 11, 0, ug);
+      if (io.ovr_gate_u) { ug[0] = io.ovr_gate_u[0]; ug[1] = io.ovr_gate_u[1]; ug[2] = io.ovr_gate_u[2]; }
+      g_pos = (ug[0] < c.term_close_prob[0]) ? group_max(g_pos) : 0.0f;
+      g_vel = (ug[1] < c.term_close_prob[1]) ? group_max(g_vel) : 0.0f;
+      g_tau = (ug[2] < c.term_close_prob[2]) ? group_max(g_tau) : 0.0f;
+      gateB = valid && (g_pos != 0.0f || g_vel != 0.0f || g_tau != 0.0f);
+      if (valid && lane == 0) { misc[M_TPOSLIM] = g_pos; misc[M_TVELLIM] = g_vel; misc[M_TTAULIM] = g_tau; misc[M_TGATE] = gateB ? 1.0f : 0.0f; }
+      if (gateB)                                            // this env terminates: its history is zero in this step's observations (as role A does for its causes)
+        for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
+    }
     if (valid && lane == 0) {
       red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
       red[R_QACC2] = s_qacc2; red[R_LIMPOS] = s_lpos; red[R_LIMVEL] = s_lvel; red[R_LIMTAU] = s_ltau; red[R_COLL] = s_coll; red[R_CLIPCNT] = clipcnt;
@@ -1136,6 +1160,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   }
   LDS_BARRIER();                                               // bar2: both halves of the reduction row + termination flags are in LDS
   STAMP(5);
+  if (close_any && !roleB) {                                   // role A: role B's causes join the reset flag (every later reader of M_RESET in this wave follows)
+    if (valid && lane == 0 && misc[M_TGATE] != 0.0f) misc[M_RESET] = 1.0f;
+    WAVE_LDS_FENCE();
+  }
 
   const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals
   const int ngroups = c.num_groups;
@@ -1460,7 +1488,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     WAVE_LDS_FENCE();
     if (valid && map_words > 0) {
       // a surviving env: every pair; a terminated env: all but the pairs that read post-reset features (after bar3)
-      if (misc[M_RESET] != 0.0f) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
+      if (misc[M_RESET] != 0.0f || gateB) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
     }
     STAMPB(5);
   }
@@ -1550,6 +1578,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       bpq[P_ETR_SUM] = etr_val; bpq[P_ETR_SQ] = etr_val * etr_val;
       bpq[P_REW_SUM] = rew_total;
       bpq[P_TERM_CONTACT] = misc[M_TCONTACT]; bpq[P_TERM_LOWH] = misc[M_TLOWH];
+      if (close_any) { bpq[P_TERM_POSLIM] = misc[M_TPOSLIM]; bpq[P_TERM_VELLIM] = misc[M_TVELLIM]; bpq[P_TERM_TAULIM] = misc[M_TTAULIM]; }
       if (MODE) {
         bpq[P_KEY_NORM] = red[R_KEYN]; bpq[P_LUP_NORM] = red[R_LUPN]; bpq[P_LLO_NORM] = red[R_LLON]; bpq[P_LVR_NORM] = red[R_LVRN];
         bpq[P_LKEY_NORM] = red[R_LKEYN]; bpq[P_TERM_REFZ] = misc[M_REFZ]; bpq[P_TERM_REFORI] = misc[M_REFORI]; bpq[P_TERM_BODYZ] = misc[M_BODYZ];
@@ -1647,6 +1676,8 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
     L[PBHC_L_TERM_GRAVITY] = (tot[P_TERM_GRAVITY] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_FAR] = (tot[P_TERM_FAR] / N) / (rfrac + 1e-15);
     L[PBHC_L_TERM_TIME_OUT] = (tot[P_TERM_TIMEOUT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_MOTION_END] = (tot[P_TERM_END] / N) / (rfrac + 1e-15);
     L[PBHC_L_TERM_CONTACT] = (tot[P_TERM_CONTACT] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_LOW_HEIGHT] = (tot[P_TERM_LOWH] / N) / (rfrac + 1e-15);
+    L[PBHC_L_TERM_DOF_POS_LIMIT] = (tot[P_TERM_POSLIM] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_DOF_VEL_LIMIT] = (tot[P_TERM_VELLIM] / N) / (rfrac + 1e-15);
+    L[PBHC_L_TERM_TORQUE_LIMIT] = (tot[P_TERM_TAULIM] / N) / (rfrac + 1e-15);
     if (c.tracking_mode) {
       L[PBHC_L_TERM_REF_POS_Z] = (tot[P_TERM_REFZ] / N) / (rfrac + 1e-15); L[PBHC_L_TERM_REF_ORI] = (tot[P_TERM_REFORI] / N) / (rfrac + 1e-15);
       L[PBHC_L_TERM_BODY_Z] = (tot[P_TERM_BODYZ] / N) / (rfrac + 1e-15);

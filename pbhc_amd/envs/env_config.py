@@ -205,10 +205,27 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     L.feet, L.penalised, L.upper, L.lower, L.track, L.key = feet, pen, upper, lower, track, key_ids
     # ---- termination
     T = ec.termination
-    for flag in ("terminate_when_close_to_dof_pos_limit", "terminate_when_close_to_dof_vel_limit", "terminate_when_close_to_torque_limit",
-                 "terminate_when_dof_far"):
-        if T.get(flag, False):
-            raise NotImplementedError(f"termination.{flag}")
+    if T.get("terminate_when_dof_far", False):
+        raise NotImplementedError("termination.terminate_when_dof_far")
+    # legged_robot_base.py:449-479 + isaacgym.py:387-388: probabilistic terminations near the joint limits (one uniform per gate and STEP)
+    TS, TP = ec.termination_scales, ec.get("termination_probality", {})
+    c.terminate_close_pos = int(bool(T.get("terminate_when_close_to_dof_pos_limit", False)))
+    c.terminate_close_vel = int(bool(T.get("terminate_when_close_to_dof_vel_limit", False)))
+    c.terminate_close_tau = int(bool(T.get("terminate_when_close_to_torque_limit", False)))
+    if c.terminate_close_pos:
+        c.term_close_prob[0] = float(TP.terminate_when_close_to_dof_pos_limit)
+        for i in range(D):
+            lo, hi = np.float32(rc.dof_pos_lower_limit_list[i]), np.float32(rc.dof_pos_upper_limit_list[i])
+            m, r = np.float32((lo + hi) / np.float32(2)), np.float32(hi - lo)
+            sc = np.float32(TS.termination_close_to_dof_pos_limit)
+            c.dof_pos_limits_termination[i][0] = float(np.float32(m - np.float32(np.float32(0.5) * r) * sc))
+            c.dof_pos_limits_termination[i][1] = float(np.float32(m + np.float32(np.float32(0.5) * r) * sc))
+    if c.terminate_close_vel:
+        c.term_close_prob[1] = float(TP.terminate_when_close_to_dof_vel_limit)
+        c.term_close_vel_scale = float(TS.termination_close_to_dof_vel_limit)
+    if c.terminate_close_tau:
+        c.term_close_prob[2] = float(TP.terminate_when_close_to_torque_limit)
+        c.term_close_tau_scale = float(TS.termination_close_to_torque_limit)
     c.terminate_by_contact = int(bool(T.get("terminate_by_contact", False)))                 # legged_robot_base.py:434-436
     tcon = []
     for n in rc.get("terminate_after_contacts_on", []):                                     # base_task.py:178-180,195-197

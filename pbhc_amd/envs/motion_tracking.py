@@ -295,10 +295,10 @@ class LeggedRobotMotionTracking:
             self._io.obs_pitch[i] = t.stride(0)
 
     # ---- test / replay hooks: inject the random draws instead of the in-kernel Philox ---------
-    def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None, dof_pos_bias=None):
+    def set_injected_draws(self, u_rfi=None, start_time=None, kp=None, kd=None, rfi_lim=None, rao=None, delay=None, dof_pos_bias=None, gate_u=None):
         """Keeps the tensors alive and points the kernel at them (None -> in-kernel RNG)."""
         self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay,
-                               ovr_dof_pos_bias=dof_pos_bias)
+                               ovr_dof_pos_bias=dof_pos_bias, ovr_gate_u=gate_u)
         for k, v in self._overrides.items():
             setattr(self._io, k, None if v is None else v.data_ptr())
 
@@ -493,6 +493,10 @@ class LeggedRobotMotionTracking:
             out["terminate_by_contact"] = g[L0 + K["PBHC_L_TERM_CONTACT"]]
         if self._c.terminate_by_low_height:
             out["terminate_by_low_height"] = g[L0 + K["PBHC_L_TERM_LOW_HEIGHT"]]
+        for flag, key, name in ((self._c.terminate_close_pos, "PBHC_L_TERM_DOF_POS_LIMIT", "dof_pos_limit"), (self._c.terminate_close_vel, "PBHC_L_TERM_DOF_VEL_LIMIT", "dof_vel_limit"),
+                                (self._c.terminate_close_tau, "PBHC_L_TERM_TORQUE_LIMIT", "torque_limit")):
+            if flag:
+                out["terminate_by_" + name] = g[L0 + K[key]]
         for i, k in enumerate(env_config.SIGMA_KEYS):
             out["adp_sigma_" + k] = g[K["PBHC_G_SIGMA"] + i]
             out["error_ema_" + k] = g[K["PBHC_G_EMA"] + i]

@@ -305,6 +305,18 @@ def test_env_step_noise_curriculum_follows_the_oracle():
     _env_step_vs_oracle(512, 4, overrides=ov, noise_curriculum=True)
 
 
+def test_env_step_close_to_limit_terminations():
+    """termination.terminate_when_close_to_{dof_pos,dof_vel,torque}_limit (legged_robot_base.py:449-479; off in the shipped yamls): with a
+    per-step probability an env terminates when a joint is beyond its termination limit — the three gates' uniforms are injected (open / closed
+    per step and gate), the limits are tightened so that a part of the envs is beyond them; reset flags, rewards, observations and the per-cause
+    log means against the oracle."""
+    ov = {"env.config.termination.terminate_when_close_to_dof_pos_limit": True, "env.config.termination.terminate_when_close_to_dof_vel_limit": True,
+          "env.config.termination.terminate_when_close_to_torque_limit": True,
+          "env.config.termination_scales.termination_close_to_dof_pos_limit": 0.55, "env.config.termination_scales.termination_close_to_dof_vel_limit": 0.02,
+          "env.config.termination_scales.termination_close_to_torque_limit": 0.35}
+    _env_step_vs_oracle(512, 4, overrides=ov, gates=[[0.1, 0.9, 0.9], [0.9, 0.1, 0.9], [0.9, 0.9, 0.1], [0.2, 0.2, 0.2]])
+
+
 def test_env_step_randomized_default_dof_pos_matches_oracle():
     """domain_rand.randomize_default_dof_pos (legged_robot_base.py:632-635; off in the shipped yamls): per-env default joint angles redrawn at
     every reset; the torques of the following steps and the dof_pos observation use them."""
@@ -345,7 +357,7 @@ def _lib_K():
     return _lib.K
 
 
-def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False):
+def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False, gates=None):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
@@ -400,10 +412,11 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
             samp["dof_pos_bias"] = 0.1 * (torch.rand(N, 23, generator=gen) - 0.5)
         frame = dict(root=root[k + 1], dof_pos=qp[k + 1], dof_vel=qv[k + 1], contact=cf[k + 1])
         body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
-        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp)
+        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp, gate_u=gates[k] if gates else None)
         env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
                                rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]),
-                               dof_pos_bias=tg(samp["dof_pos_bias"]) if default_bias else None)
+                               dof_pos_bias=tg(samp["dof_pos_bias"]) if default_bias else None,
+                               gate_u=torch.tensor(gates[k], dtype=torch.float32, device=DEV) if gates else None)
         obs, rew, reset, extras = env.step({"actions": tg(act)})
         torch.cuda.synchronize()
         w = f"step {k}: "
@@ -415,6 +428,13 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
+        if gates:
+            log = env.read_log()
+            cause = ("dof_pos_limit", "dof_vel_limit", "torque_limit")[k] if k < 3 else None
+            for c_ in ("dof_pos_limit", "dof_vel_limit", "torque_limit"):
+                close(torch.tensor(log["terminate_by_" + c_]), orc.log["terminate_by_" + c_], 1e-5, w + "log terminate_by_" + c_)
+                if cause is not None:                                    # only the open gate may fire, and it does for a part of the envs
+                    assert (float(orc.log["terminate_by_" + c_]) > 0) == (c_ == cause), (k, c_, float(orc.log["terminate_by_" + c_]))
         if default_bias and "default_dof_pos" in orc.s:
             close(env.default_dof_pos, orc.s["default_dof_pos"], 1e-7, w + "default_dof_pos")
             assert float((orc.s["default_dof_pos"] - orc.default_dof_pos).abs().max()) > 0.01
