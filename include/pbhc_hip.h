@@ -487,7 +487,9 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
  * use the library) whose partial images go to `scratch` (parts * N * K floats) and are summed in a fixed order. */
 int pbhc_linear_wgrad_parts(int M, int N, int K);
 int pbhc_linear_wgrad(const float* dy, const float* x, float* dw, float* scratch, int M, int N, int K, void* stream);
-/* diagnosis: force the tile shape of the two entries above (0: 128x128, 1: 96x128, 2: 64x128; -1: automatic) */
+/* test / measurement aid for the Linear entries above.  shape < 0: everything automatic.  Otherwise bits 0-7: tile shape (0: 128x128, 1: 96x128,
+ * 2: 64x128, 3: 64x64 forward only, 0xff: automatic); bits 8-15: K-loop ablation flags (tools/gemm_ablation.py; results are wrong with parts
+ * off); bits 16-23: staging version (0: automatic, 1: register-staged version 1, 2: LDS-DMA with BK 16 x 3 stages). */
 void pbhc_gemm_debug_force_shape(int shape);
 
 /* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,

@@ -18,10 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["pbhc_amd/csrc/pbhc_kernels.hip", "pbhc_amd/csrc/pbhc_math.h", "include/pbhc_hip.h"]
 
 
+def _code_only(text):
+    """C / C++ source without comments and whitespace: what the compiler sees, so that editing documentation does not orphan a profile"""
+    import re
+
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def source_hash():
     h = hashlib.sha256()
     for f in SOURCES:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        h.update(_code_only(open(os.path.join(ROOT, f), "r").read()).encode())
     return h.hexdigest()[:16]
 
 
