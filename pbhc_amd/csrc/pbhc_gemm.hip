@@ -549,44 +549,49 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
 // Weight gradient of a Linear: dW[n, k] = sum_m dy[m, n] x[m, k] (autograd's `dy.t() @ x`, agents/modules/modules.py:47-63 under torch.autograd).
 // The reduction runs over the minibatch rows (24 576) and the output is small, so the rows are split over P workgroup groups that each write a
 // partial [N, K] image, summed in a fixed order by k_wgrad_sum (what the library path does as a split-K batched GEMM + torch.sum).
-// Tile: 64 (n) x 128 (k) per workgroup = 4 waves x (two 32x32 tiles); both operands are m-major, so both are staged as [m][cols] pieces by
-// LDS-DMA (A: 4 m rows x 64 n per 1 KiB piece, B: 2 m rows x 128 k) with the column chunk rotated by half a row for m rows with bit 2 set —
-// the two k halves of a wave's ds_read_b32 then sit 32 banks apart — and read with four ds_read_b32 per operand tile and k block.
-// Same VALU-free K loop as k_gemm2 (scalar stage advance, constant fragment addresses).  K % 4 != 0 (380- / 630-wide inputs): the chunk that
-// straddles a row's end is fetched from [K-4, K) and its columns are rotated back when the partial image is written.
+// Both operands are m-major (a row of dy / x per sample), i.e. the MFMA's reduction index runs across LDS rows.  Instead of gathering each
+// lane's four k values with 4-byte reads, the 32x32 tiles INTERLEAVE their rows: a lane reads 8 contiguous bytes of one m row — columns
+// 2i, 2i+1 — and feeds column 2i to tile 0 and column 2i+1 to tile 1 (tile q owns the output rows / columns = q mod 2).  One ds_read_b64 per
+// operand then serves four MFMAs of a k step (2 x 2 tiles), the reads of a 32-lane group are 256 contiguous bytes (conflict-free without a
+// swizzle), and the interleave is undone when the accumulators are written to the epilogue's LDS image.
+// Tile: 128 (n) x 128 (k) per workgroup = 2 x 2 waves of 64 x 64; stages of 32 rows by LDS-DMA (2 m rows per 1 KiB piece), 2-deep ring, two
+// workgroups per CU; same VALU-free K loop as k_gemm2.  K % 4 != 0 (380- / 630-wide inputs): the chunk that straddles a row's end is fetched
+// from [K-4, K) and its columns are rotated back when the partial image is written.
 #define WG_BK 32
-#define WG_BM 64
+#define WG_BM 128
 #define WG_BN 128
 __global__ __launch_bounds__(GEMM_T, 2) void k_wgrad(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
-                                                      int N, int K, int rows_per_part, int tiles_k) {
+                                                      int N, int K, int stages_total, int tiles_k, int tiles, int P) {
   constexpr int A_STAGE = WG_BK * WG_BM, STAGE = WG_BK * (WG_BM + WG_BN);     // floats
-  constexpr int A_PIECES = A_STAGE / 256, PIECES = STAGE / 256, LPW = PIECES / 4;   // 8 + 16 pieces, 6 per wave
-  extern __shared__ __attribute__((aligned(16))) float lds[];                // 2 stages; reused by the epilogue image [64][132]
-  const int tile = blockIdx.x, p_idx = blockIdx.y;
+  constexpr int A_PIECES = A_STAGE / 256, PIECES = STAGE / 256, LPW = PIECES / 4;   // 16 + 16 pieces, 8 per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];                // 2 stages (64 KB); reused by the epilogue image [128][132]
+  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs; the tiles of one row group read the same dy / x rows, so a
+  // row group lives on ONE XCD (its rows are fetched into that L2 once and hit by the group's other tiles) — P is a multiple of 8 when >= 8
+  int tile, p_idx;
+  if ((P & 7) == 0) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; p_idx = xcd + 8 * (slot / tiles); tile = slot - (slot / tiles) * tiles; }
+  else { p_idx = blockIdx.x / tiles; tile = blockIdx.x - p_idx * tiles; }
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * WG_BM, k0c = tile_k * WG_BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, kk = lane >> 5;
-  const int nk = rows_per_part / WG_BK;
-  const float* dYp = dY + (size_t)p_idx * rows_per_part * N;
-  const float* Xp = X + (size_t)p_idx * rows_per_part * K;
+  // this group's run of K stages (uneven split: any P fills the chip)
+  const int st0 = (int)((long long)p_idx * stages_total / P), st1 = (int)((long long)(p_idx + 1) * stages_total / P);
+  const int nk = st1 - st0;
+  const float* dYp = dY + (size_t)st0 * WG_BK * N;
+  const float* Xp = X + (size_t)st0 * WG_BK * K;
 
   unsigned voff[LPW];
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    const int p = wave + 4 * i;                            // 24 pieces over 4 waves: no wrap
-    if (p < A_PIECES) {
-      const int row = p * 4 + (lane >> 4);                 // m row inside the stage
-      const int c = ((lane & 15) - 8 * ((row >> 2) & 1)) & 15;
-      const int col = min(n0 + 4 * c, N - 4);
-      voff[i] = ((unsigned)row * (unsigned)N + (unsigned)col) * 4u;
-    } else {
-      const int row = (p - A_PIECES) * 2 + (lane >> 5);
-      const int c = ((lane & 31) - 8 * ((row >> 2) & 1)) & 31;
-      const int col = min(k0c + 4 * c, K - 4);             // beyond the row's end (incl. the straddling chunk): [K-4, K), rotated back in the epilogue
-      voff[i] = ((unsigned)row * (unsigned)K + (unsigned)col) * 4u;
-    }
+    const int p = wave + 4 * i;                            // 32 pieces over 4 waves: no wrap; a piece = 2 m rows x 128 columns
+    const bool isA = p < A_PIECES;
+    const int row = (isA ? p : p - A_PIECES) * 2 + (lane >> 5);
+    const int c = lane & 31;
+    // beyond the matrix (and the chunk that straddles a row's end): the last whole chunk of the row — never stored, or rotated back below
+    const int col = isA ? min(n0 + 4 * c, N - 4) : min(k0c + 4 * c, K - 4);
+    voff[i] = ((unsigned)row * (unsigned)(isA ? N : K) + (unsigned)col) * 4u;
   }
   auto issue = [&](int st, auto slot_c) {
     constexpr int SLOT = decltype(slot_c)::value;
@@ -599,55 +604,61 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_wgrad(const float* __restrict__ d
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-  // constant per-lane fragment indices inside a stage (floats): m row part 4 kk, column rotated by 32 for the kk = 1 half
-  int fa[2], fb;
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) fa[i] = 4 * kk * WG_BM + ((i * 32 + r + 32 * kk) & (WG_BM - 1));
-  fb = A_STAGE + 4 * kk * WG_BN + ((wave * 32 + r + 32 * kk) & (WG_BN - 1));
+      for (int e = 0; e < 16; ++e) acc[q][p][e] = 0.0f;
+  // constant per-lane fragment indices inside a stage (floats): m row kk of the k step, columns 2r, 2r+1 of this wave's 64
+  const int fa = kk * WG_BM + wm * 64 + 2 * r;
+  const int fb = A_STAGE + kk * WG_BN + wn * 64 + 2 * r;
 
   auto stage_body = [&](auto slot_c, int kb) {
     constexpr int SLOT = decltype(slot_c)::value;
     wait_vmcnt<0>();
     lds_barrier_raw();
     if (kb + 1 < nk) issue(kb + 1, IC<(SLOT + 1) % 2>{});
-    f32x4 a[2][2], b[2];
-    auto read_frags = [&](int k8, f32x4 (&af)[2], f32x4& bf) {
+    // four k steps (8 m rows) of fragments per group, the next group read while this one's MFMAs run
+    f32x2 a[2][4], b[2][4];
+    auto read_frags = [&](int g, f32x2 (&af)[4], f32x2 (&bf)[4]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        af[0][s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BM + fa[0]];
-        af[1][s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BM + fa[1]];
-        bf[s] = lds[SLOT * STAGE + (k8 * 8 + s) * WG_BN + fb];
+      for (int t = 0; t < 4; ++t) {
+        af[t] = *reinterpret_cast<const f32x2*>(&lds[SLOT * STAGE + (8 * g + 2 * t) * WG_BM + fa]);
+        bf[t] = *reinterpret_cast<const f32x2*>(&lds[SLOT * STAGE + (8 * g + 2 * t) * WG_BN + fb]);
       }
     };
     read_frags(0, a[0], b[0]);
 #pragma unroll
-    for (int k8 = 0; k8 < WG_BK / 8; ++k8) {
-      if (k8 + 1 < WG_BK / 8) read_frags(k8 + 1, a[(k8 + 1) & 1], b[(k8 + 1) & 1]);
+    for (int g = 0; g < WG_BK / 8; ++g) {
+      if (g + 1 < WG_BK / 8) read_frags(g + 1, a[(g + 1) & 1], b[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k8 & 1][i][s], b[k8 & 1][s], acc[i], 0, 0, 0);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) acc[q][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][t][q], b[g & 1][t][p], acc[q][p], 0, 0, 0);
     }
   };
-  issue(0, IC<0>{});
+  if (nk > 0) issue(0, IC<0>{});
   for (int kb = 0; kb < nk; kb += 2) {
     stage_body(IC<0>{}, kb);
     if (kb + 1 < nk) stage_body(IC<1>{}, kb + 1);
   }
 
-  // ---- epilogue: accumulators -> [64][132] image -> partial[p][n][k] with 16-byte stores ----
+  // ---- epilogue: accumulators -> [128][132] image (tile (q, p) element e of lane (r, kk): row 2 (8 (e/4) + 4 kk + e%4) + q, column 2 r + p) ->
+  // partial[p_idx][n][k] with 16-byte stores
   constexpr int CS = WG_BN + 4;
   lds_barrier_raw();
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) lds[(i * 32 + 8 * (e >> 2) + 4 * kk + (e & 3)) * CS + wave * 32 + r] = acc[i][e];
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 64 + 2 * (8 * (e >> 2) + 4 * kk + (e & 3)) + q;
+      *reinterpret_cast<f32x2*>(&lds[row * CS + wn * 64 + 2 * r]) = f32x2{acc[q][0][e], acc[q][1][e]};
+    }
   lds_barrier_raw();
   float* out = part + (size_t)p_idx * N * K;
   const int c4 = (tid & 31) * 4, rr = tid >> 5;            // 8 rows per pass
@@ -822,30 +833,33 @@ int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_strid
 }
 
 int pbhc_linear_wgrad_parts(int M, int N, int K) {
-  // number of row groups: as many workgroups as fill 768 slots (3 per CU) in whole rounds, every group a multiple of 32 rows
+  // number of row groups: as many workgroups as fill the 512 resident slots (two 64 KB workgroups per CU) in one round; a group takes a run of
+  // 32-row stages (uneven runs allowed), at least four of them
   if (M < 32 || (M & 31) || N < 4 || (N & 3) || K < 4) return 0;
   const int tiles = ((N + WG_BM - 1) / WG_BM) * ((K + WG_BN - 1) / WG_BN);
   const int stages = M / WG_BK;
-  int best = 0;
-  for (int P = 1; P <= 128 && P <= stages; ++P) {
-    if (stages % P) continue;
-    if ((long)tiles * P > 768 && best) break;
-    if (stages / P < 4) break;                             // at least four K stages per workgroup
-    best = P;
-    if ((long)tiles * P >= 768) break;
-  }
-  return best;
+  int P = 512 / tiles;
+  if (P > stages / 4) P = stages / 4;
+  if (P > 256) P = 256;
+  if (P >= 8 && (P & ~7) * 10 >= P * 9) P &= ~7;           // whole row groups per XCD (k_wgrad's workgroup order) when that costs < 10 % of the workgroups
+  return P < 1 ? 1 : P;
 }
 
 int pbhc_linear_wgrad(const float* dy, const float* x, float* dw, float* scratch, int M, int N, int K, void* stream) {
   GEMM_ARG(dy && x && dw && scratch && M >= 1 && N >= 1 && K >= 1);
   GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)x & 3) == 0);
   const int P = pbhc_linear_wgrad_parts(M, N, K);
-  GEMM_ARG(P >= 1 && (size_t)M * (size_t)(N > K ? N : K) < (1u << 30));
+  GEMM_ARG(P >= 1 && (M & 31) == 0 && (N & 3) == 0 && K >= 4 && (size_t)M * (size_t)(N > K ? N : K) < (1u << 30));
   hipStream_t st = (hipStream_t)stream;
   const int tn = (N + WG_BM - 1) / WG_BM, tk = (K + WG_BN - 1) / WG_BN;
-  constexpr int LDS_BYTES = 2 * WG_BK * (WG_BM + WG_BN) * 4;     // 48 KB (the [64][132] image fits inside)
-  hipLaunchKernelGGL(k_wgrad, dim3(tn * tk, P), dim3(GEMM_T), LDS_BYTES, st, dy, x, scratch, N, K, M / P, tk);
+  constexpr int RING = 2 * WG_BK * (WG_BM + WG_BN) * 4, IMAGE = WG_BM * (WG_BN + 4) * 4;
+  constexpr int LDS_BYTES = RING > IMAGE ? RING : IMAGE;          // 67 584 B: above the 64 KB default
+  static bool attr_set = false;
+  if (!attr_set) {
+    GEMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_wgrad, dim3(tn * tk * P), dim3(GEMM_T), LDS_BYTES, st, dy, x, scratch, N, K, M / WG_BK, tk, tn * tk, P);
   const int n = N * K;
   hipLaunchKernelGGL(k_wgrad_sum, dim3((n / 4 + 256) / 256), dim3(256), 0, st, scratch, dw, n, P);
   GEMM_HIP(hipGetLastError());

@@ -134,7 +134,7 @@ def test_linear_wgrad_matches_fp64(shape):
     dy = torch.randn(M, N, device="cuda", generator=g)
     x = torch.randn(M, K, device="cuda", generator=g)
     P = lib.pbhc_linear_wgrad_parts(M, N, K)
-    assert P >= 1 and (M // 32) % P == 0
+    assert 1 <= P <= max(1, (M // 32) // 4)
     dw = torch.full((N, K), float("nan"), device="cuda")
     scratch = torch.full((P * N * K,), float("nan"), device="cuda")
     _lib.check(lib.pbhc_linear_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), scratch.data_ptr(), M, N, K, _lib.current_stream()), "wgrad")
@@ -149,7 +149,7 @@ def test_linear_wgrad_parts_rejects_what_the_kernel_cannot_take():
     assert lib.pbhc_linear_wgrad_parts(24576, 23, 128) == 0          # out_features % 4
     assert lib.pbhc_linear_wgrad_parts(1000, 64, 64) == 0            # rows % 32
     assert lib.pbhc_linear_wgrad_parts(24576, 64, 3) == 0            # in_features < 4
-    assert lib.pbhc_linear_wgrad_parts(24576, 768, 630) == 12 and lib.pbhc_linear_wgrad_parts(24576, 512, 768) == 16
+    assert lib.pbhc_linear_wgrad_parts(24576, 768, 630) == 16 and lib.pbhc_linear_wgrad_parts(24576, 512, 768) == 21     # 512 resident slots / tiles; whole groups per XCD when cheap
 
 
 @pytest.mark.parametrize("cfg", [(257, 20, 60, 40, 6, 2), (300, 10, 30, 20, 4, 2), (64, 8, 40, 20, 4, 2), (130, 6, 20, 10, 2, 1)])
