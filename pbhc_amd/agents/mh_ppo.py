@@ -461,8 +461,11 @@ class MHPPO:
         keys = list(self.UPDATE_KEYS)
         if self._need_next:
             keys += ["next_actor_obs", "next_critic_obs"]
+        loss["_acc"] = torch.zeros(4, device=self.device)      # running sums of the loss kernel's scalars: one add per optimiser step, not one per meter
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=keys, indices=indices):
             self._update_ppo(batch, loss)
+        acc = loss.pop("_acc")
+        loss["Surrogate"] += acc[0]; loss["Value"] += acc[1]; loss["Entropy"] += acc[2]
         n = self.num_learning_epochs * self.num_mini_batches
         self.storage.clear()
         self.actor_learning_rate = self._lr_a        # tensors; read back lazily by the logger
@@ -533,7 +536,10 @@ class MHPPO:
         _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
                                        self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
                                        self.adam_eps, 0.0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
-        loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
+        if "_acc" in loss:
+            loss["_acc"].add_(self._loss_scalars)
+        else:
+            loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         return loss
 
     def _update_ppo_eager(self, b, loss):

@@ -464,8 +464,11 @@ class PPO:
 
     def _training_step(self, indices=None):
         loss = {k: torch.zeros((), device=self.device) for k in ["Value", "Entropy", "Surrogate", "priv_reg_loss"]}
+        loss["_acc"] = torch.zeros(4, device=self.device)      # running sums of the loss kernel's scalars: one add per optimiser step
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=self.UPDATE_KEYS, indices=indices):
             self._update_ppo(batch, loss)
+        acc = loss.pop("_acc")
+        loss["Surrogate"] += acc[0]; loss["Value"] += acc[1]; loss["Entropy"] += acc[2]
         n = self.num_learning_epochs * self.num_mini_batches
         self.storage.clear()
         self.update_counter()
@@ -528,7 +531,10 @@ class PPO:
                 pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
             pdist.allreduce_mean_(self._gflat[: self._n_main])
         self._adam(0, 0, self._n_main, self._lr[0:1])
-        loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
+        if "_acc" in loss:
+            loss["_acc"].add_(self._loss_scalars)
+        else:
+            loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         loss["priv_reg_loss"] += priv_reg.detach()
         return loss
 

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/stepseq
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/stepseq/t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --workload v2_teacher29 --clips 256 > gpurun_out/stepseq/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/stepseq/t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary ${PBHC_SEQ_ARGS:---workload v2_teacher29 --clips 256} > gpurun_out/stepseq/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob, re
 f = glob.glob("gpurun_out/stepseq/t/**/*kernel_trace.csv", recursive=True)[0]
