@@ -514,14 +514,14 @@ class MHPPO:
                                      self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
         na, nc = self._n_actor, self._n_critic
         if self._dp:
-            # the actor's gradient segment is all-reduced while the critic's backward runs; the tiny KL exchange rides in between
+            # The critic's gradient segment (3.8 MB: the larger one) is all-reduced while the ACTOR's backward runs; only the actor's 1.45 MB
+            # exchange is left exposed before the optimiser step.  The minibatch KL mean sits in the slot behind the critic's segment: one
+            # collective carries both (the adaptive learning-rate rule, mh_ppo.py:455-466, needs the mean over ALL ranks' samples).
+            self._gflat[na + nc:na + nc + 1].copy_(self._loss_scalars[3:4])
+            torch.autograd.backward([value], [self._grad_value])
+            h_c = pdist.all_reduce(self._gflat[na:na + nc + 1], async_op=True)
             torch.autograd.backward([mu], [self._grad_mu])
             h_a = pdist.all_reduce(self._gflat[:na], async_op=True)
-            torch.autograd.backward([value], [self._grad_value])
-            # the minibatch KL mean sits in the slot behind the critic's segment: one collective carries both (the adaptive learning-rate
-            # rule, mh_ppo.py:455-466, needs the mean over ALL ranks' samples before the optimiser step)
-            self._gflat[na + nc:na + nc + 1].copy_(self._loss_scalars[3:4])
-            h_c = pdist.all_reduce(self._gflat[na:na + nc + 1], async_op=True)
             h_a.wait(); h_c.wait()
             self._gflat.div_(self.world_size)
             if adapt:
