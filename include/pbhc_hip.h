@@ -408,6 +408,10 @@ int pbhc_env_finalize(PbhcEnv* env, const double* totals, double num_envs_total,
 #define PBHC_PROFILE_RING 512
 int pbhc_env_profile(PbhcEnv* env, int enable);
 int pbhc_env_profile_read(PbhcEnv* env, float* ms_out, int max_count, int* count);
+/* What the dispatch-attached event pair reads BEYOND a kernel's execution (queue-side start / stop handling): measured with a one-wave kernel
+ * that spins for exactly 20 us of the 100 MHz wall clock (median of 33 launches minus 0.020 ms).  Subtract it from pbhc_env_profile_read's values
+ * to compare with a profiler's kernel durations. */
+int pbhc_env_profile_overhead(PbhcEnv* env, void* stream, float* overhead_ms);
 
 /* Rollout-side fusions of MHPPO._rollout_step (mh_ppo.py:270-342).
  * pbhc_policy_sample: a ~ Normal(mu, std) (Philox keyed by seed / counter[0] / env), log-prob, and the writes of one rollout-buffer

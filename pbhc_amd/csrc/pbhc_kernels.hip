@@ -2190,6 +2190,31 @@ int pbhc_env_profile(PbhcEnv* e, int enable) {
   return PBHC_OK;
 }
 
+// One wave that spins for `ticks` of the 100 MHz wall clock: a kernel of KNOWN duration, to calibrate the dispatch-attached event pair
+__global__ void k_profile_spin(long long ticks, long long* sink) {
+  const long long t0 = wall_clock64();
+  long long t = t0;
+  while (t - t0 < ticks) t = wall_clock64();          // bounded: the wall clock always advances
+  if (sink && threadIdx.x == 0) *sink = t - t0;
+}
+int pbhc_env_profile_overhead(PbhcEnv* e, void* stream, float* overhead_ms) {
+  ARG_CHECK(e && overhead_ms && e->profile);
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  float v[33];
+  const long long ticks = 2000;                             // 20 us
+  for (int i = 0; i < 33; ++i) {
+    hipExtLaunchKernelGGL(k_profile_spin, dim3(1), dim3(64), 0, st, a, b, 0, ticks, (long long*)nullptr);
+    HIP_CHECK(hipEventSynchronize(b));
+    HIP_CHECK(hipEventElapsedTime(&v[i], a, b));
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  for (int i = 1; i < 33; ++i) { float x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+  *overhead_ms = v[16] - 0.020f;                            // median reading minus the spin's own 20 us
+  return PBHC_OK;
+}
 int pbhc_env_profile_read(PbhcEnv* e, float* ms_out, int max_count, int* count) {
   ARG_CHECK(e && ms_out && count && e->profile);
   int n = e->prof_count < PBHC_PROFILE_RING ? e->prof_count : PBHC_PROFILE_RING;
