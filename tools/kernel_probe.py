@@ -27,8 +27,11 @@ for _ in range(100):
     env.step({"actions": act})
 buf = (C.c_float * 512)(); cnt = C.c_int(0)
 _lib.check(lib.pbhc_env_profile_read(env._env, buf, 100, C.byref(cnt)))
-ms = sorted(buf[i] for i in range(cnt.value))
-print(f"k_env_step N={N}: median {ms[len(ms)//2]*1e3:.1f} us  min {ms[0]*1e3:.1f} us  mean {sum(ms)/len(ms)*1e3:.1f} us")
+ov = C.c_float(0.0)
+if hasattr(lib, "pbhc_env_profile_overhead"):
+    _lib.check(lib.pbhc_env_profile_overhead(env._env, _lib.current_stream(), C.byref(ov)))     # what the event pair reads beyond the kernel (20 us spin calibration)
+ms = sorted(buf[i] - max(ov.value, 0.0) for i in range(cnt.value))
+print(f"k_env_step N={N}: median {ms[len(ms)//2]*1e3:.1f} us  min {ms[0]*1e3:.1f} us  mean {sum(ms)/len(ms)*1e3:.1f} us   (event pair minus its calibrated overhead of {ov.value * 1e3:.1f} us)")
 if hasattr(lib, "pbhc_debug_read_stamps"):
     st = (C.c_ulonglong * 64)()
     lib.pbhc_debug_read_stamps(st, 64)
