@@ -384,3 +384,59 @@ def test_hip_env_reproduces_sim2sim_log():
         assert torch.equal(o["actor_obs"][0], o["actor_obs"][N - 1])
         check_log_row(o, log, r, worst)
     assert worst["anchor_ref_rot"] > 0 and worst["actions"] == 0.0
+
+
+def test_general_tracking_observation_noise_at_shard_size():
+    """BASELINE configs[4]'s per-GPU shard: 4096 envs, 29-DoF teacher, a mixed clip library, observation noise ON and the shipped domain
+    randomisation ON (`obs_ppo_teacher.yaml:86-113`, `domain_rand/main.yaml`).  Noise-on vs noise-off step from the same state and seeds
+    (reference: helpers.parse_observation, (x + (2U-1) * noise) * scale, helpers.py:128-152): per key and group the differences are bounded by
+    noise * scale, have mean ~ 0 and the variance of a uniform on [-1, 1]; noise-free keys are identical."""
+    import bench
+    from pbhc_amd import motion_lib as ML
+    from tests.helpers import clip_from_env_golden
+
+    N, M = 4096, 64
+    g = dict(np.load(os.path.join(GOLDEN, "env_v2_teacher29.npz")))
+    clips = bench.synth_library(clip_from_env_golden(g), M, seed=11)
+    outs = []
+    for noise_off in (True, False):
+        orig = ML.load_motion_file
+        ML.load_motion_file = lambda path: [(f"c{i}", c) for i, c in enumerate(clips)]
+        try:
+            torch.manual_seed(21)
+            cfg, env = build_hip_env("v2_g1_29dof_teacher.yaml", N, general=True, noise_off=noise_off)
+        finally:
+            ML.load_motion_file = orig
+        torch.manual_seed(22)
+        env.reset_all()
+        obs, rew, reset, _ = env.step({"actions": torch.zeros(N, env.num_dof, device=DEV)})
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v).all()) for v in obs.values()) and bool(torch.isfinite(rew).all())
+        outs.append(({k: v.clone() for k, v in obs.items()}, cfg, env.layout, reset.clone()))
+    (clean, _, _, r0), (noisy, cfg, L, r1) = outs
+    assert torch.equal(r0, r1)                                   # the noise does not feed termination
+    ob = cfg.obs
+    checked = 0
+    def width(key):
+        return L.obs_dims[key] if key in L.obs_dims else sum(L.obs_dims[k] * n for k, n in ob.obs_auxiliary[key].items())
+
+    for grp, keys in ob.obs_dict.items():
+        pos = 0
+        if noisy[grp].shape[1] != sum(width(k) for k in keys):   # the future-target group: one row of its keys per future step (general_tracking.py:501-560)
+            assert noisy[grp].shape[1] % sum(width(k) for k in keys) == 0 and all(float(ob.noise_scales[k]) == 0.0 for k in keys), grp
+            assert torch.equal(noisy[grp], clean[grp]), grp
+            continue
+        for key in sorted(keys):
+            d = width(key)
+            if key not in ob.obs_auxiliary:
+                diff = (noisy[grp][:, pos:pos + d] - clean[grp][:, pos:pos + d]).cpu()
+                amp = float(ob.noise_scales[key]) * float(ob.obs_scales[key])
+                if amp == 0.0:
+                    assert float(diff.abs().max()) == 0.0, (grp, key)
+                else:
+                    assert float(diff.abs().max()) <= amp * (1 + 1e-5) + 1e-6, (grp, key, float(diff.abs().max()), amp)
+                    assert abs(float(diff.mean())) < 0.05 * amp and abs(float(diff.var()) / (amp * amp / 3.0) - 1.0) < 0.1, (grp, key, float(diff.mean()), float(diff.var()), amp)
+                    checked += 1
+            pos += d
+        assert pos == noisy[grp].shape[1], grp
+    assert checked >= 4
