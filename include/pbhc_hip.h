@@ -397,6 +397,12 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
 void pbhc_env_destroy(PbhcEnv* env);
 /* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */
 int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
+/* The same step as its two launches, for a caller that keeps the one-workgroup reduction off its critical chain (the rollout of
+ * mh_ppo.py:270-342 is step -> policy forward -> step: only the fused launch has to precede the policy forward).  `launch` = the fused
+ * per-env kernel on `stream`; `finish` = the reduction of its partial sums into the globals (or into io->totals_out) on a stream of the
+ * caller's choice, ordered by the caller after the launch and before the next launch / pbhc_policy_sample (which reads the step counter). */
+int pbhc_env_step_launch(PbhcEnv* env, const PbhcStepIO* io, void* stream);
+int pbhc_env_step_finish(PbhcEnv* env, const PbhcStepIO* io, void* stream);
 /* Second half of a step launched with io->totals_out: `totals` = the element-wise sum over ranks of every shard's totals_out,
  * `num_envs_total` = the number of envs of all ranks.  Must run before the next pbhc_env_step of this env. */
 #define PBHC_NUM_TOTALS 64

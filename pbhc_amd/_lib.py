@@ -87,7 +87,8 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
-           "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided"]
+           "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
+           "pbhc_env_step_launch", "pbhc_env_step_finish"]
 
 
 class PbhcError(RuntimeError):
@@ -115,6 +116,8 @@ def _load():
     lib.pbhc_env_destroy.argtypes = [vp]
     lib.pbhc_env_destroy.restype = None
     lib.pbhc_env_step.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
+    lib.pbhc_env_step_launch.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
+    lib.pbhc_env_step_finish.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
     lib.pbhc_env_finalize.argtypes = [vp, vp, C.c_double, vp]
     lib.pbhc_env_profile.argtypes = [vp, i]
     lib.pbhc_env_profile_read.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(C.c_int)]

@@ -204,12 +204,20 @@ def forward_inference(seq, x):
     lin = [m for m in seq if isinstance(m, nn.Linear)]
     act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
     lib, st = _lib.lib(), _lib.current_stream()
-    h = x if x.is_contiguous() else x.contiguous()
+    # a rollout slab is a [N, C] view of 128-byte-padded rows: read in place through the row pitch (no .contiguous() copy of the slab)
+    pitched = (not x.is_contiguous() and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % 4 == 0
+               and x.data_ptr() % 16 == 0 and x.shape[1] >= 4 and len(lin) > 1)
+    h = x if (x.is_contiguous() or pitched) else x.contiguous()
     B = h.shape[0]
     for l in lin[:-1]:
         z = torch.empty(B, l.out_features, device=h.device)
-        _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(), None,
-                                           B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
+        bias = l.bias.data_ptr() if l.bias is not None else None
+        if h.is_contiguous():
+            _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), bias, z.data_ptr(), None, B, l.out_features, l.in_features, act, st),
+                       "pbhc_linear_act_fwd")
+        else:
+            _lib.check(lib.pbhc_linear_act_fwd_strided(h.data_ptr(), h.stride(0), 0, l.weight.data_ptr(), bias, z.data_ptr(), None, l.out_features, 0, 1,
+                                                       B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd_strided")
         h = z
     return torch.addmm(lin[-1].bias, h, lin[-1].weight.t())
 

@@ -408,29 +408,50 @@ class MHPPO:
         with torch.inference_mode():
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
-            # Per control step only the actor is on the critical path (actions -> env step).  The critic of slab t — written by the env step
-            # of t-1 — runs on a branch stream next to the actor chain, the sampling kernel and the fused env step, and is joined
-            # before the bootstrap kernel that consumes its values.  Each chain is one hipGraph launch per step.
+            # Per control step the dependent chain is env step -> actor forward -> sampling -> env step.  Everything else of a step runs on a
+            # branch stream NEXT to that chain: the env step's one-workgroup reduction (sigma EMA, curricula, step counter), the bootstrap /
+            # done / episode-statistics kernel, and the critic forward of the slab the step has just written.  The chain waits for the branch
+            # once per step, right before the sampling kernel (which reads the step counter the reduction advances).  Each policy chain is one
+            # hipGraph launch per step.
             cur, br = torch.cuda.current_stream(), self._branch_stream
             actor_fwd = policy_forward_graphs(self, lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t]), key="actor")
             critic_fwd = policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
+            split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
+            if split:
+                env.set_finalize_stream(br)
+            post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
+            br.wait_stream(cur)
             for t in range(T):
-                br.wait_stream(cur)
                 with torch.cuda.stream(br):
                     st.values[t].copy_(critic_fwd(t))
                 mu = actor_fwd(t)
+                if split and t > 0:
+                    cur.wait_event(post_done)          # reduction + bootstrap kernel of step t-1 (13 us of work, issued ~100 us ago)
                 _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), None, N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
                                                   st.actions_log_prob[t].data_ptr(), None, stream), "pbhc_policy_sample")
                 env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
                 nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
-                cur.wait_stream(br)
                 if self._need_next:
                     for k in keys:
                         getattr(st, "next_" + k)[t].copy_(nxt[k])
-                _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                 float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                 self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+                if split:
+                    # branch: [reduction of step t, queued by env.step] -> bootstrap kernel of step t (values[t] were produced earlier on this
+                    # stream) -> critic of slab t+1 (next iteration)
+                    with torch.cuda.stream(br):
+                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                         float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                         self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), br.cuda_stream), "pbhc_rollout_post")
+                        post_done.record(br)
+                else:
+                    cur.wait_stream(br)
+                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                     float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                     self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+                    br.wait_stream(cur)
+            cur.wait_stream(br)
+            if split:
+                env.set_finalize_stream(None)
             st.step = T
             self._timer.split()
             self._compute_returns(self._last_obs)

@@ -428,16 +428,38 @@ class PPO:
                 getattr(st, k)[0].copy_(obs_dict[k])
             mode = bool(self.hist_encoding)                    # the captured forward depends on the latent source
             fwd = policy_forward_graphs(self, lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2], key=mode)
+            # the dependent chain of a control step is env step -> policy forward -> sampling -> env step; the env step's one-workgroup reduction
+            # and the bootstrap / episode-statistics kernel run next to the policy forward on a branch stream (joined before the sampling kernel,
+            # which reads the step counter the reduction advances)
+            split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
+            cur = torch.cuda.current_stream()
+            if split:
+                br = self.__dict__.setdefault("_branch_stream", None) or torch.cuda.Stream(device=self.device)
+                self._branch_stream = br
+                post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
+                env.set_finalize_stream(br)
             for t in range(T):
                 mu, value = fwd(t)
+                if split and t > 0:
+                    cur.wait_event(post_done)
                 _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
                                                   st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
                 env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
                 nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
-                _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                 float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                 self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+                if split:
+                    with torch.cuda.stream(br):
+                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                         float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                         self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), br.cuda_stream), "pbhc_rollout_post")
+                        post_done.record(br)
+                else:
+                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                     float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
+                                                     self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+            if split:
+                cur.wait_stream(br)
+                env.set_finalize_stream(None)
             st.step = T
             self._timer.split()
             self._compute_returns(self._last_obs)

@@ -2228,7 +2228,7 @@ int pbhc_env_profile_read(PbhcEnv* e, float* ms_out, int max_count, int* count) 
   return PBHC_OK;
 }
 
-int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
+static int env_step_check(PbhcEnv* e, const PbhcStepIO* io) {
   ARG_CHECK(e && io);
   ARG_CHECK(io->actions_in && io->frame_root && io->frame_dof_pos && io->frame_dof_vel && io->frame_contact && io->frame_cursor && io->num_frames >= 1);
   ARG_CHECK(io->root_states && io->dof_state && io->actions && io->last_actions && io->actions_after_delay && io->action_queue);
@@ -2242,6 +2242,13 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
     ARG_CHECK((uint64_t)e->cfg.num_envs * (uint64_t)(io->obs_pitch[g] ? io->obs_pitch[g] : e->cfg.groups[g].pitch) < (1ull << 30));   // 32-bit row offsets in the kernel
   }
   ARG_CHECK(io->hist_pitch == 0 || io->hist_pitch >= e->cfg.hist_dim);
+  return PBHC_OK;
+}
+
+// first half of a step: the fused launch (per-env work + per-workgroup partial sums)
+int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
+  const int rc = env_step_check(e, io);
+  if (rc != PBHC_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int slot = e->prof_count % PBHC_PROFILE_RING;
   // profiling: the event pair is attached to the dispatch itself (hipExtLaunchKernelGGL: start / stop taken from the kernel's own
@@ -2254,11 +2261,25 @@ int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
     hipExtLaunchKernelGGL(k_env_step<0>, dim3(e->nblocks), dim3(PBHC_TPB), e->lds_bytes, st, pe0, pe1, 0, (const PbhcEnvConfig*)e->d_cfg, e->tbl, *io,
                           (const double*)e->d_glob, e->d_partials, e->lds_stride, (const float*)e->d_skc, (const uint32_t*)e->cfg.map_image);
   if (e->profile) e->prof_count++;
-  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, st, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor, io->num_frames,
-                     (const double*)nullptr, io->totals_out, 0.0);
   e->step_ctr++;
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
+}
+
+// second half: the one-workgroup reduction of the partial sums into the globals (adaptive sigma, curricula, log means, step counter) — or,
+// with io->totals_out, into this shard's totals for the ranks' exchange.  `stream` may differ from the launch's: the caller orders it
+// after the fused launch and before the next one (the rollout runs it next to the policy forward, off the step -> policy -> step chain).
+int pbhc_env_step_finish(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
+  ARG_CHECK(e && io && io->frame_cursor && io->num_frames >= 1);
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, (hipStream_t)stream, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor,
+                     io->num_frames, (const double*)nullptr, io->totals_out, 0.0);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
+int pbhc_env_step(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
+  const int rc = pbhc_env_step_launch(e, io, stream);
+  return rc != PBHC_OK ? rc : pbhc_env_step_finish(e, io, stream);
 }
 
 int pbhc_env_finalize(PbhcEnv* e, const double* totals, double num_envs_total, void* stream) {

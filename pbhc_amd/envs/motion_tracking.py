@@ -134,6 +134,7 @@ class LeggedRobotMotionTracking:
         self._env = C.c_void_p()
         _lib.check(self._lib.pbhc_env_create(C.byref(self._c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(self._env)), "pbhc_env_create")
         self._totals, self._stat_pending, self._stat_group, self._num_envs_total = None, None, None, float(N)     # enable_global_statistics()
+        self._finalize_stream, self._step_done, self._fin_done, self._fin_pending = None, None, None, False        # set_finalize_stream()
         self._init_buffers()
         self._init_obs_buffers()
         self._build_io()
@@ -320,6 +321,23 @@ class LeggedRobotMotionTracking:
         self._io.totals_out = self._totals.data_ptr()
         return True
 
+    def set_finalize_stream(self, stream):
+        """Run every step's one-workgroup reduction (`pbhc_env_step_finish`: sigma EMA, curricula, log means, step counter) on `stream`
+        instead of the stepping stream (None: back to one stream).  The env orders it after its fused launch and joins it before the next
+        one; a caller that reads the globals on the stepping stream in between (pbhc_policy_sample reads the step counter) calls
+        `wait_finalize()` first."""
+        if self._finalize_stream is not None:
+            self.wait_finalize()
+        self._finalize_stream = stream
+        if stream is not None and self._step_done is None:
+            self._step_done, self._fin_done = torch.cuda.Event(), torch.cuda.Event()
+
+    def wait_finalize(self):
+        """the current stream waits for the last step's reduction (no-op on one stream)"""
+        if self._fin_pending:
+            torch.cuda.current_stream().wait_event(self._fin_done)
+            self._fin_pending = False
+
     def _flush_statistics(self):
         h = self._stat_pending
         if h is not None:
@@ -355,6 +373,7 @@ class LeggedRobotMotionTracking:
         return obs_dict
 
     def _reset_all_state(self, keep_reset_buf=False):
+        self.wait_finalize()
         """reset_envs_idx(arange(N)) (legged_robot_base.py:491-517).  keep_reset_buf: the periodic resample inside step() — the reference's
         resample_motion() resets every env WITHOUT touching reset_buf, the dones of that step stay those of its own _check_termination."""
         N, dev = self.num_envs, self.device
@@ -452,9 +471,26 @@ class LeggedRobotMotionTracking:
             prev.materialise()
         del prev
         self._flush_statistics()
-        _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
+        fs = self._finalize_stream
+        if fs is None:
+            _lib.check(self._lib.pbhc_env_step(self._env, C.byref(io), _lib.current_stream()), "pbhc_env_step")
+        else:
+            # the fused launch here, its one-workgroup reduction on the side stream (set_finalize_stream): this stream goes straight on to
+            # the policy forward of the new observations; the reduction is joined again before the next launch (wait_finalize)
+            cur = torch.cuda.current_stream()
+            self.wait_finalize()
+            _lib.check(self._lib.pbhc_env_step_launch(self._env, C.byref(io), cur.cuda_stream), "pbhc_env_step_launch")
+            self._step_done.record(cur)
+            fs.wait_event(self._step_done)
+            _lib.check(self._lib.pbhc_env_step_finish(self._env, C.byref(io), fs.cuda_stream), "pbhc_env_step_finish")
+            self._fin_done.record(fs)
+            self._fin_pending = True
         if self._totals is not None:
-            self._stat_pending = pdist.all_reduce(self._totals, group=self._stat_group, async_op=True)
+            if fs is None:
+                self._stat_pending = pdist.all_reduce(self._totals, group=self._stat_group, async_op=True)
+            else:
+                with torch.cuda.stream(fs):      # the shard's totals are written by the reduction on the side stream: the exchange follows it there
+                    self._stat_pending = pdist.all_reduce(self._totals, group=self._stat_group, async_op=True)
         self.common_step_counter += 1
         # _update_tasks_callback (motion_tracking.py:320-325, general_tracking.py:216-222): periodic slot -> clip resampling + reset of every
         # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
@@ -476,6 +512,7 @@ class LeggedRobotMotionTracking:
 
     # ---- logging: device-side means, read back on demand (no per-step sync) ----------------
     def read_log(self):
+        self.wait_finalize()
         self._flush_statistics()
         g = self.globals.cpu().numpy()
         L0 = K["PBHC_G_LOG"]

@@ -547,6 +547,52 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
+def _rollouts_with_split(split, agent="v1"):
+    """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state"""
+    import os
+
+    os.environ["PBHC_ROLLOUT_SPLIT"] = "1" if split else "0"
+    try:
+        torch.manual_seed(11)
+        np.random.seed(11)
+        if agent == "v1":
+            from pbhc_amd.agents.mh_ppo import MHPPO as Algo
+
+            cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 512, noise_off=False)
+        else:
+            from tests.test_gpu_parity_v2 import _v2_algo
+
+            cfg, env, algo = _v2_algo(256, noise_off=False)
+        if agent == "v1":
+            algo = Algo(env=env, config=cfg.algo.config, log_dir=None, device=DEV)
+            algo.setup()
+        algo._train_mode()
+        obs = env.reset_all()
+        for _ in range(3):
+            algo.storage.clear()
+            obs = algo._rollout_step(obs)
+        torch.cuda.synchronize()
+        st = algo.storage
+        out = {k: getattr(st, k).clone() for k in st.stored_keys}
+        out["globals"] = env.globals.clone()
+        out["episode_sums"] = env._episode_sums.clone()
+        out["ep_stats"] = algo._ep_stats.clone()
+        return out
+    finally:
+        os.environ.pop("PBHC_ROLLOUT_SPLIT", None)
+
+
+@pytest.mark.parametrize("agent", ["v1", "v2"])
+def test_rollout_branch_stream_equals_one_stream(agent):
+    """The rollout keeps the env step's reduction, the bootstrap kernel (and the v1 critic) on a branch stream next to the step -> policy ->
+    sampling chain; that is a schedule, not arithmetic: buffers, globals (sigma EMA, curricula, step counter) and episode statistics are
+    bit-identical to the one-stream order (mh_ppo.py:270-342, ppo_mimic.py:371-438)."""
+    a = _rollouts_with_split(True, agent)
+    b = _rollouts_with_split(False, agent)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_learn_runs_two_iterations():
     from pbhc_amd.agents.mh_ppo import MHPPO
 
