@@ -428,9 +428,14 @@ int pbhc_policy_sample(const float* mu, const float* std, const float* value, in
                        float* actions, float* action_mean, float* action_sigma, float* logp, float* values_out, void* stream);
 /* pbhc_rollout_post: rewards_stored = rew + gamma * values * time_out (bootstrap, :300-305), dones = reset_buf != 0, and the
  * episode book-keeping (:311-323) kept on the device: cur_reward_sum/cur_episode_length [N], ep_stats double[3] +=
- * (sum of finished returns, sum of finished lengths, count). */
+ * (sum of finished returns, sum of finished lengths, count).
+ * pbhc_rollout_post2: the same with `values` NULL allowed — rewards_stored = rew, the caller adds the bootstrap once the values exist (the
+ * critic evaluated over all steps' slabs at once) — and the step's time-out flags copied to time_outs_out [N] (may be NULL) for that. */
 int pbhc_rollout_post(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
                       float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, void* stream);
+int pbhc_rollout_post2(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
+                       float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, uint8_t* time_outs_out,
+                       void* stream);
 
 /* GAE + returns + normalised advantages.  Replaces MHPPO._compute_returns (mh_ppo.py:348-395).
  * rewards/values/returns [T,N,R], dones [T,N] bool, last_values [N,R], advantages [T,N].
@@ -484,6 +489,19 @@ int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float
  * x + l*s*C with lda = T*C, written to out[:, l, :] of [B, L, O] (y + l*O, ldc = L*O).  K >= 4. */
 int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_stride, const float* w, const float* bias, float* y, float* pre, int ldc,
                                 long long y_batch_stride, int batches, int M, int N, int K, int act, void* stream);
+/* The WHOLE Linear / activation stack of a no-grad forward (the rollout's policy and critic evaluation, `BaseModule.forward`,
+ * agents/modules/modules.py:47-63 as called from mh_ppo.py:286-290 / ppo_mimic.py:392-400) in one launch: a workgroup carries 16 rows through
+ * every layer, activations stay in LDS.  y[M, dims[L]] = W_L-1 act(... act(W_0 x + b_0) ...) + b_L-1 (no activation after the last layer).
+ * x rows ldx floats apart, y rows ldy apart; weights[l] = the PACKED copy (pbhc_mlp_pack, pbhc_mlp_packed_floats(dims[l+1], dims[l]) floats,
+ * 16-byte aligned) of nn.Linear.weight [dims[l+1], dims[l]] — the MFMA operand fragments laid out 1 KiB-contiguous per wave-instruction;
+ * the caller repacks when the weights change (once per rollout: they are constant over its steps).  biases[l] may be NULL; act as
+ * pbhc_linear_act_fwd.  pbhc_mlp_fwd_lds_bytes: the launch's dynamic LDS (<= 160 KB or the call is refused). */
+#define PBHC_MLP_MAX_LAYERS 8
+size_t pbhc_mlp_packed_floats(int N, int K);
+int pbhc_mlp_pack(const float* w, int N, int K, float* packed, void* stream);
+size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers);
+int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                 int M, void* stream);
 /* The input gradient of that Linear with the activation backward of the layer BELOW folded in (what autograd runs as mm + elu_backward /
  * silu_backward + a column sum; replaces `dy @ w` + pbhc_act_bwd_partials):
  *   dx[M,N] = (dy[M,K] . w[K,N]) * act'(saved[M,N])   N = in_features, K = out_features; saved = the lower layer's activation OUTPUT

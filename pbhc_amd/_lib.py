@@ -88,7 +88,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
            "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
-           "pbhc_env_step_launch", "pbhc_env_step_finish"]
+           "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2"]
 
 
 class PbhcError(RuntimeError):
@@ -133,11 +133,18 @@ def _load():
     lib.pbhc_linear_wgrad_parts.argtypes = [i, i, i]
     lib.pbhc_linear_act_fwd_strided.argtypes = [vp, i, C.c_longlong, vp, vp, vp, vp, i, C.c_longlong, i, i, i, i, i, vp]
     lib.pbhc_linear_wgrad.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.pbhc_mlp_fwd.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, vp, i, i, vp]
+    lib.pbhc_mlp_fwd_lds_bytes.argtypes = [C.POINTER(i), i]
+    lib.pbhc_mlp_fwd_lds_bytes.restype = C.c_size_t
+    lib.pbhc_mlp_pack.argtypes = [vp, i, i, vp, vp]
+    lib.pbhc_mlp_packed_floats.argtypes = [i, i]
+    lib.pbhc_mlp_packed_floats.restype = C.c_size_t
     lib.pbhc_gemm_debug_force_shape.restype = None
     lib.pbhc_adam_clip.argtypes = [vp, vp, vp, vp, i, vp, vp, f, f, f, f, f, vp, vp, vp]
     lib.pbhc_adam_clip2.argtypes = [vp, vp, vp, vp, i, i, vp, vp, f, f, f, f, f, vp, vp, vp]
     lib.pbhc_policy_sample.argtypes = [vp, vp, vp, i, i, i, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.pbhc_rollout_post.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp]
+    lib.pbhc_rollout_post2.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp, vp]
     lib.pbhc_gae.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, vp, vp, vp]
     lib.pbhc_debug_rotations.argtypes = [i, vp, vp, vp, i, vp, vp]
     return lib

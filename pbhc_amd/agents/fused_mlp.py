@@ -198,9 +198,50 @@ class _FusedMLP(torch.autograd.Function):
         return (dx, None, *flat)
 
 
+FUSED_STACK = os.environ.get("PBHC_FUSED_STACK", "1") != "0"
+_STACK_MAX_ROWS = int(os.environ.get("PBHC_FUSED_STACK_MAX_ROWS", "16384"))
+
+
+def pack_stack(seq):
+    """Owner's declaration "the weights of `seq` stay as they are until release_stack()" (a rollout, an evaluation run): repacks them into
+    the operand layout of `pbhc_mlp_fwd` (one launch per layer, ~1.5 / 3.8 MB) so that `forward_inference` can run the whole stack as ONE
+    launch.  Returns False — and changes nothing — where the stack kernel does not apply."""
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    lib = _lib.lib()
+    n = len(lin)
+    if not (FUSED_GEMM and FUSED_STACK and 1 <= n <= _lib.K["PBHC_MLP_MAX_LAYERS"] and lin[0].weight.is_cuda and lin[0].weight.dtype == torch.float32
+            and all(l.weight.is_contiguous() for l in lin) and supported(seq)):
+        return False
+    c = getattr(seq, "_pbhc_stack", None)
+    sizes = [int(lib.pbhc_mlp_packed_floats(l.out_features, l.in_features)) for l in lin]
+    if c is None or c["sizes"] != sizes or c["bufs"][0].device != lin[0].weight.device:
+        dims = (C.c_int * (n + 1))(lin[0].in_features, *[l.out_features for l in lin])
+        lds = int(lib.pbhc_mlp_fwd_lds_bytes(dims, n))
+        if lds > 160 * 1024:
+            return False
+        bufs = [torch.empty(sz, device=lin[0].weight.device) for sz in sizes]       # allocated once: captured graphs keep reading these addresses
+        c = dict(sizes=sizes, bufs=bufs, dims=dims, w=(C.c_void_p * n)(*[b.data_ptr() for b in bufs]), valid=False)
+        seq._pbhc_stack = c
+    st = _lib.current_stream()
+    for l, buf in zip(lin, c["bufs"]):
+        _lib.check(lib.pbhc_mlp_pack(l.weight.data_ptr(), l.out_features, l.in_features, buf.data_ptr(), st), "pbhc_mlp_pack")
+    c["b"] = (C.c_void_p * n)(*[None if l.bias is None else l.bias.data_ptr() for l in lin])
+    c["valid"] = True
+    return True
+
+
+def release_stack(seq):
+    """the weights of `seq` may change again: `forward_inference` goes back to the layer-by-layer kernels"""
+    c = getattr(seq, "_pbhc_stack", None)
+    if c is not None:
+        c["valid"] = False
+
+
 def forward_inference(seq, x):
-    """No-grad forward of the same stack (the rollout's policy / critic evaluation): hidden layers through `pbhc_linear_act_fwd`, the narrow
-    output layer through the library.  Plain launches on the current stream, so it can be captured in a hipGraph like the eager form."""
+    """No-grad forward of the same stack (the rollout's policy / critic evaluation).  Between pack_stack() and release_stack() — the owner's
+    promise that the weights are constant — the WHOLE stack is one launch (`pbhc_mlp_fwd`: a workgroup carries 16 rows through every layer,
+    activations stay in LDS — at the rollout's 4 096 rows the layer-by-layer chain is launch- and tail-bound); otherwise hidden layers go
+    through `pbhc_linear_act_fwd` and the narrow output layer through the library.  Plain launches on the current stream, so either form can be captured in a hipGraph."""
     lin = [m for m in seq if isinstance(m, nn.Linear)]
     act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
     lib, st = _lib.lib(), _lib.current_stream()
@@ -209,6 +250,11 @@ def forward_inference(seq, x):
                and x.data_ptr() % 16 == 0 and x.shape[1] >= 4 and len(lin) > 1)
     h = x if (x.is_contiguous() or pitched) else x.contiguous()
     B = h.shape[0]
+    c = getattr(seq, "_pbhc_stack", None)
+    if c is not None and c["valid"] and B <= _STACK_MAX_ROWS:
+        out = torch.empty(B, lin[-1].out_features, device=h.device)
+        _lib.check(lib.pbhc_mlp_fwd(h.data_ptr(), h.stride(0), c["w"], c["b"], c["dims"], len(lin), act, out.data_ptr(), out.stride(0), B, st), "pbhc_mlp_fwd")
+        return out
     for l in lin[:-1]:
         z = torch.empty(B, l.out_features, device=h.device)
         bias = l.bias.data_ptr() if l.bias is not None else None

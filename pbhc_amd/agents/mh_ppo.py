@@ -409,49 +409,81 @@ class MHPPO:
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
             # Per control step the dependent chain is env step -> actor forward -> sampling -> env step.  Everything else of a step runs on a
-            # branch stream NEXT to that chain: the env step's one-workgroup reduction (sigma EMA, curricula, step counter), the bootstrap /
-            # done / episode-statistics kernel, and the critic forward of the slab the step has just written.  The chain waits for the branch
-            # once per step, right before the sampling kernel (which reads the step counter the reduction advances).  Each policy chain is one
-            # hipGraph launch per step.
+            # branch stream NEXT to that chain: the env step's one-workgroup reduction (sigma EMA, curricula, step counter) and the done /
+            # episode-statistics kernel.  The chain waits for the branch once per step, right before the sampling kernel (which reads the step
+            # counter the reduction advances).
+            # The critic's values are consumed only by the time-out bootstrap and by GAE, both after the rollout: evaluated ONCE over all T
+            # slabs (98 304 rows: whole-chip GEMM tiles at ~120 TFLOP/s) it costs 1.5 ms, against 24 x 85 us for per-step forwards that
+            # share the chip with the step -> actor chain (a control step's kernels add up to its duration: overlap buys ~10 %).
+            # PBHC_CRITIC_BATCHED=0: the critic of slab t on the branch stream next to the actor, one hipGraph launch per step.
+            from . import fused_mlp
+
             cur, br = torch.cuda.current_stream(), self._branch_stream
-            actor_fwd = policy_forward_graphs(self, lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t]), key="actor")
-            critic_fwd = policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
             split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
+            overlap_step = os.environ.get("PBHC_ROLLOUT_OVERLAP_STEP", "1") != "0"
+            batched = split and os.environ.get("PBHC_CRITIC_BATCHED", "1") != "0"
+            # the weights are constant over the rollout: the networks named here run as ONE launch per step from a packed copy (pbhc_mlp_fwd);
+            # packed BEFORE the step graphs are captured below — the capture records whichever kernels the forward launches
+            stack_nets = [n_ for n_ in os.environ.get("PBHC_STACK_NETS", "actor").split(",") if n_ and not (batched and n_ == "critic")]
+            stacks = [m.module for n_, m in (("actor", self.actor.actor_module), ("critic", self.critic.critic_module)) if n_ in stack_nets and m._fused]
+            stacks = [q for q in stacks if fused_mlp.pack_stack(q)]
+            actor_fwd = policy_forward_graphs(self, lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t]), key="actor")
+            critic_fwd = None if batched else policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
             if split:
                 env.set_finalize_stream(br)
             post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
+            if batched and self.__dict__.get("_time_outs") is None:
+                self._time_outs = torch.zeros(T, N, 1, dtype=torch.bool, device=self.device)
+            # per-step device addresses, formed once (the host's share of a control step is what bounds the loop once the critic is out of it)
+            sc = self.__dict__.get("_step_ptrs")
+            if sc is None or sc[0] is not st or sc[2] != batched:
+                P = lambda x: x.data_ptr()
+                sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t])),
+                                post=(P(st.rewards[t]), P(st.dones[t])), values=P(st.values[t]),
+                                tout=P(self._time_outs[t]) if batched else None,
+                                act={"actions": st.actions[t]},
+                                obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)], batched)
+                self._step_ptrs = sc
+            steps = sc[1]
+            std_p, sum_p, len_p, stat_p, gamma = std.data_ptr(), self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
+            br_h = br.cuda_stream
             br.wait_stream(cur)
             for t in range(T):
-                with torch.cuda.stream(br):
-                    st.values[t].copy_(critic_fwd(t))
+                sp = steps[t]
+                if not batched:
+                    with torch.cuda.stream(br):
+                        st.values[t].copy_(critic_fwd(t))
                 mu = actor_fwd(t)
                 if split and t > 0:
                     cur.wait_event(post_done)          # reduction + bootstrap kernel of step t-1 (13 us of work, issued ~100 us ago)
-                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std.data_ptr(), None, N, A, R, self._sample_seed, counter,
-                                                  st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
-                                                  st.actions_log_prob[t].data_ptr(), None, stream), "pbhc_policy_sample")
-                env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
-                nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
+                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
+                env.set_obs_outputs(sp["obs_out"])
+                if split and not overlap_step:
+                    cur.wait_stream(br)                # the critic of slab t has finished: the fused env step gets the chip to itself
+                nxt, rewards, dones, infos = env.step(sp["act"])
                 if self._need_next:
                     for k in keys:
                         getattr(st, "next_" + k)[t].copy_(nxt[k])
                 if split:
-                    # branch: [reduction of step t, queued by env.step] -> bootstrap kernel of step t (values[t] were produced earlier on this
-                    # stream) -> critic of slab t+1 (next iteration)
-                    with torch.cuda.stream(br):
-                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                         float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                         self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), br.cuda_stream), "pbhc_rollout_post")
-                        post_done.record(br)
+                    # branch: [reduction of step t, queued by env.step] -> done / episode-statistics kernel of step t (per-step critic: values[t]
+                    # were produced earlier on this stream and the bootstrap is added here) -> critic of slab t+1 (next iteration)
+                    _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), None if batched else sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                      gamma, *sp["post"], sum_p, len_p, stat_p, sp["tout"], br_h), "pbhc_rollout_post2")
+                    post_done.record(br)
                 else:
                     cur.wait_stream(br)
-                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                     float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                     self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
+                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                     gamma, *sp["post"], sum_p, len_p, stat_p, stream), "pbhc_rollout_post")
                     br.wait_stream(cur)
             cur.wait_stream(br)
             if split:
                 env.set_finalize_stream(None)
+            for q in stacks:
+                fused_mlp.release_stack(q)
+            if batched:
+                # mh_ppo.py:286-305 for all steps at once: values of every slab, then rewards += gamma * values * time_outs
+                st.values.copy_(self.critic.critic_module(st.critic_obs.flatten(0, 1)).view(T, N, R))
+                st.rewards.addcmul_(st.values, self._time_outs.to(torch.float32), value=float(self.gamma))
             st.step = T
             self._timer.split()
             self._compute_returns(self._last_obs)

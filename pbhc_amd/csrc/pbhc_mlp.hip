@@ -1,0 +1,253 @@
+// Whole-stack forward of a Linear / activation stack (the policy and the critic of the rollout: `BaseModule.forward` under no_grad,
+// reference agents/modules/modules.py:47-63 called from mh_ppo.py:286-290 once per control step) as ONE launch on the gfx950 matrix cores.
+//
+// At the rollout's 4 096 rows a layer-by-layer GEMM chain is launch- and tail-bound: 380 -> 512 -> 256 -> 128 -> 23 is four launches whose
+// later layers have 128 / 64 / 16 output tiles for 256 CUs, and every activation makes a round trip through HBM (76 us for 3 GFLOP).  Here a
+// workgroup owns 16 ROWS and carries them through every layer:
+//   * 4 096 rows = 256 workgroups = one per CU, 8 waves each; the activations of the 16 rows live in two LDS images (ping-pong), never in HBM;
+//   * a wave owns a run of 16-column output tiles of the layer (`v_mfma_f32_16x16x4_f32`, f32 in / f32 accumulate: the same arithmetic class
+//     as the library GEMM, k-ordered fmaf chains); its B operand — rows of the weight matrix, used by this wave only — goes STRAIGHT from
+//     global memory (L2-resident: 1.4 MB / 3.8 MB per network) to the MFMA's registers, from a PACKED copy of the weights (`pbhc_mlp_pack`,
+//     once per rollout: the weights are constant over its 24 steps) in which the 64 lanes' 16-byte fragments of one (tile, k-step) are 1 KiB
+//     contiguous: lane (j, g) holds W[n0 + j][k0 + 4 g .. + 3], i.e. the k index of MFMA step s is k0 + 4 g + s for lane group g — the A
+//     fragment is read from LDS with the same permutation (one ds_read_b128 per 16 k), and a k permutation common to both operands leaves
+//     the product unchanged.  (Reading the fragments from the nn.Linear layout — 16 rows x 64 bytes per wave-instruction, consecutive lanes
+//     on different rows — cost ~77 cycles per load in the texture addresser: 51 us for the actor at ANY row count from 64 to 4 096;)
+//   * three k-steps of B loads are in flight per wave (register ring of four), the accumulators get bias + activation and are stored as the next
+//     layer's A image (row pitch = 4 mod 32 words: conflict-free ds_write_b32 per 32-lane half); the last layer goes to global memory.
+// Rounding differs from the layer-by-layer path by summation order only (pinned against fp64 by tests/test_gpu_gemm.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pbhc_hip.h"
+
+extern thread_local char g_pbhc_err[512];
+#define MLP_FAIL(code, ...) do { snprintf(g_pbhc_err, sizeof(g_pbhc_err), __VA_ARGS__); return (code); } while (0)
+#define MLP_ARG(cond) do { if (!(cond)) MLP_FAIL(PBHC_EINVAL, "%s: argument check failed: %s", __func__, #cond); } while (0)
+#define MLP_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) MLP_FAIL(PBHC_EHIP, "%s: %s: %s", __func__, #expr, hipGetErrorString(e_)); } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) MlpF4U { f32x4 v; };
+
+#ifndef MLP_WAVES
+#define MLP_WAVES 8
+#endif
+#define MLP_T (64 * MLP_WAVES)
+#define MLP_ROWS 16
+#ifndef MLP_NST
+#define MLP_NST 4                                          // B register ring: k-steps of loads in flight per wave (2 / 3 / 4 measured: 38.6 / 38.2 / 37.1 us)
+#endif
+
+struct MlpArgs {
+  const float* w[PBHC_MLP_MAX_LAYERS];
+  const float* b[PBHC_MLP_MAX_LAYERS];
+  int dim[PBHC_MLP_MAX_LAYERS + 1];
+  int nl, act, M, ldx, ldy, pitch0, pitch1;                // pitch0 / pitch1: row pitch (floats) of the even / odd activation image
+  const float* x;
+  float* y;
+};
+
+__host__ __device__ __forceinline__ int mlp_pitch(int k) { return ((k + 15) & ~15) + 4; }   // zero-padded to a whole k-step; 4 mod 32 words where it matters
+
+__device__ __forceinline__ float mlp_act(int act, float v) {
+  if (act == 1) return v > 0.0f ? v : expf(v) - 1.0f;       // ATen's GPU ELU: exp(x) - 1 in f32
+  if (act == 2) return v / (1.0f + expf(-v));             // SiLU as ATen computes it
+  if (act == 3) return v > 0.0f ? v : 0.0f;
+  return v;
+}
+
+// T output tiles (16 columns each) of one layer for this wave: acc[t] += A[16, Kp] . Wp[tile_t]^T, Kp = K rounded up to 16 (both operands are
+// zero there), `nks` = Kp / 16 k-steps, Wp = the layer's packed weights [tile][k-step][lane][4].
+template <int T>
+__device__ __forceinline__ void mlp_tiles(const float* __restrict__ Wp, int nks, const int (&tile)[T], const float* __restrict__ A, int P, f32x4 (&acc)[T]) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  unsigned int woff[T];                                    // byte offset of this lane's fragment of the tile's k-step 0 (< 2^30: checked on the host)
+#pragma unroll
+  for (int t = 0; t < T; ++t) woff[t] = ((unsigned int)(tile[t] * nks) * 64u + (unsigned int)lane) * 16u;
+  const float* arow = A + j * P + 4 * g;
+  f32x4 breg[MLP_NST][T];
+  // every ring load is UNCONDITIONAL (k-step clamped to the last one: a few redundant loads at the end of a tile run): a load under a
+  // branch makes the compiler's waitcnt pass assume the worst at the join and drain the ring (vmcnt(0)) once per unrolled round
+  const int klast = nks - 1;
+#pragma unroll
+  for (int s = 0; s < MLP_NST - 1; ++s) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) breg[s][t] = *reinterpret_cast<const f32x4*>((const char*)Wp + woff[t] + 1024u * (unsigned int)min(s, klast));
+  }
+  f32x4 a = *reinterpret_cast<const f32x4*>(arow);         // A fragment of the step at hand; the next one is read under this step's MFMAs
+  for (int k0 = 0; k0 < nks; k0 += MLP_NST) {
+#pragma unroll
+    for (int u = 0; u < MLP_NST; ++u) {
+      const int k = k0 + u;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        breg[(u + MLP_NST - 1) % MLP_NST][t] = *reinterpret_cast<const f32x4*>((const char*)Wp + woff[t] + 1024u * (unsigned int)min(k + MLP_NST - 1, klast));
+      if (k < nks) {
+        const f32x4 an = *reinterpret_cast<const f32x4*>(arow + 16 * min(k + 1, klast));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], breg[u][t][s], acc[t], 0, 0, 0);
+        }
+        a = an;
+      }
+    }
+  }
+}
+
+// tiles [first, first + T) of layer `l` for this wave: product, bias, activation, store (next A image, or global rows for the last layer)
+template <int T>
+__device__ __forceinline__ void mlp_run(const MlpArgs& a, int l, int first, int ntiles, const float* __restrict__ A, int P, float* __restrict__ O, int PO, int row0) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int K = a.dim[l], N = a.dim[l + 1];
+  int tile[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) tile[t] = min(first + t, ntiles - 1);
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mlp_tiles<T>(a.w[l], (K + 15) >> 4, tile, A, P, acc);
+  const bool last = l == a.nl - 1;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (first + t >= ntiles) continue;                      // (a clamped duplicate of the wave's last tile)
+    const int n = 16 * tile[t] + j;
+    const float bias = (a.b[l] && n < N) ? a.b[l][n] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = 4 * g + v;
+      float val = acc[t][v] + bias;
+      if (!last) {
+        val = n < N ? mlp_act(a.act, val) : 0.0f;         // columns [N, ceil16(N)) of the next A image are zeros
+        O[r * PO + n] = val;
+      } else if (n < N && row0 + r < a.M) {
+        a.y[(size_t)(row0 + r) * a.ldy + n] = val;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs a) {
+  extern __shared__ float mlp_smem[];
+  float* const img0 = mlp_smem;                            // (offsets into the one shared array, so that every access stays a DS instruction)
+  const int off1 = MLP_ROWS * a.pitch0;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const int wave = threadIdx.x >> 6;
+  {
+    // the 16 input rows -> image 0, zero-padded to the 16-wide k-step (rows past M: the last row again, never stored)
+    const int K = a.dim[0], P = a.pitch0, Kp = (K + 15) & ~15;
+    const bool vec = (a.ldx & 3) == 0 && (((uintptr_t)a.x) & 15) == 0 && a.ldx >= ((K + 3) & ~3);
+    if (vec) {
+      const int cpr = Kp >> 2;                             // 16-byte chunks per row
+      for (int i = threadIdx.x; i < MLP_ROWS * cpr; i += MLP_T) {
+        const int r = i / cpr, c = (i - r * cpr) << 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < K) {
+          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)min(row0 + r, a.M - 1) * a.ldx + c);      // may cover row padding: masked below
+          if (c + 1 >= K) v[1] = 0.f;
+          if (c + 2 >= K) v[2] = 0.f;
+          if (c + 3 >= K) v[3] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(img0 + r * P + c) = v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < MLP_ROWS * Kp; i += MLP_T) {
+        const int r = i / Kp, c = i - r * Kp;
+        img0[r * P + c] = c < K ? a.x[(size_t)min(row0 + r, a.M - 1) * a.ldx + c] : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < a.nl; ++l) {
+    const float* A = mlp_smem + ((l & 1) ? off1 : 0);
+    float* O = mlp_smem + ((l & 1) ? 0 : off1);
+    const int P = (l & 1) ? a.pitch1 : a.pitch0, PO = (l & 1) ? a.pitch0 : a.pitch1;
+    const int ntiles = (a.dim[l + 1] + 15) >> 4;
+    const int per = (ntiles + MLP_WAVES - 1) / MLP_WAVES;   // tiles per wave (wave-uniform run [wave * per, ...))
+    int first = wave * per;
+    const int end = min(first + per, ntiles);
+    while (first < end) {
+      const int n = end - first;
+      if (n >= 4) { mlp_run<4>(a, l, first, ntiles, A, P, O, PO, row0); first += 4; }
+      else if (n == 3) { mlp_run<3>(a, l, first, ntiles, A, P, O, PO, row0); first += 3; }
+      else if (n == 2) { mlp_run<2>(a, l, first, ntiles, A, P, O, PO, row0); first += 2; }
+      else { mlp_run<1>(a, l, first, ntiles, A, P, O, PO, row0); first += 1; }
+    }
+    __syncthreads();
+  }
+}
+
+// nn.Linear.weight [N, K] -> [ceil(N/16)][ceil(K/16)][64 lanes][4]: lane (j = l % 16, g = l / 16) of (tile, k-step) holds
+// W[16 tile + j][16 kstep + 4 g .. + 3], zeros outside the matrix
+__global__ void k_mlp_pack(const float* __restrict__ w, int N, int K, float* __restrict__ out, int nks, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int lane = (int)(i & 63);
+  const size_t ts = i >> 6;
+  const int ks = (int)(ts % (size_t)nks), tile = (int)(ts / (size_t)nks);
+  const int n = 16 * tile + (lane & 15), k = 16 * ks + 4 * (lane >> 4);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    const float* p = w + (size_t)n * K + k;
+    if (k < K) v[0] = p[0];
+    if (k + 1 < K) v[1] = p[1];
+    if (k + 2 < K) v[2] = p[2];
+    if (k + 3 < K) v[3] = p[3];
+  }
+  reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
+extern "C" {
+
+size_t pbhc_mlp_packed_floats(int N, int K) { return (size_t)((N + 15) / 16) * (size_t)((K + 15) / 16) * 256; }
+
+int pbhc_mlp_pack(const float* w, int N, int K, float* packed, void* stream) {
+  MLP_ARG(w && packed && N >= 1 && K >= 1 && (((uintptr_t)packed) & 15) == 0);
+  const size_t total4 = pbhc_mlp_packed_floats(N, K) / 4;
+  hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, packed, (K + 15) / 16, total4);
+  MLP_HIP(hipGetLastError());
+  return PBHC_OK;
+}
+
+size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers) {
+  int p0 = 0, p1 = 0;
+  for (int l = 0; l < num_layers; ++l) {                   // image (l & 1) holds layer l's input
+    const int p = mlp_pitch(dims[l]);
+    if (l & 1) p1 = p > p1 ? p : p1; else p0 = p > p0 ? p : p0;
+  }
+  return (size_t)MLP_ROWS * (size_t)(p0 + p1) * sizeof(float);
+}
+
+int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                 int M, void* stream) {
+  MLP_ARG(x && weights && biases && dims && y && M >= 1 && num_layers >= 1 && num_layers <= PBHC_MLP_MAX_LAYERS && act >= 0 && act <= 3);
+  MLP_ARG(ldx >= dims[0] && ldy >= dims[num_layers] && (((uintptr_t)x) & 3) == 0);
+  MlpArgs a;
+  a.nl = num_layers; a.act = act; a.M = M; a.ldx = ldx; a.ldy = ldy; a.x = x; a.y = y;
+  a.pitch0 = a.pitch1 = 0;
+  for (int l = 0; l <= num_layers; ++l) {
+    MLP_ARG(dims[l] >= 1 && dims[l] <= 4096);
+    a.dim[l] = dims[l];
+  }
+  for (int l = 0; l < num_layers; ++l) {
+    MLP_ARG(weights[l] && (((uintptr_t)weights[l]) & 15) == 0 && pbhc_mlp_packed_floats(dims[l + 1], dims[l]) < (1u << 28));      // packed (pbhc_mlp_pack)
+    a.w[l] = weights[l];
+    a.b[l] = biases[l];
+    const int p = mlp_pitch(dims[l]);
+    if (l & 1) a.pitch1 = p > a.pitch1 ? p : a.pitch1; else a.pitch0 = p > a.pitch0 ? p : a.pitch0;
+  }
+  if (a.pitch1 == 0) a.pitch1 = 4;
+  const size_t lds = (size_t)MLP_ROWS * (size_t)(a.pitch0 + a.pitch1) * sizeof(float);
+  MLP_ARG(lds <= 160 * 1024);
+  static size_t lds_allowed = 64 * 1024;                   // raised once per process on the first wide stack (the first rollout runs outside any capture)
+  if (lds > lds_allowed) {
+    MLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_allowed = 160 * 1024;
+  }
+  hipLaunchKernelGGL(k_mlp_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_T), lds, (hipStream_t)stream, a);
+  MLP_HIP(hipGetLastError());
+  return PBHC_OK;
+}
+
+}  // extern "C"

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_policy_sample(const float* __restrict__
 __global__ __launch_bounds__(256) void k_rollout_post(const float* __restrict__ rew, const float* __restrict__ values, const int64_t* __restrict__ reset_buf,
                                                       const uint8_t* __restrict__ time_outs, int N, int R, float gamma, float* __restrict__ rewards_out,
                                                       uint8_t* __restrict__ dones_out, float* __restrict__ cur_rew, float* __restrict__ cur_len,
-                                                      double* __restrict__ ep_stats) {
+                                                      double* __restrict__ ep_stats, uint8_t* __restrict__ time_outs_out) {
   __shared__ double sh[3][8];
   const int lane = threadIdx.x & 31, lr = threadIdx.x >> 5, row = blockIdx.x * 8 + lr;
   const bool valid = row < N;
@@ -430,13 +430,14 @@ __global__ __launch_bounds__(256) void k_rollout_post(const float* __restrict__ 
   if (valid && lane < R) {
     const size_t i = (size_t)row * R + lane;
     r = rew[i];
-    rewards_out[i] = r + gamma * values[i] * to;
+    rewards_out[i] = values ? r + gamma * values[i] * to : r;      // values == NULL: the caller adds the time-out bootstrap later (batched critic)
   }
   const float rsum = gsum32(r);
   double a = 0.0, b = 0.0, c = 0.0;
   if (valid && lane == 0) {
     const bool done = reset_buf[row] > 0;
     dones_out[row] = done ? 1 : 0;
+    if (time_outs_out) time_outs_out[row] = time_outs[row];
     const float cr = cur_rew[row] + rsum, cl = cur_len[row] + 1.0f;
     if (done) { a = (double)cr; b = (double)cl; c = 1.0; }
     cur_rew[row] = done ? 0.0f : cr;
@@ -462,13 +463,20 @@ int pbhc_policy_sample(const float* mu, const float* std, const float* value, in
   return PBHC_OK;
 }
 
-int pbhc_rollout_post(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
-                      float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, void* stream) {
-  ARG_CHECK(rew && values && reset_buf && time_outs && rewards_out && dones_out && cur_reward_sum && cur_episode_length && ep_stats && N >= 1 && R >= 1 && R <= 32);
+int pbhc_rollout_post2(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
+                       float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, uint8_t* time_outs_out,
+                       void* stream) {
+  ARG_CHECK(rew && reset_buf && time_outs && rewards_out && dones_out && cur_reward_sum && cur_episode_length && ep_stats && N >= 1 && R >= 1 && R <= 32);
   hipLaunchKernelGGL(k_rollout_post, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, rew, values, reset_buf, time_outs, N, R, gamma, rewards_out, dones_out,
-                     cur_reward_sum, cur_episode_length, ep_stats);
+                     cur_reward_sum, cur_episode_length, ep_stats, time_outs_out);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
+}
+
+int pbhc_rollout_post(const float* rew, const float* values, const int64_t* reset_buf, const uint8_t* time_outs, int N, int R, float gamma,
+                      float* rewards_out, uint8_t* dones_out, float* cur_reward_sum, float* cur_episode_length, double* ep_stats, void* stream) {
+  ARG_CHECK(values);
+  return pbhc_rollout_post2(rew, values, reset_buf, time_outs, N, R, gamma, rewards_out, dones_out, cur_reward_sum, cur_episode_length, ep_stats, nullptr, stream);
 }
 
 int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,

@@ -176,3 +176,64 @@ def test_window_conv_strided_batch_matches_conv1d(cfg, act_cls):
     new = [y.detach(), x.grad, conv.weight.grad, conv.bias.grad]
     for a, b in zip(ref, new):
         assert a.shape == b.shape and (a - b).abs().max().item() < 3e-5 * max(1.0, a.abs().max().item())
+
+
+# whole-stack forward (`pbhc_mlp_fwd`, csrc/pbhc_mlp.hip): (rows, layer widths, x row pitch or 0 for contiguous).  The rollout's actor and
+# critic on padded slabs, ragged rows (tail workgroup), widths that are not multiples of 16 / 4 (k tails, ragged output tiles), one layer
+STACKS = [(4096, [380, 512, 256, 128, 23], 384), (4096, [630, 768, 512, 128, 21], 640), (1000, [380, 512, 256, 128, 23], 0), (37, [630, 768, 512, 128, 21], 0),
+          (16, [5, 7], 0), (130, [37, 50, 19, 3], 40), (64, [64, 64], 0), (33, [23, 1000, 30, 60, 17, 4], 0)]
+
+
+@pytest.mark.parametrize("stack", STACKS)
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_mlp_stack_forward_matches_fp64(stack, act):
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, dims, pitch = stack
+    g = torch.Generator(device="cuda").manual_seed(77 * act + M + sum(dims))
+    xs = torch.randn(M, pitch or dims[0], device="cuda", generator=g)
+    x = xs[:, :dims[0]]
+    Ws = [torch.randn(dims[i + 1], dims[i], device="cuda", generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [0.1 * torch.randn(dims[i + 1], device="cuda", generator=g) for i in range(len(dims) - 1)]
+    n = len(Ws)
+    packed = [torch.empty(lib.pbhc_mlp_packed_floats(t.shape[0], t.shape[1]), device="cuda") for t in Ws]
+    for t, pk in zip(Ws, packed):
+        _lib.check(lib.pbhc_mlp_pack(t.data_ptr(), t.shape[0], t.shape[1], pk.data_ptr(), _lib.current_stream()), "pbhc_mlp_pack")
+    w = (C.c_void_p * n)(*[t.data_ptr() for t in packed])
+    b = (C.c_void_p * n)(*[t.data_ptr() for t in bs])
+    d = (C.c_int * (n + 1))(*dims)
+    assert lib.pbhc_mlp_fwd_lds_bytes(d, n) <= 160 * 1024
+    y = torch.full((M, dims[-1] + 3), 7.0, device="cuda")                       # wider rows: the columns beyond the output must stay untouched
+    _lib.check(lib.pbhc_mlp_fwd(x.data_ptr(), x.stride(0), w, b, d, n, act, y.data_ptr(), y.stride(0), M, _lib.current_stream()), "pbhc_mlp_fwd")
+    h = x.double()
+    for i in range(n):
+        h = h @ Ws[i].double().t() + bs[i].double()
+        if i < n - 1:
+            h = _act_ref(act, h)
+    torch.cuda.synchronize()
+    err = (y[:, :dims[-1]].double() - h).abs().max().item()
+    assert err < TOL, err
+    assert torch.all(y[:, dims[-1]:] == 7.0)
+
+
+def test_module_inference_forward_uses_the_stack_kernel_and_matches_layers():
+    """BaseModule.forward under no_grad (the rollout's path): whole-stack kernel == the layer-by-layer fused path == nn.Sequential"""
+    from pbhc_amd.agents import fused_mlp
+
+    torch.manual_seed(3)
+    seq = nn.Sequential(nn.Linear(380, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, 23)).cuda()
+    slab = torch.randn(4096, 384, device="cuda")
+    x = slab[:, :380]
+    with torch.no_grad():
+        ref = seq(x)
+        b = fused_mlp.forward_inference(seq, x)                  # layer by layer
+        assert fused_mlp.pack_stack(seq)
+        a = fused_mlp.forward_inference(seq, x)                  # whole stack
+        seq[0].weight.mul_(2.0)                                  # the owner changes the weights: release, then the layer path sees them
+        fused_mlp.release_stack(seq)
+        c = fused_mlp.forward_inference(seq, x)
+        ref2 = seq(x)
+    torch.cuda.synchronize()
+    assert (a - ref).abs().max().item() < TOL and (b - ref).abs().max().item() < TOL and (c - ref2).abs().max().item() < 2 * TOL
+    assert not torch.equal(a, b)                                 # (different summation order: the two paths really are different kernels)

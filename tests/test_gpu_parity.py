@@ -547,11 +547,12 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
-def _rollouts_with_split(split, agent="v1"):
+def _rollouts_with_split(split, agent="v1", batched=False):
     """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state"""
     import os
 
     os.environ["PBHC_ROLLOUT_SPLIT"] = "1" if split else "0"
+    os.environ["PBHC_CRITIC_BATCHED"] = "1" if batched else "0"
     try:
         torch.manual_seed(11)
         np.random.seed(11)
@@ -577,20 +578,38 @@ def _rollouts_with_split(split, agent="v1"):
         out["globals"] = env.globals.clone()
         out["episode_sums"] = env._episode_sums.clone()
         out["ep_stats"] = algo._ep_stats.clone()
+        if batched:
+            out["_time_outs_seen"] = algo._time_outs.any().reshape(1)
         return out
     finally:
         os.environ.pop("PBHC_ROLLOUT_SPLIT", None)
+        os.environ.pop("PBHC_CRITIC_BATCHED", None)
 
 
 @pytest.mark.parametrize("agent", ["v1", "v2"])
 def test_rollout_branch_stream_equals_one_stream(agent):
-    """The rollout keeps the env step's reduction, the bootstrap kernel (and the v1 critic) on a branch stream next to the step -> policy ->
-    sampling chain; that is a schedule, not arithmetic: buffers, globals (sigma EMA, curricula, step counter) and episode statistics are
-    bit-identical to the one-stream order (mh_ppo.py:270-342, ppo_mimic.py:371-438)."""
+    """The rollout keeps the env step's reduction and the bootstrap kernel (and the v1 per-step critic) on a branch stream next to the
+    step -> policy -> sampling chain; that is a schedule, not arithmetic: buffers, globals (sigma EMA, curricula, step counter) and episode
+    statistics are bit-identical to the one-stream order (mh_ppo.py:270-342, ppo_mimic.py:371-438)."""
     a = _rollouts_with_split(True, agent)
     b = _rollouts_with_split(False, agent)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_rollout_batched_critic_equals_per_step_critic():
+    """MHPPO's default rollout evaluates the critic ONCE over all T slabs after the loop and adds the time-out bootstrap
+    (rewards += gamma * values * time_outs, mh_ppo.py:300-305) then; against the per-step critic everything the critic does not feed is
+    bit-identical, and values / rewards / returns / advantages agree to GEMM rounding (different tile shapes at 98 304 rows)."""
+    a = _rollouts_with_split(True, "v1", batched=True)
+    b = _rollouts_with_split(True, "v1", batched=False)
+    soft = {"values": 2e-5, "rewards": 2e-5, "returns": 1e-4, "advantages": 2e-4}
+    assert bool(a.pop("_time_outs_seen"))            # envs reach the end of the clip inside the rollout: the bootstrap term is exercised
+    for k in a:
+        if k in soft:
+            close(a[k], b[k], soft[k], "batched critic " + k, rtol=1e-5)
+        else:
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_learn_runs_two_iterations():
