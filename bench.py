@@ -316,7 +316,16 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     nets = list(algo.alg.named_parameters()) if hasattr(algo, "alg") else list(algo.actor.named_parameters()) + list(algo.critic.named_parameters())
     flops_per_sample = 2.0 * sum(p.numel() for n, p in nets if n.endswith("weight") and p.dim() == 2)     # Linear layers only (conv windows not counted)
-    upd_flops = 3.0 * flops_per_sample * T * N * algo.num_learning_epochs
+    upd_flops_3x = 3.0 * flops_per_sample * T * N * algo.num_learning_epochs          # SURVEY 8d's convention: backward = 2 x forward for every layer
+    if hasattr(algo, "alg"):
+        upd_flops, flops_note = upd_flops_3x, "Linear layers x 3 (the encoders' conv windows are not counted; the main stacks' inputs carry gradients)"
+    else:
+        # EXECUTED work: forward + weight gradient of every layer, input gradient of every layer but a stack's first (observations need none)
+        per = 0.0
+        for m in (algo.actor.actor_module.module, algo.critic.critic_module.module):
+            lins = [l for l in m if isinstance(l, torch.nn.Linear)]
+            per += sum(2.0 * l.in_features * l.out_features * (3.0 if i else 2.0) for i, l in enumerate(lins))
+        upd_flops, flops_note = per * T * N * algo.num_learning_epochs, "executed GEMM work (no input gradient for the first layers)"
     n_grad = sum(p.numel() for _, p in nets)
     ar_ms = allreduce_probe(n_grad, device) if dp else None
     out = None
@@ -334,7 +343,9 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "note": "whole update phase, fp32: fused MFMA forward / input-gradient Linear kernels + library weight-gradient GEMMs + loss + gather + Adam"},
+                                "frac": upd_flops / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "flops": upd_flops, "flops_counted": flops_note,
+                                "frac_by_3x_forward_convention": upd_flops_3x / (update_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                "note": "whole update phase, fp32: fused MFMA forward / input-gradient Linear kernels + library weight-gradient GEMMs + loss + gather + Adam"},
         }
         if dp:
             out["collectives"] = {"backend": backend, "all_reduces_per_iter": coll["all_reduce"] / K, "all_reduce_bytes_per_iter": coll["all_reduce_bytes"] / K,

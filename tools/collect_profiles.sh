@@ -24,3 +24,11 @@ python3 tools/gemm_probe.py 24576 > gpurun_out/prof2/gemm_probe_24576.txt 2>&1
 python3 tools/gemm_probe.py 4096 > gpurun_out/prof2/gemm_probe_4096.txt 2>&1
 python3 tools/gemm_ablation.py 0 > gpurun_out/prof2/gemm_ablation.txt 2>&1
 python3 tools/mfma_peak_probe.py > gpurun_out/prof2/mfma_peak.txt 2>&1
+# rollout: one control step kernel by kernel on both streams, the loop's period and the tail (batched critic, bootstrap, GAE); the whole-stack
+# policy kernel against the layer chain
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof2/rtl -- python3 tools/rollout_trace_probe.py > gpurun_out/prof2/rtl.log 2>&1
+python3 tools/rollout_timeline.py gpurun_out/prof2/rtl > gpurun_out/prof2/rollout_step_timeline.txt
+python3 tools/rollout_tail_timeline.py gpurun_out/prof2/rtl > gpurun_out/prof2/rollout_tail_timeline.txt
+find gpurun_out/prof2/rtl -name "*.csv" -size +4M -delete
+for n in 64 1024 4096; do python3 tools/mlp_probe.py $n 2>&1 | grep rows; done > gpurun_out/prof2/mlp_stack_probe.txt
+python3 tools/rollout_host_time.py 2>&1 | grep "^rollout" > gpurun_out/prof2/rollout_host_time.txt
