@@ -497,6 +497,24 @@ int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_strid
  * the caller repacks when the weights change (once per rollout: they are constant over its steps).  biases[l] may be NULL; act as
  * pbhc_linear_act_fwd.  pbhc_mlp_fwd_lds_bytes: the launch's dynamic LDS (<= 160 KB or the call is refused). */
 #define PBHC_MLP_MAX_LAYERS 8
+/* pbhc_mlp_fwd_sample: the policy's stack with pbhc_policy_sample folded into the last layer's epilogue (mh_ppo.py:286-296: the rollout's
+ * act() + log-prob + buffer writes): mu = the stack's output [M, A] (A = dims[L] <= 32), actions = mu + std * z with z from the Philox call
+ * pbhc_policy_sample makes — keyed by seed / (uint32)counter[0] + counter_offset / row / column — action_mean = mu, action_sigma = std,
+ * logp[M] = the row's Normal log-density.  `counter`: a device double the caller keeps constant over a rollout (a snapshot of the env's step
+ * counter at its start) with counter_offset = the step index, so that the launch does not wait for the previous step's reduction. */
+typedef struct PbhcMlpSample {
+  const float* std;            /* [A] */
+  const double* counter;
+  uint64_t seed;
+  int32_t counter_offset;
+  int32_t pad_;
+  float* actions;              /* [M, A] */
+  float* action_mean;          /* [M, A] */
+  float* action_sigma;         /* [M, A] */
+  float* logp;                 /* [M] */
+} PbhcMlpSample;
+int pbhc_mlp_fwd_sample(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, int M,
+                        const PbhcMlpSample* sample, void* stream);
 size_t pbhc_mlp_packed_floats(int N, int K);
 int pbhc_mlp_pack(const float* w, int N, int K, float* packed, void* stream);
 size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers);

@@ -82,13 +82,14 @@ PbhcOutMap = _S["PbhcOutMap"]
 PbhcEnvConfig = _S["PbhcEnvConfig"]
 PbhcMotionTable = _S["PbhcMotionTable"]
 PbhcStepIO = _S["PbhcStepIO"]
+PbhcMlpSample = _S["PbhcMlpSample"]
 
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
            "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
-           "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2"]
+           "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample"]
 
 
 class PbhcError(RuntimeError):
@@ -134,6 +135,7 @@ def _load():
     lib.pbhc_linear_act_fwd_strided.argtypes = [vp, i, C.c_longlong, vp, vp, vp, vp, i, C.c_longlong, i, i, i, i, i, vp]
     lib.pbhc_linear_wgrad.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.pbhc_mlp_fwd.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, vp, i, i, vp]
+    lib.pbhc_mlp_fwd_sample.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, i, C.POINTER(PbhcMlpSample), vp]
     lib.pbhc_mlp_fwd_lds_bytes.argtypes = [C.POINTER(i), i]
     lib.pbhc_mlp_fwd_lds_bytes.restype = C.c_size_t
     lib.pbhc_mlp_pack.argtypes = [vp, i, i, vp, vp]

@@ -268,6 +268,25 @@ def forward_inference(seq, x):
     return torch.addmm(lin[-1].bias, h, lin[-1].weight.t())
 
 
+def forward_sample(seq, x, std, seed, counter, counter_offset, actions, action_mean, action_sigma, logp):
+    """The policy stack AND the rollout's sampling (mh_ppo.py:286-296: act(), log-prob, the buffer writes) as one launch
+    (`pbhc_mlp_fwd_sample`); needs pack_stack(seq).  Returns False — nothing launched — where that does not apply (the caller then runs
+    forward_inference + pbhc_policy_sample)."""
+    c = getattr(seq, "_pbhc_stack", None)
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    B = x.shape[0]
+    if not (c is not None and c["valid"] and B <= _STACK_MAX_ROWS and x.dim() == 2 and x.stride(1) == 1 and lin[-1].out_features <= 32
+            and actions.is_contiguous() and action_mean.is_contiguous() and action_sigma.is_contiguous() and logp.is_contiguous()):
+        return False
+    smp = _lib.PbhcMlpSample()
+    smp.std, smp.counter, smp.seed, smp.counter_offset = std.data_ptr(), counter, int(seed), int(counter_offset)
+    smp.actions, smp.action_mean, smp.action_sigma, smp.logp = actions.data_ptr(), action_mean.data_ptr(), action_sigma.data_ptr(), logp.data_ptr()
+    act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
+    _lib.check(_lib.lib().pbhc_mlp_fwd_sample(x.data_ptr(), x.stride(0), c["w"], c["b"], c["dims"], len(lin), act, B, C.byref(smp), _lib.current_stream()),
+               "pbhc_mlp_fwd_sample")
+    return True
+
+
 def forward(seq, x):
     """seq: nn.Sequential of Linear / activation; x [B, in]."""
     params = []

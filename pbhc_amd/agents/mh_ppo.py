@@ -427,7 +427,24 @@ class MHPPO:
             stack_nets = [n_ for n_ in os.environ.get("PBHC_STACK_NETS", "actor").split(",") if n_ and not (batched and n_ == "critic")]
             stacks = [m.module for n_, m in (("actor", self.actor.actor_module), ("critic", self.critic.critic_module)) if n_ in stack_nets and m._fused]
             stacks = [q for q in stacks if fused_mlp.pack_stack(q)]
-            actor_fwd = policy_forward_graphs(self, lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t]), key="actor")
+            # ... and the sampling kernel in that launch's last epilogue, keyed by a snapshot of the step counter + the step index (the same
+            # keys pbhc_policy_sample forms from the live counter, without waiting for the previous step's reduction)
+            fuse_sample = bool(stacks) and stacks[0] is self.actor.actor_module.module and os.environ.get("PBHC_FUSED_SAMPLE", "1") != "0"
+            if fuse_sample:
+                if self.__dict__.get("_ctr0") is None:
+                    self._ctr0 = torch.zeros(1, dtype=torch.float64, device=self.device)
+                env.wait_finalize()
+                self._ctr0.copy_(env.globals[K["PBHC_G_STEP_COUNTER"]:K["PBHC_G_STEP_COUNTER"] + 1])
+                ctr0_p, a_seq = self._ctr0.data_ptr(), self.actor.actor_module.module
+
+                def actor_eager(t):
+                    if not fused_mlp.forward_sample(a_seq, getattr(st, "actor_obs")[t], std, self._sample_seed, ctr0_p, t, st.actions[t], st.action_mean[t],
+                                                    st.action_sigma[t], st.actions_log_prob[t]):
+                        raise _lib.PbhcError("pbhc_mlp_fwd_sample does not apply to this policy (PBHC_FUSED_SAMPLE=0)")
+                    return st.action_mean[t]
+            else:
+                actor_eager = lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t])
+            actor_fwd = policy_forward_graphs(self, actor_eager, key="actor_s" if fuse_sample else "actor")
             critic_fwd = None if batched else policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
             if split:
                 env.set_finalize_stream(br)
@@ -455,8 +472,10 @@ class MHPPO:
                         st.values[t].copy_(critic_fwd(t))
                 mu = actor_fwd(t)
                 if split and t > 0:
-                    cur.wait_event(post_done)          # reduction + bootstrap kernel of step t-1 (13 us of work, issued ~100 us ago)
-                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
+                    cur.wait_event(post_done)          # reduction + book-keeping kernel of step t-1 (13 us of work, issued ~60 us ago)
+                    env.finalize_joined()
+                if not fuse_sample:
+                    _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
                 env.set_obs_outputs(sp["obs_out"])
                 if split and not overlap_step:
                     cur.wait_stream(br)                # the critic of slab t has finished: the fused env step gets the chip to itself

@@ -442,6 +442,7 @@ class PPO:
                 mu, value = fwd(t)
                 if split and t > 0:
                     cur.wait_event(post_done)
+                    env.finalize_joined()
                 _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
                                                   st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
                                                   st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")

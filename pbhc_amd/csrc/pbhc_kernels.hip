@@ -97,9 +97,9 @@ struct Lds {
   enum {
     ACT = 0, ACTD = 32, TAU = 64, Q = 96, QD = 128, RDOF = 160, RDOFV = 192,          // 7 x 32
     ROOT = 224,                                                                      // 16
-    MISC = 240,                                                                      // 48: scalars
-    CF = 288,                                                                        // 108 contact forces
-    BP = 396,                                                                        // body pos3/quat4/vel3/ang3 x Bxp, then the reference's, same shapes
+    MISC = 240,                                                                      // 56: scalars
+    CF = 296,                                                                        // 108 contact forces
+    BP = 404,                                                                        // body pos3/quat4/vel3/ang3 x Bxp, then the reference's, same shapes
     RED_WORDS = 80, FUT_WORDS = 10 * PBHC_MAX_FUTURE                                 // reductions; general tracking: per-step future scratch
   };
   int bq, bv, bw, rp, rq, rv, rw, red, fut, feat;
@@ -121,9 +121,10 @@ enum {
   M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI,                     // general tracking: termination causes, anchor z / gravity-z differences
   M_CLIPCNT,                                                    // clipped actions of this step (role B -> reduction row)
   M_TCONTACT, M_TLOWH,                                          // termination causes: contact on a terminating body, low base height
-  M_TPOSLIM, M_TVELLIM, M_TTAULIM, M_TGATE                      // ... close to a joint position / velocity / torque limit (role B), any of them
+  M_TPOSLIM, M_TVELLIM, M_TTAULIM, M_TGATE,                     // ... close to a joint position / velocity / torque limit (role B), any of them
+  M_ORIGIN0, M_ORIGIN1, M_ORIGIN2, M_CLIP_LEN, M_CLIP_DT, M_CLIP_NF, M_CLIP_ROW0      // env origin + clip meta (role B's prologue loads) for role A's reset path
 };
-static_assert(M_TGATE < 48, "MISC region");
+static_assert(M_CLIP_ROW0 < 56, "MISC region");
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
 // flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
@@ -843,6 +844,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         misc[M_RCONTACT0 + lane] = a * rc0 + bb * rc1;
         if (MODE) feat[c.feat_off[PBHC_F_REF_CONTACT_MASK] + lane] = a * rc0 + bb * rc1;
       }
+      if (lane == 0) {       // for role A's reset path (phase G, after bar2): the env origin and the clip meta without another memory round trip
+        misc[M_ORIGIN0] = origin.x; misc[M_ORIGIN1] = origin.y; misc[M_ORIGIN2] = origin.z;
+        misc[M_CLIP_LEN] = m_len; misc[M_CLIP_DT] = m_dt; misc[M_CLIP_NF] = __int_as_float(m_nf); misc[M_CLIP_ROW0] = __int_as_float(m_row0);
+      }
       if (lane < Bx) {
         st3(rp + 3 * lane, mk3(a * rp0.x + bb * rp1.x + origin.x, a * rp0.y + bb * rp1.y + origin.y, a * rp0.z + bb * rp1.z + origin.z));
         st4(rq + 4 * lane, slerp(rq0, rq1, bb));
@@ -1317,7 +1322,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     const bool do_reset = valid && misc[M_RESET] != 0.0f;
     if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)adelay; }
     if (do_reset) {
-      LOAD_CLIP_META();
+      // env origin + clip meta: role B's prologue loads, handed over in LDS before bar1
+      const f3 origin = mk3(misc[M_ORIGIN0], misc[M_ORIGIN1], misc[M_ORIGIN2]);
+      const float m_len = misc[M_CLIP_LEN], m_dt = misc[M_CLIP_DT];
+      const int m_nf = __float_as_int(misc[M_CLIP_NF]), m_row0 = __float_as_int(misc[M_CLIP_ROW0]);
       for (int dd = lane; dd < D; dd += PBHC_G) {
         act[dd] = 0.0f; actd[dd] = 0.0f;
         float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
@@ -1411,9 +1419,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)
     if (valid && map_words > 0) {
       OBS_GROUPS(0, true);
-      // a terminated env: role B skips the pairs of ITS rows that read post-reset features (it cannot know them before bar3) — this
-      // role, which has just produced them, writes those too: nobody waits for bar3 to finish an observation row
-      if (do_reset) { OBS_GROUPS_LATE(1); }
     }
   } else {
     // =============== role B, interval 2b: state outputs, future targets, the observation rows assigned to this role ================
@@ -1494,6 +1499,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   }
   LDS_BARRIER();                                               // bar3: post-reset features are in LDS
   STAMP(9);
+  // a terminated env (~1 % of them): the pairs of role B's rows that read post-reset features, by role B itself — it is idle from here to bar4
+  // while role A, the chain that sets the kernel's duration, writes the state back (round 2: role A wrote them before bar3, +2.8 k cycles on
+  // exactly the workgroups that finish last)
+  if (roleB && valid && map_words > 0 && misc[M_RESET] != 0.0f) { OBS_GROUPS_LATE(1); }
 
   // =============== interval 3: state write-back (role A) ================================================================================
   if (valid) {

@@ -21,6 +21,7 @@
 #include <stdio.h>
 
 #include "../../include/pbhc_hip.h"
+#include "pbhc_math.h"
 
 extern thread_local char g_pbhc_err[512];
 #define MLP_FAIL(code, ...) do { snprintf(g_pbhc_err, sizeof(g_pbhc_err), __VA_ARGS__); return (code); } while (0)
@@ -46,6 +47,12 @@ struct MlpArgs {
   int nl, act, M, ldx, ldy, pitch0, pitch1;                // pitch0 / pitch1: row pitch (floats) of the even / odd activation image
   const float* x;
   float* y;
+  // optional sampling epilogue of the last layer (the rollout's policy: a ~ Normal(mu, std), pbhc_policy_sample's arithmetic and Philox keys)
+  const float* std;
+  const double* counter;
+  unsigned long long seed;
+  int counter_offset;
+  float *actions, *action_mean, *action_sigma, *logp;
 };
 
 __host__ __device__ __forceinline__ int mlp_pitch(int k) { return ((k + 15) & ~15) + 4; }   // zero-padded to a whole k-step; 4 mod 32 words where it matters
@@ -121,8 +128,27 @@ __device__ __forceinline__ void mlp_run(const MlpArgs& a, int l, int first, int 
       if (!last) {
         val = n < N ? mlp_act(a.act, val) : 0.0f;         // columns [N, ceil16(N)) of the next A image are zeros
         O[r * PO + n] = val;
-      } else if (n < N && row0 + r < a.M) {
-        a.y[(size_t)(row0 + r) * a.ldy + n] = val;
+      } else {
+        const bool ok = n < N && row0 + r < a.M;
+        if (ok && a.y) a.y[(size_t)(row0 + r) * a.ldy + n] = val;
+        if (a.actions) {
+          // mh_ppo.py:286-296 on the accumulators: action = mu + std * z (Box-Muller on one Philox call keyed by row / step counter / column,
+          // exactly k_policy_sample's), the column's log-prob term -> the idle activation image, summed per row after the barrier
+          float lp = 0.0f;
+          if (ok) {
+            const size_t i = (size_t)(row0 + r) * N + n;
+            const float m = val, sg = a.std[n];
+            uint32_t o[4];
+            pbhc::philox4x32((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)(row0 + r), (uint32_t)a.counter[0] + (uint32_t)a.counter_offset, 0x5A4Du, (uint32_t)n, o);
+            const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            const float act = m + sg * z;
+            a.actions[i] = act; a.action_mean[i] = m; a.action_sigma[i] = sg;
+            const float d = act - m;
+            lp = -(d * d) / (2.0f * sg * sg) - logf(sg) - 0.9189385332046727f;
+          }
+          O[r * PO + n] = lp;
+        }
       }
     }
   }
@@ -175,6 +201,13 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs a) {
       else { mlp_run<1>(a, l, first, ntiles, A, P, O, PO, row0); first += 1; }
     }
     __syncthreads();
+    if (l == a.nl - 1 && a.actions && threadIdx.x < MLP_ROWS && row0 + (int)threadIdx.x < a.M) {
+      // log-prob of the row: its columns' terms in column order (a fixed order: deterministic)
+      const int N = a.dim[a.nl];
+      float lp = 0.0f;
+      for (int n = 0; n < N; ++n) lp += O[threadIdx.x * PO + n];
+      a.logp[row0 + threadIdx.x] = lp;
+    }
   }
 }
 
@@ -219,11 +252,18 @@ size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers) {
   return (size_t)MLP_ROWS * (size_t)(p0 + p1) * sizeof(float);
 }
 
-int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
-                 int M, void* stream) {
-  MLP_ARG(x && weights && biases && dims && y && M >= 1 && num_layers >= 1 && num_layers <= PBHC_MLP_MAX_LAYERS && act >= 0 && act <= 3);
-  MLP_ARG(ldx >= dims[0] && ldy >= dims[num_layers] && (((uintptr_t)x) & 3) == 0);
+static int mlp_launch(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                      int M, const PbhcMlpSample* smp, void* stream) {
+  MLP_ARG(x && weights && biases && dims && (y || smp) && M >= 1 && num_layers >= 1 && num_layers <= PBHC_MLP_MAX_LAYERS && act >= 0 && act <= 3);
+  MLP_ARG(ldx >= dims[0] && (!y || ldy >= dims[num_layers]) && (((uintptr_t)x) & 3) == 0);
   MlpArgs a;
+  a.std = nullptr; a.counter = nullptr; a.seed = 0; a.counter_offset = 0;
+  a.actions = a.action_mean = a.action_sigma = a.logp = nullptr;
+  if (smp) {
+    MLP_ARG(smp->std && smp->counter && smp->actions && smp->action_mean && smp->action_sigma && smp->logp);
+    a.std = smp->std; a.counter = smp->counter; a.seed = smp->seed; a.counter_offset = smp->counter_offset;
+    a.actions = smp->actions; a.action_mean = smp->action_mean; a.action_sigma = smp->action_sigma; a.logp = smp->logp;
+  }
   a.nl = num_layers; a.act = act; a.M = M; a.ldx = ldx; a.ldy = ldy; a.x = x; a.y = y;
   a.pitch0 = a.pitch1 = 0;
   for (int l = 0; l <= num_layers; ++l) {
@@ -248,6 +288,18 @@ int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const flo
   hipLaunchKernelGGL(k_mlp_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_T), lds, (hipStream_t)stream, a);
   MLP_HIP(hipGetLastError());
   return PBHC_OK;
+}
+
+int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                 int M, void* stream) {
+  MLP_ARG(y);
+  return mlp_launch(x, ldx, weights, biases, dims, num_layers, act, y, ldy, M, nullptr, stream);
+}
+
+int pbhc_mlp_fwd_sample(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, int M,
+                        const PbhcMlpSample* sample, void* stream) {
+  MLP_ARG(sample);
+  return mlp_launch(x, ldx, weights, biases, dims, num_layers, act, nullptr, 0, M, sample, stream);
 }
 
 }  // extern "C"

@@ -338,6 +338,12 @@ class LeggedRobotMotionTracking:
             torch.cuda.current_stream().wait_event(self._fin_done)
             self._fin_pending = False
 
+    def finalize_joined(self):
+        """The caller has made the stepping stream wait for something it queued on the finalize stream AFTER the last step's reduction
+        (the rollout's book-keeping kernel): that wait covers the reduction, a second cross-stream wait (~10 us of dispatch latency each,
+        signalled or not) is not needed."""
+        self._fin_pending = False
+
     def _flush_statistics(self):
         h = self._stat_pending
         if h is not None:

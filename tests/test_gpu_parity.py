@@ -547,12 +547,13 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
-def _rollouts_with_split(split, agent="v1", batched=False):
+def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True):
     """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state"""
     import os
 
     os.environ["PBHC_ROLLOUT_SPLIT"] = "1" if split else "0"
     os.environ["PBHC_CRITIC_BATCHED"] = "1" if batched else "0"
+    os.environ["PBHC_FUSED_SAMPLE"] = "1" if fused_sample else "0"
     try:
         torch.manual_seed(11)
         np.random.seed(11)
@@ -584,6 +585,7 @@ def _rollouts_with_split(split, agent="v1", batched=False):
     finally:
         os.environ.pop("PBHC_ROLLOUT_SPLIT", None)
         os.environ.pop("PBHC_CRITIC_BATCHED", None)
+        os.environ.pop("PBHC_FUSED_SAMPLE", None)
 
 
 @pytest.mark.parametrize("agent", ["v1", "v2"])
@@ -595,6 +597,20 @@ def test_rollout_branch_stream_equals_one_stream(agent):
     b = _rollouts_with_split(False, agent)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_rollout_fused_sampling_equals_sampling_kernel():
+    """MHPPO's default rollout samples in the policy kernel's last epilogue (`pbhc_mlp_fwd_sample`, keyed by a snapshot of the step counter +
+    the step index) instead of launching `pbhc_policy_sample` on the live counter: the same Philox keys and arithmetic, so every action — and
+    with it every observation, reward and env state of three rollouts — is bit-identical; the log-prob sums its columns in another order."""
+    a = _rollouts_with_split(True, "v1", batched=True, fused_sample=True)
+    b = _rollouts_with_split(True, "v1", batched=True, fused_sample=False)
+    a.pop("_time_outs_seen"); b.pop("_time_outs_seen")
+    for k in a:
+        if k == "actions_log_prob":
+            close(a[k], b[k], 2e-5, "fused sampling log-prob", rtol=1e-6)
+        else:
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_rollout_batched_critic_equals_per_step_critic():
