@@ -616,7 +616,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const int N = rt.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
   const int lane = threadIdx.x & (PBHC_G - 1);
   const int wave = threadIdx.x >> 6;
-  const bool roleB = wave >= 2;                                            // wave-uniform
+  const bool roleB = wave >= 2;                                            // wave-uniform (alternating the roles' waves between co-resident
+                                                                           // workgroups, so that every SIMD holds two waves of each role, measured no change)
   const int le = ((wave & 1) << 1) | ((threadIdx.x >> 5) & 1);             // env slot of this half-wave in the workgroup
   const int env = blockIdx.x * PBHC_EPB + le;
   const bool valid = env < N;
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     // post-reset features of a NON-terminated env (what phase H of role A computes after a reset), the observation maps -> LDS ========
     uint32_t mreg[PBHC_MAPREG];
     if (map_words > 0) {
-      const int wl = threadIdx.x - 2 * PBHC_G * 2;            // 0..127 over the two role-B waves
+      const int wl = threadIdx.x & (2 * PBHC_G * 2 - 1);            // 0..127 over the two role-B waves
 #pragma unroll
       for (int u = 0; u < PBHC_MAPREG; ++u) mreg[u] = map_img[min(wl + u * 128, map_words - 1)];
     }
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       if (MODE && lane < NF) feat[c.feat_off[PBHC_F_CONTACT_MASK] + lane] = misc[M_CFILT0 + lane];
     }
     if (map_words > 0) {
-      const int wl = threadIdx.x - 2 * PBHC_G * 2;
+      const int wl = threadIdx.x & (2 * PBHC_G * 2 - 1);
 #pragma unroll
       for (int u = 0; u < PBHC_MAPREG; ++u) { const int i = wl + u * 128; if (i < map_words) mapl[i] = mreg[u]; }
       for (int i = wl + PBHC_MAPREG * 128; i < map_words; i += 128) mapl[i] = map_img[i];
@@ -1326,6 +1327,29 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       const f3 origin = mk3(misc[M_ORIGIN0], misc[M_ORIGIN1], misc[M_ORIGIN2]);
       const float m_len = misc[M_CLIP_LEN], m_dt = misc[M_CLIP_DT];
       const int m_nf = __float_as_int(misc[M_CLIP_NF]), m_row0 = __float_as_int(misc[M_CLIP_ROW0]);
+      // The start phase and the control delay of the new episode first (one Philox call, computed by every lane: no hand-over), so that the two
+      // table rows of the second lookup — (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was invalidated,
+      // motion_tracking.py:378,536-543,477-507) — are REQUESTED before the per-dof draws, the stores and the episode book-keeping below and
+      // consumed after them: the memory round trip of the lookup runs under ~2.5 k cycles of work instead of behind it.
+      float ue[4];
+      pbhc::rng_uniform4(rt.seed, env, step_ctr, 6, 0, ue);
+      const float mlen = m_len;                              // = tbl.motion_len[mid]
+      const float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
+      const float t2 = (0.0f + 1.0f) * dt + ns;
+      float lk_b = 0.0f, lq0 = 0.0f, lq1 = 0.0f, lv0 = 0.0f, lv1 = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lr0 = 0.0f, lr1 = 0.0f;
+      if (!MODE) {
+        int f0, f1;
+        frame_blend(t2, m_len, m_nf, m_dt, &f0, &f1, &lk_b);
+        const float* r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
+        const float* r1 = tbl.frames + (size_t)(m_row0 + f1) * tbl.row;
+        lq0 = r0[dc]; lq1 = r1[dc]; lv0 = r0[D + dc]; lv1 = r1[D + dc];
+        const int cl = 2 * D + min(lane, 1);
+        lc0 = r0[cl]; lc1 = r1[cl];
+        // the root body's 13 values, one per lane: pos (lanes 0-2), rot (3-6), vel (7-9), ang vel (10-12)
+        const int l13 = min(lane, 12);
+        const int col = l13 < 3 ? o_pos + l13 : (l13 < 7 ? o_rot + l13 - 3 : (l13 < 10 ? o_vel + l13 - 7 : o_ang + l13 - 10));
+        lr0 = r0[col]; lr1 = r1[col];
+      }
       for (int dd = lane; dd < D; dd += PBHC_G) {
         act[dd] = 0.0f; actd[dd] = 0.0f;
         float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
@@ -1357,11 +1381,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
         io.end_time_ratio_buf[env] = etr;
         etr_val = etr;
-        float mlen = m_len;                                  // = tbl.motion_len[mid], in registers since the prologue
         io.motion_len[env] = mlen;
-        float ue[4];                                     // start phase and control delay of the new episode from one Philox call
-        pbhc::rng_uniform4(rt.seed, env, step_ctr, 6, 0, ue);
-        float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
         io.motion_start_times[env] = ns;
         misc[M_NEWSTART] = ns;
         if (c.randomize_ctrl_delay) {
@@ -1373,16 +1393,23 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         misc[M_EPLEN] = 0.0f;
       }
       WAVE_LDS_FENCE();
-      // second lookup at (0+1)*dt + new start: dof + root only (kick_motion_res after the cache was
-      // invalidated, motion_tracking.py:378,536-543,477-507)
-      float t2 = (0.0f + 1.0f) * dt + misc[M_NEWSTART];
       if (MODE) {
         // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
         // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
         motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
         motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, rdof, rdofv, misc + M_RCONTACT0, rp, rq, rv, rw);
       } else {
-        motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, t2, origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
+        // motion_lookup_meta(..., bodies = false, q, qd, ...) on the rows requested above (the same lerp / slerp arithmetic, lane <-> value)
+        const float la = 1.0f - lk_b;
+        if (lane < D) { q[lane] = la * lq0 + lk_b * lq1; qd[lane] = la * lv0 + lk_b * lv1; }
+        if (lane < 2) misc[M_RCONTACT0 + lane] = la * lc0 + lk_b * lc1;
+        const float lin = la * lr0 + lk_b * lr1;
+        if (lane < 3) rp[lane] = lin + (lane == 0 ? origin.x : (lane == 1 ? origin.y : origin.z));
+        else if (lane >= 7 && lane < 10) rv[lane - 7] = lin;
+        else if (lane >= 10 && lane < 13) rw[lane - 10] = lin;
+        const f4 q0r = mk4(__shfl(lr0, 3, PBHC_G), __shfl(lr0, 4, PBHC_G), __shfl(lr0, 5, PBHC_G), __shfl(lr0, 6, PBHC_G));
+        const f4 q1r = mk4(__shfl(lr1, 3, PBHC_G), __shfl(lr1, 4, PBHC_G), __shfl(lr1, 5, PBHC_G), __shfl(lr1, 6, PBHC_G));
+        if (lane == 0) st4(rq, slerp(q0r, q1r, lk_b));
       }
       WAVE_LDS_FENCE();
       if (lane == 0) {
