@@ -427,78 +427,81 @@ class MHPPO:
             stack_nets = [n_ for n_ in os.environ.get("PBHC_STACK_NETS", "actor").split(",") if n_ and not (batched and n_ == "critic")]
             stacks = [m.module for n_, m in (("actor", self.actor.actor_module), ("critic", self.critic.critic_module)) if n_ in stack_nets and m._fused]
             stacks = [q for q in stacks if fused_mlp.pack_stack(q)]
-            # ... and the sampling kernel in that launch's last epilogue, keyed by a snapshot of the step counter + the step index (the same
-            # keys pbhc_policy_sample forms from the live counter, without waiting for the previous step's reduction)
-            fuse_sample = bool(stacks) and stacks[0] is self.actor.actor_module.module and os.environ.get("PBHC_FUSED_SAMPLE", "1") != "0"
-            if fuse_sample:
-                if self.__dict__.get("_ctr0") is None:
-                    self._ctr0 = torch.zeros(1, dtype=torch.float64, device=self.device)
-                env.wait_finalize()
-                self._ctr0.copy_(env.globals[K["PBHC_G_STEP_COUNTER"]:K["PBHC_G_STEP_COUNTER"] + 1])
-                ctr0_p, a_seq = self._ctr0.data_ptr(), self.actor.actor_module.module
+            try:
+                # ... and the sampling kernel in that launch's last epilogue, keyed by a snapshot of the step counter + the step index (the same
+                # keys pbhc_policy_sample forms from the live counter, without waiting for the previous step's reduction)
+                fuse_sample = bool(stacks) and stacks[0] is self.actor.actor_module.module and os.environ.get("PBHC_FUSED_SAMPLE", "1") != "0"
+                if fuse_sample:
+                    if self.__dict__.get("_ctr0") is None:
+                        self._ctr0 = torch.zeros(1, dtype=torch.float64, device=self.device)
+                    env.wait_finalize()
+                    self._ctr0.copy_(env.globals[K["PBHC_G_STEP_COUNTER"]:K["PBHC_G_STEP_COUNTER"] + 1])
+                    ctr0_p, a_seq = self._ctr0.data_ptr(), self.actor.actor_module.module
 
-                def actor_eager(t):
-                    if not fused_mlp.forward_sample(a_seq, getattr(st, "actor_obs")[t], std, self._sample_seed, ctr0_p, t, st.actions[t], st.action_mean[t],
-                                                    st.action_sigma[t], st.actions_log_prob[t]):
-                        raise _lib.PbhcError("pbhc_mlp_fwd_sample does not apply to this policy (PBHC_FUSED_SAMPLE=0)")
-                    return st.action_mean[t]
-            else:
-                actor_eager = lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t])
-            actor_fwd = policy_forward_graphs(self, actor_eager, key="actor_s" if fuse_sample else "actor")
-            critic_fwd = None if batched else policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
-            if split:
-                env.set_finalize_stream(br)
-            post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
-            if batched and self.__dict__.get("_time_outs") is None:
-                self._time_outs = torch.zeros(T, N, 1, dtype=torch.bool, device=self.device)
-            # per-step device addresses, formed once (the host's share of a control step is what bounds the loop once the critic is out of it)
-            sc = self.__dict__.get("_step_ptrs")
-            if sc is None or sc[0] is not st or sc[2] != batched:
-                P = lambda x: x.data_ptr()
-                sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t])),
-                                post=(P(st.rewards[t]), P(st.dones[t])), values=P(st.values[t]),
-                                tout=P(self._time_outs[t]) if batched else None,
-                                act={"actions": st.actions[t]},
-                                obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)], batched)
-                self._step_ptrs = sc
-            steps = sc[1]
-            std_p, sum_p, len_p, stat_p, gamma = std.data_ptr(), self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
-            br_h = br.cuda_stream
-            br.wait_stream(cur)
-            for t in range(T):
-                sp = steps[t]
-                if not batched:
-                    with torch.cuda.stream(br):
-                        st.values[t].copy_(critic_fwd(t))
-                mu = actor_fwd(t)
-                if split and t > 0:
-                    cur.wait_event(post_done)          # reduction + book-keeping kernel of step t-1 (13 us of work, issued ~60 us ago)
-                    env.finalize_joined()
-                if not fuse_sample:
-                    _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
-                env.set_obs_outputs(sp["obs_out"])
-                if split and not overlap_step:
-                    cur.wait_stream(br)                # the critic of slab t has finished: the fused env step gets the chip to itself
-                nxt, rewards, dones, infos = env.step(sp["act"])
-                if self._need_next:
-                    for k in keys:
-                        getattr(st, "next_" + k)[t].copy_(nxt[k])
-                if split:
-                    # branch: [reduction of step t, queued by env.step] -> done / episode-statistics kernel of step t (per-step critic: values[t]
-                    # were produced earlier on this stream and the bootstrap is added here) -> critic of slab t+1 (next iteration)
-                    _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), None if batched else sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                      gamma, *sp["post"], sum_p, len_p, stat_p, sp["tout"], br_h), "pbhc_rollout_post2")
-                    post_done.record(br)
+                    def actor_eager(t):
+                        if not fused_mlp.forward_sample(a_seq, getattr(st, "actor_obs")[t], std, self._sample_seed, ctr0_p, t, st.actions[t], st.action_mean[t],
+                                                        st.action_sigma[t], st.actions_log_prob[t]):
+                            raise _lib.PbhcError("pbhc_mlp_fwd_sample does not apply to this policy (PBHC_FUSED_SAMPLE=0)")
+                        return st.action_mean[t]
                 else:
-                    cur.wait_stream(br)
-                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                     gamma, *sp["post"], sum_p, len_p, stat_p, stream), "pbhc_rollout_post")
-                    br.wait_stream(cur)
-            cur.wait_stream(br)
-            if split:
-                env.set_finalize_stream(None)
-            for q in stacks:
-                fused_mlp.release_stack(q)
+                    actor_eager = lambda t: self.actor.actor_module(getattr(st, "actor_obs")[t])
+                actor_fwd = policy_forward_graphs(self, actor_eager, key="actor_s" if fuse_sample else "actor")
+                critic_fwd = None if batched else policy_forward_graphs(self, lambda t: self.critic.critic_module(getattr(st, "critic_obs")[t]), key="critic")
+                if split:
+                    env.set_finalize_stream(br)
+                post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
+                if batched and self.__dict__.get("_time_outs") is None:
+                    self._time_outs = torch.zeros(T, N, 1, dtype=torch.bool, device=self.device)
+                # per-step device addresses, formed once (the host's share of a control step is what bounds the loop once the critic is out of it)
+                sc = self.__dict__.get("_step_ptrs")
+                if sc is None or sc[0] is not st or sc[2] != batched:
+                    P = lambda x: x.data_ptr()
+                    sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t])),
+                                    post=(P(st.rewards[t]), P(st.dones[t])), values=P(st.values[t]),
+                                    tout=P(self._time_outs[t]) if batched else None,
+                                    act={"actions": st.actions[t]},
+                                    obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)], batched)
+                    self._step_ptrs = sc
+                steps = sc[1]
+                std_p, sum_p, len_p, stat_p, gamma = std.data_ptr(), self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
+                br_h = br.cuda_stream
+                br.wait_stream(cur)
+                for t in range(T):
+                    sp = steps[t]
+                    if not batched:
+                        with torch.cuda.stream(br):
+                            st.values[t].copy_(critic_fwd(t))
+                    mu = actor_fwd(t)
+                    if split and t > 0:
+                        cur.wait_event(post_done)          # reduction + book-keeping kernel of step t-1 (13 us of work, issued ~60 us ago)
+                        env.finalize_joined()
+                    if not fuse_sample:
+                        _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
+                    env.set_obs_outputs(sp["obs_out"])
+                    if split and not overlap_step:
+                        cur.wait_stream(br)                # the critic of slab t has finished: the fused env step gets the chip to itself
+                    nxt, rewards, dones, infos = env.step(sp["act"])
+                    if self._need_next:
+                        for k in keys:
+                            getattr(st, "next_" + k)[t].copy_(nxt[k])
+                    if split:
+                        # branch: [reduction of step t, queued by env.step] -> done / episode-statistics kernel of step t (per-step critic: values[t]
+                        # were produced earlier on this stream and the bootstrap is added here) -> critic of slab t+1 (next iteration)
+                        _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), None if batched else sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                          gamma, *sp["post"], sum_p, len_p, stat_p, sp["tout"], br_h), "pbhc_rollout_post2")
+                        post_done.record(br)
+                    else:
+                        cur.wait_stream(br)
+                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                         gamma, *sp["post"], sum_p, len_p, stat_p, stream), "pbhc_rollout_post")
+                        br.wait_stream(cur)
+                cur.wait_stream(br)
+                if split:
+                    env.set_finalize_stream(None)
+            finally:
+                # (also when a step raises: a stack left marked valid would serve stale weights to every later no-grad forward)
+                for q in stacks:
+                    fused_mlp.release_stack(q)
             if batched:
                 # mh_ppo.py:286-305 for all steps at once: values of every slab, then rewards += gamma * values * time_outs
                 st.values.copy_(self.critic.critic_module(st.critic_obs.flatten(0, 1)).view(T, N, R))

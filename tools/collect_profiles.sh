@@ -32,3 +32,6 @@ python3 tools/rollout_tail_timeline.py gpurun_out/prof2/rtl > gpurun_out/prof2/r
 find gpurun_out/prof2/rtl -name "*.csv" -size +4M -delete
 for n in 64 1024 4096; do python3 tools/mlp_probe.py $n 2>&1 | grep rows; done > gpurun_out/prof2/mlp_stack_probe.txt
 python3 tools/rollout_host_time.py 2>&1 | grep "^rollout" > gpurun_out/prof2/rollout_host_time.txt
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof2/utl -- python3 tools/update_trace_probe.py > gpurun_out/prof2/utl.log 2>&1
+python3 tools/update_step_timeline.py gpurun_out/prof2/utl > gpurun_out/prof2/update_step_timeline.txt
+find gpurun_out/prof2/utl -name "*.csv" -size +4M -delete
