@@ -462,7 +462,7 @@ int pbhc_ppo_loss_scratch_floats(int B);
  * silu_backward + a column sum, agents/modules/modules.py:47-63 under torch.autograd): dz = dy * act'(saved), grad_bias = colsum(dz).
  * act: 0 none (bias gradient of the output layer), 1 ELU from the activation output, 2 SiLU from the pre-activation, 3 ReLU from the
  * output.  dy/saved/dz [B,n] row-major (dz may alias dy), grad_bias [n], scratch >= PBHC_ACT_MAX_BLOCKS * n floats. */
-#define PBHC_ACT_MAX_BLOCKS 512
+#define PBHC_ACT_MAX_BLOCKS 1024
 int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act, float* dz, float* grad_bias, float* scratch, void* stream);
 /* The same in two halves, so that a whole network's bias gradients are finished by ONE launch: pbhc_act_bwd_partials does the slab pass
  * and leaves per-row-block column sums in `scratch` (returns their count in *num_row_blocks); pbhc_colsum_final sums up to

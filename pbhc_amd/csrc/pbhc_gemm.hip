@@ -726,7 +726,7 @@ static hipError_t gemm_launch(const float* A, const float* B, const float* bias,
 
 // tile shapes: 0 = 128x128 (2x2 waves of 2x2 tiles), 1 = 96x128 (1x4 waves of 3x1 tiles: 24576 rows = 256 panels, one per CU when N = 128),
 // 2 = 64x128 (1x4 waves of 2x1)
-static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : 64; }   // (shape 3, forward only: 64 x 64, 2x2 waves of one tile)
+static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : shape == 4 ? 32 : 64; }   // (shape 3, forward only: 64 x 64, 2x2 waves of one tile)
 
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
@@ -767,15 +767,22 @@ static hipError_t gemm_dispatch(int shape, const float* A, const float* B, const
   if constexpr (MODE == 0) {
     if (shape == 3) return gemm_variant<MODE, 2, 2, 1, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
   }
+  if (shape == 4) return gemm_variant<MODE, 1, 4, 1, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);        // 32 x 128
   return gemm_variant<MODE, 1, 4, 2, 1>(A, B, bias, S, C, pre, part, M, N, K, act, st);
 }
 
 // Tile choice (measured on MI355X at the update's 24 576-row minibatch, tools/gemm_probe.py): 64 x 128 tiles, three workgroups per CU, are the
 // fastest for every N >= 256 (1 536 / 1 024 / 768 / 384 ... tiles fill 768 slots in whole rounds); a 128-column layer has one column tile, and
 // 96-row tiles then put exactly one tile on each of the 256 CUs (24 576 = 256 x 96).
-static int pick_shape(int M, int N, int forced, bool forward) {
-  if (forced >= 0 && forced <= 3) return forced;
+static int pick_shape(int M, int N, int K, int forced, bool forward) {
+  if (forced >= 0 && forced <= 4) return forced;
   if (forward && N <= 64) return 3;                        // one 64-column tile holds every output column (the encoders' 60- / 30-wide per-step Linear)
+  // 32 x 128 tiles (one 32 x 32 tile per wave, three to four workgroups per CU) where the K loop is short — the 128-column layers' forward
+  // (K 256 / 512) and the input gradients of layers with <= 128 outputs (K = out_features): more workgroups in flight hide a tile's prologue and
+  // epilogue, which is most of such a launch.  Chosen from the update's own trace (profiles/round2_update_step_timeline.txt: forward 128x256
+  // 28.5 -> 20.0 us, 128x512 36.3 -> 31.9; input gradient 21 -> 128 17.2 -> 10.5, 23 -> 128 15.7 -> 9.2, 128 -> 512 42.3 -> 39.8); the wider layers
+  // lose 2-10 % on it there although a back-to-back probe (tools/gemm_probe.py --shape 2,4, operands warm in L2) shows them 3-8 % faster
+  if (M <= 32 * PBHC_ACT_MAX_BLOCKS && M >= 8192 && (forward ? N <= 128 : K <= 128)) return 4;
   if (N <= 128 && M % 96 == 0 && (M / 96) % 256 == 0) return 1;
   // few rows (the rollout's 4 096-row policy / critic forward): 64 x 64 tiles keep every CU busy where 64 x 128 tiles would leave fewer than two
   // workgroups per CU (measured at 4 096 rows: the six hidden layers 139 us against 181 us for library GEMM + ELU)
@@ -796,7 +803,7 @@ void pbhc_gemm_debug_force_shape(int shape) {
 int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream) {
   GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3);
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0);
-  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, g_force_shape, true), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
+  GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, K, g_force_shape, true), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
   return PBHC_OK;
 }
 
@@ -804,7 +811,7 @@ int pbhc_linear_dgrad_act(const float* dy, const float* w, const float* saved, f
                           int act, void* stream) {
   GEMM_ARG(dy && w && dx && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3 && (act == 0 || saved) && (!scratch || num_row_blocks));
   GEMM_ARG(((uintptr_t)dy & 3) == 0 && ((uintptr_t)w & 3) == 0);
-  int shape = pick_shape(M, N, g_force_shape, false);
+  int shape = pick_shape(M, N, K, g_force_shape, false);
   if (shape == 3) shape = 2;
   if ((M + tile_bm(shape) - 1) / tile_bm(shape) > PBHC_ACT_MAX_BLOCKS) shape = 0;
   const int nb = (M + tile_bm(shape) - 1) / tile_bm(shape);
@@ -822,7 +829,7 @@ int pbhc_linear_act_fwd_strided(const float* x, int lda, long long x_batch_strid
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0 && x_batch_stride >= 0 && y_batch_stride >= 0);
   GEMM_ARG((size_t)M * (size_t)lda < (1u << 30) && (size_t)N * (size_t)K < (1u << 30));      // 32-bit byte offsets inside one batch
   hipStream_t st = (hipStream_t)stream;
-  const int shape = pick_shape(M, N, g_force_shape, true);
+  const int shape = pick_shape(M, N, K, g_force_shape, true);
   hipError_t e;
   if (shape == 3) e = gemm2_launch<0, 2, 2, 1, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);
   else if (shape == 1) e = gemm2_launch<0, 1, 4, 3, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, lda, ldc, x_batch_stride, y_batch_stride, batches);

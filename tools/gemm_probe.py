@@ -72,8 +72,8 @@ def main():
             w = torch.randn(Kout, Nin, device=dev) / Kout ** 0.5
             saved = F.elu(torch.randn(M, Nin, device=dev))
             dx = torch.empty(M, Nin, device=dev)
-            part = torch.empty(512 * Nin, device=dev)
-            part2 = torch.empty(512 * Nin, device=dev)
+            part = torch.empty(1024 * Nin, device=dev)
+            part2 = torch.empty(1024 * Nin, device=dev)
             nb = C.c_int(0)
             nb2 = C.c_int(0)
             st = _lib.current_stream()
