@@ -30,6 +30,7 @@ from .. import _lib
 
 _ACT_ID = {nn.ELU: 1, nn.SiLU: 2, nn.ReLU: 3}
 FUSED_GEMM = os.environ.get("PBHC_FUSED_GEMM", "1") != "0"
+_WGRAD_P = {tuple(int(v) for v in kv.split(":")[0].split("x")): int(kv.split(":")[1]) for kv in os.environ.get("PBHC_WGRAD_P", "").split(",") if kv}
 FUSED_WGRAD = os.environ.get("PBHC_FUSED_WGRAD", "0") == "1"        # measured slower than the library's split-K form: opt-in
 
 
@@ -79,7 +80,11 @@ def _wgrad_library(d, x, out):
     n, k = out.shape
     B = d.shape[0]
     nk = n * k
-    P = 0 if n < 64 else 32 if nk <= 128 * 256 else 8 if nk <= 128 * 512 else 16 if nk <= 256 * 512 else 8 if nk <= 512 * 384 else 0
+    # (chosen in the update itself — bench.py with PBHC_WGRAD_P — not in a back-to-back probe, whose operands are warm in L2: 512 x 380 8 -> 4 parts
+    # -0.35 ms per update, 256 x 512 16 -> 32 and 128 x 512 8 -> 16 another -0.05)
+    P = 0 if n < 64 else 32 if nk <= 128 * 256 else 16 if nk <= 128 * 512 else 32 if nk <= 256 * 512 else 4 if nk <= 512 * 384 else 0
+    if _WGRAD_P:                                       # measurement aid: PBHC_WGRAD_P="512x380:4,256x512:8"
+        P = _WGRAD_P.get((n, k), P)
     if P == 0 or B % P or B // P < 256:
         return torch.mm(d.t(), x, out=out)
     part = torch.bmm(d.view(P, B // P, n).transpose(1, 2), x.view(P, B // P, k))
