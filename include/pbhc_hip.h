@@ -476,6 +476,15 @@ typedef struct PbhcColsumJob {
 } PbhcColsumJob;
 int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int act, float* dz, float* scratch, int* num_row_blocks, void* stream);
 int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
+/* Backward of a stack's narrow OUTPUT Linear (y = h W^T + b, A = out_features <= 32, K = in_features in {64, 128, 192, 256}) in one pass over the
+ * rows — what autograd runs as mm (weight gradient), a column sum (bias gradient), mm (input gradient) and the activation backward of the layer
+ * below (agents/modules/modules.py:47-63 under torch.autograd; mh_ppo.py:513-517):
+ *   dh[M,K] = (dy[M,A] . w[A,K]) * act'(saved)       saved = the lower layer's activation OUTPUT (ELU, ReLU; NULL: = h) or PRE-activation (SiLU)
+ *   part_dw[b, A*K], part_db[b, A], part_cs[b, K]    partial rows b < *num_row_blocks (<= PBHC_ACT_MAX_BLOCKS) of dW = dy^T h, db = colsum(dy) and
+ *                                                    colsum(dh); finish each with a pbhc_colsum_final job (n = A*K, A, K). */
+int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,
+                        float* part_db, float* part_cs, int* num_row_blocks, void* stream);
+
 
 /* One Linear of a training-time Linear / activation stack on the fp32 matrix cores with its activation folded into the GEMM epilogue
  * (agents/modules/modules.py:47-63: `nn.Linear` followed by `nn.ELU` / `nn.SiLU` / `nn.ReLU`; replaces torch.addmm + the activation pass):

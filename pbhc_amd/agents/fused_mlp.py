@@ -146,7 +146,8 @@ class _FusedMLP(torch.autograd.Function):
         widths = [l.out_features for l in lin]
         MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
         scratch = torch.empty(MAXB * sum(widths), device=d.device)       # per-layer row-block column sums, finished by ONE launch below
-        jobs = (_lib._S["PbhcColsumJob"] * L)()
+        jobs = (_lib._S["PbhcColsumJob"] * (L + 1))()               # one per layer's bias gradient (+ the output layer's weight gradient)
+        njobs = L
         nb = C.c_int(0)
         ret_w = []
         off = 0
@@ -169,6 +170,28 @@ class _FusedMLP(torch.autograd.Function):
             direct = may_direct and l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
             part = scratch[offs[i]:offs[i] + MAXB * n]
+            k_in = l.in_features
+            if (i == L - 1 and i > 0 and ctx.fused and OUT_BWD and n <= 32 and k_in in (64, 128, 192, 256) and l.weight.is_contiguous()
+                    and ins[i].is_contiguous() and L + 1 <= _lib.K["PBHC_MAX_COLSUM_JOBS"]):
+                # the narrow output layer: weight / bias / input gradient and the activation backward of the layer below in ONE pass over the rows
+                # (`pbhc_linear_out_bwd`; autograd: two library launches of split-K for 0.14 GFLOP, a column sum, a GEMM and an activation pass)
+                gw = l.weight.grad if direct else torch.empty(n, k_in, device=d.device)
+                part_dw = torch.empty(MAXB * n * k_in, device=d.device)
+                dn = torch.empty(B, k_in, device=d.device)
+                saved = acts[i - 1]
+                _lib.check(lib.pbhc_linear_out_bwd(d.data_ptr(), ins[i].data_ptr(), None if saved.data_ptr() == ins[i].data_ptr() else saved.data_ptr(),
+                                                   l.weight.data_ptr(), B, n, k_in, ctx.act, dn.data_ptr(), part_dw.data_ptr(), part.data_ptr(),
+                                                   scratch[offs[i - 1]:].data_ptr(), C.byref(nb), st), "pbhc_linear_out_bwd")
+                j = jobs[L - 1 - i]
+                j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
+                j = jobs[L]
+                j.part, j.out, j.num_row_blocks, j.n = part_dw.data_ptr(), gw.data_ptr(), nb.value, n * k_in
+                njobs = L + 1
+                keep = (part_dw,)                        # (alive until the finishing launch below has been queued)
+                ret_w.append((None, None) if direct else (gw, gb))
+                d = dn
+                have_partials = True
+                continue
             if not have_partials:
                 _lib.check(lib.pbhc_act_bwd_partials(d.data_ptr(), acts[i].data_ptr() if i < L - 1 else None, B, n, ctx.act if i < L - 1 else 0, d.data_ptr(),
                                                      part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
@@ -190,7 +213,7 @@ class _FusedMLP(torch.autograd.Function):
                 have_partials = True
             elif i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
-        _lib.check(lib.pbhc_colsum_final(jobs, L, st), "pbhc_colsum_final")
+        _lib.check(lib.pbhc_colsum_final(jobs, njobs, st), "pbhc_colsum_final")
         if ctx.live is not None:
             seq._fused_live.discard(ctx.live)
             ctx.live = None
@@ -203,6 +226,7 @@ class _FusedMLP(torch.autograd.Function):
         return (dx, None, *flat)
 
 
+OUT_BWD = os.environ.get("PBHC_FUSED_OUT_BWD", "1") != "0"
 FUSED_STACK = os.environ.get("PBHC_FUSED_STACK", "1") != "0"
 _STACK_MAX_ROWS = int(os.environ.get("PBHC_FUSED_STACK_MAX_ROWS", "16384"))
 

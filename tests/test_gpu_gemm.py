@@ -237,3 +237,39 @@ def test_module_inference_forward_uses_the_stack_kernel_and_matches_layers():
     torch.cuda.synchronize()
     assert (a - ref).abs().max().item() < TOL and (b - ref).abs().max().item() < TOL and (c - ref2).abs().max().item() < 2 * TOL
     assert not torch.equal(a, b)                                 # (different summation order: the two paths really are different kernels)
+
+
+@pytest.mark.parametrize("shape", [(24576, 23, 128), (24576, 21, 128), (1000, 23, 128), (37, 1, 64), (4096, 32, 256), (513, 12, 192)])
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_linear_out_bwd_matches_fp64(shape, act):
+    """`pbhc_linear_out_bwd`: the narrow output layer's weight / bias / input gradient + the activation backward of the layer below in one pass
+    (what autograd runs as mm, a column sum, mm and elu_backward / silu_backward on agents/modules/modules.py:47-63)."""
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, A, K = shape
+    g = torch.Generator(device="cuda").manual_seed(31 * act + M + A + K)
+    z = torch.randn(M, K, device="cuda", generator=g)                   # pre-activation of the layer below
+    h = _act_ref(act, z)
+    dy = torch.randn(M, A, device="cuda", generator=g)
+    w = torch.randn(A, K, device="cuda", generator=g) / K ** 0.5
+    saved = z if act == 2 else None                                     # ELU / ReLU: derivative from the output (= h)
+    MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
+    dh = torch.empty(M, K, device="cuda")
+    pdw, pdb, pcs = torch.empty(MAXB * A * K, device="cuda"), torch.empty(MAXB * A, device="cuda"), torch.empty(MAXB * K, device="cuda")
+    nb = C.c_int(0)
+    _lib.check(lib.pbhc_linear_out_bwd(dy.data_ptr(), h.data_ptr(), None if saved is None else saved.data_ptr(), w.data_ptr(), M, A, K, act, dh.data_ptr(),
+                                       pdw.data_ptr(), pdb.data_ptr(), pcs.data_ptr(), C.byref(nb), _lib.current_stream()), "pbhc_linear_out_bwd")
+    assert 1 <= nb.value <= MAXB
+    jobs = (_lib._S["PbhcColsumJob"] * 3)()
+    dw, db, cs = torch.empty(A, K, device="cuda"), torch.empty(A, device="cuda"), torch.empty(K, device="cuda")
+    for j, (part, out, n) in enumerate([(pdw, dw, A * K), (pdb, db, A), (pcs, cs, K)]):
+        jobs[j].part, jobs[j].out, jobs[j].num_row_blocks, jobs[j].n = part.data_ptr(), out.data_ptr(), nb.value, n
+    _lib.check(lib.pbhc_colsum_final(jobs, 3, _lib.current_stream()), "pbhc_colsum_final")
+    torch.cuda.synchronize()
+    ref_dh = (dy.double() @ w.double()) * _act_grad_ref(act, z.double())
+    scale = max(1.0, M ** 0.5)
+    assert (dh.double() - ref_dh).abs().max().item() < TOL
+    assert (dw.double() - dy.double().t() @ h.double()).abs().max().item() < TOL * scale
+    assert (db.double() - dy.double().sum(0)).abs().max().item() < TOL * scale
+    assert (cs.double() - ref_dh.sum(0)).abs().max().item() < TOL * scale
