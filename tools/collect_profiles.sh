@@ -35,3 +35,7 @@ python3 tools/rollout_host_time.py 2>&1 | grep "^rollout" > gpurun_out/prof2/rol
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof2/utl -- python3 tools/update_trace_probe.py > gpurun_out/prof2/utl.log 2>&1
 python3 tools/update_step_timeline.py gpurun_out/prof2/utl > gpurun_out/prof2/update_step_timeline.txt
 find gpurun_out/prof2/utl -name "*.csv" -size +4M -delete
+# raw traces are scratch: only the summaries travel back (the merge-back limit is 64 MiB)
+find gpurun_out/prof2 -name "*kernel_trace.csv" -delete
+find gpurun_out/prof2 -name "*counter_collection.csv" -delete
+du -sh gpurun_out/prof2
