@@ -395,9 +395,9 @@ class MHPPO:
         return self.critic.evaluate(obs_dict["critic_obs"])
 
     def _rollout_step(self, obs_dict):
-        """mh_ppo.py:270-342.  Per control step: actor + critic forward (GEMMs), ONE sample/log-prob/buffer-write kernel, the fused
-        env step — which writes the next observations straight into the next rollout-buffer slab — and ONE bootstrap /
-        done / episode-statistics kernel.  No host synchronisation."""
+        """mh_ppo.py:270-342.  Per control step: the policy stack + sampling / log-prob / buffer writes (one launch), the fused env step —
+        which writes the next observations straight into the next rollout-buffer slab — and ONE done / episode-statistics kernel; the
+        critic over all slabs and the time-out bootstrap after the loop.  No host synchronisation."""
         st, env, lib = self.storage, self.env, _lib.lib()
         T, N, A, R = self.num_steps_per_env, env.num_envs, self.num_act, self.num_rew_fn
         keys = list(obs_dict.keys())
@@ -408,10 +408,9 @@ class MHPPO:
         with torch.inference_mode():
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
-            # Per control step the dependent chain is env step -> actor forward -> sampling -> env step.  Everything else of a step runs on a
-            # branch stream NEXT to that chain: the env step's one-workgroup reduction (sigma EMA, curricula, step counter) and the done /
-            # episode-statistics kernel.  The chain waits for the branch once per step, right before the sampling kernel (which reads the step
-            # counter the reduction advances).
+            # Per control step the dependent chain is env step -> policy forward (+ sampling in its last epilogue) -> env step.  Everything
+            # else of a step runs on a branch stream NEXT to that chain: the env step's one-workgroup reduction (sigma EMA, curricula, step
+            # counter) and the done / episode-statistics kernel.  The chain waits for the branch once per step, right before the next env step.
             # The critic's values are consumed only by the time-out bootstrap and by GAE, both after the rollout: evaluated ONCE over all T
             # slabs (98 304 rows: whole-chip GEMM tiles at ~120 TFLOP/s) it costs 1.5 ms, against 24 x 85 us for per-step forwards that
             # share the chip with the step -> actor chain (a control step's kernels add up to its duration: overlap buys ~10 %).
@@ -420,7 +419,6 @@ class MHPPO:
 
             cur, br = torch.cuda.current_stream(), self._branch_stream
             split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
-            overlap_step = os.environ.get("PBHC_ROLLOUT_OVERLAP_STEP", "1") != "0"
             batched = split and os.environ.get("PBHC_CRITIC_BATCHED", "1") != "0"
             # the weights are constant over the rollout: the networks named here run as ONE launch per step from a packed copy (pbhc_mlp_fwd);
             # packed BEFORE the step graphs are captured below — the capture records whichever kernels the forward launches
@@ -478,8 +476,6 @@ class MHPPO:
                     if not fuse_sample:
                         _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
                     env.set_obs_outputs(sp["obs_out"])
-                    if split and not overlap_step:
-                        cur.wait_stream(br)                # the critic of slab t has finished: the fused env step gets the chip to itself
                     nxt, rewards, dones, infos = env.step(sp["act"])
                     if self._need_next:
                         for k in keys:
