@@ -1600,9 +1600,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
 
   STAMP(11);
   // ---------------- workgroup partial sums for the host-side scalars of the reference ------------
+  if (!roleB) {                                              // (the zero fill by all 32 lanes: one lane storing 64 words in turn was 0.9 k cycles of every workgroup's tail)
+    float* bpq0 = blockpart + le * PBHC_NP;
+    for (int k = lane; k < PBHC_NP; k += PBHC_G) bpq0[k] = 0.0f;
+  }
+  WAVE_LDS_FENCE();
   if (!roleB && lane == 0) {
     float* bpq = blockpart + le * PBHC_NP;
-    for (int k = 0; k < PBHC_NP; ++k) bpq[k] = 0.0f;
     if (valid) {
       for (int k = 0; k < PBHC_NUM_SIGMA; ++k) bpq[P_ERR + k] = err[k];
       bpq[P_UPPER_NORM] = red[R_UPN]; bpq[P_LOWER_NORM] = red[R_LON]; bpq[P_VR_NORM] = red[R_VRN];
