@@ -460,15 +460,21 @@ __global__ __launch_bounds__(256) void k_rollout_post(const float* __restrict__ 
 // branches), reads the row's dy from an LDS tile (broadcast reads), and writes dh = (dy W) * act'(saved) plus the partial column sums of dh (the
 // bias gradient of the layer below), dW and db — one partial row per (workgroup, rl), finished by pbhc_colsum_final like every other column sum.
 #define OUTB_T 256
-#define OUTB_TILE 16                 // rows whose h / saved values a thread group requests together
-#define OUTB_CHUNK 96                // rows of dy staged in LDS at once (a workgroup's whole run at 24 576 rows)
-template <int AP>                    // A rounded up to a multiple of 8: the register arrays and the FMA loops are this long (zeros beyond A)
+#define OUTB_HR 16                   // rows a thread requests together (h / saved values in flight per thread)
+#define OUTB_CHUNK 128               // rows of dy staged in LDS at once (a workgroup's whole run at 24 576 rows)
+// AP: A rounded up to a multiple of 8 — the register arrays and the FMA loops are this long (zeros beyond A).  KT: K as a compile-time constant
+// (128, 256) or 0 for a run-time K: with it the row-lane count RPI = 256 / K is a constant, every one of a thread's OUTB_HR request slots maps to
+// a row of the tile (run-time K: a tile is 16 rows and at K = 128 half the slots stay empty), and the guards fold away.
+template <int AP, int KT>
 __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ saved,
-                                                          const float* __restrict__ w, int M, int A, int K, int act, int rows_per_block,
+                                                          const float* __restrict__ w, int M, int A, int Krt, int act, int rows_per_block,
                                                           float* __restrict__ dh, float* __restrict__ part_dw, float* __restrict__ part_db,
                                                           float* __restrict__ part_cs) {
   __shared__ __attribute__((aligned(16))) float sdy[OUTB_CHUNK][AP];
-  const int c = threadIdx.x % K, rl = threadIdx.x / K, RPI = OUTB_T / K;      // K divides 256 or K = 192 (then 64 threads idle)
+  const int K = KT > 0 ? KT : Krt;
+  const int RPI = OUTB_T / K;                                                  // K divides 256 or K = 192 (then 64 threads idle)
+  const int TR = KT > 0 ? OUTB_HR * (OUTB_T / (KT > 0 ? KT : 1)) : OUTB_HR;    // rows per tile (a divisor of OUTB_CHUNK)
+  const int c = threadIdx.x % K, rl = threadIdx.x / K;
   const bool live = rl < RPI;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float wc[AP], acc[AP];
@@ -483,22 +489,22 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
       sdy[rr][a] = (a < A && rc + rr < re) ? dy[(size_t)(rc + rr) * A + a] : 0.0f;
     }
     __syncthreads();
-    for (int rt = rc; rt < re; rt += OUTB_TILE) {
+    for (int rt = rc; rt < re; rt += TR) {
       // this thread's rows of the tile, ALL requested before the first is used (a load -> fma -> store chain per row leaves one load in flight
       // per wave: the first version of this kernel ran at 0.8 TB/s)
-      float hv[OUTB_TILE], sv[OUTB_TILE];
+      float hv[OUTB_HR], sv[OUTB_HR];
 #pragma unroll
-      for (int u = 0; u < OUTB_TILE; ++u) {
+      for (int u = 0; u < OUTB_HR; ++u) {
         const int rr = rl + u * RPI;
-        const bool ok = live && rr < OUTB_TILE && rt + rr < re;
+        const bool ok = live && rr < TR && rt + rr < re;
         const size_t o = (size_t)(rt + (ok ? rr : 0)) * K + c;
         hv[u] = ok ? h[o] : 0.0f;
         sv[u] = saved ? (ok ? saved[o] : 0.0f) : hv[u];
       }
 #pragma unroll
-      for (int u = 0; u < OUTB_TILE; ++u) {
+      for (int u = 0; u < OUTB_HR; ++u) {
         const int rr = rl + u * RPI;
-        if (live && rr < OUTB_TILE && rt + rr < re) {
+        if (live && rr < TR && rt + rr < re) {
           const float* dr = sdy[rt - rc + rr];
           float d[AP];
 #pragma unroll
@@ -530,6 +536,15 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
     part_cs[pb * K + c] = cs;
     if (c < A) part_db[pb * A + c] = dbacc;
   }
+}
+
+template <int KT>
+static void out_bwd_launch(int grid, hipStream_t st, const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, int rpb,
+                           float* dh, float* part_dw, float* part_db, float* part_cs) {
+  if (A <= 8) hipLaunchKernelGGL((k_out_layer_bwd<8, KT>), dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  else if (A <= 16) hipLaunchKernelGGL((k_out_layer_bwd<16, KT>), dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  else if (A <= 24) hipLaunchKernelGGL((k_out_layer_bwd<24, KT>), dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  else hipLaunchKernelGGL((k_out_layer_bwd<32, KT>), dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
 }
 
 extern "C" {
@@ -611,18 +626,17 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
   ARG_CHECK(dy && h && w && dh && part_dw && part_db && part_cs && num_row_blocks && M >= 1 && A >= 1 && A <= 32 && act >= 0 && act <= 3);
   ARG_CHECK(K == 64 || K == 128 || K == 192 || K == 256);
   const int RPI = OUTB_T / K;
-  int grid = (M + OUTB_TILE - 1) / OUTB_TILE;
+  int grid = (M + OUTB_HR - 1) / OUTB_HR;
   const int cap = PBHC_ACT_MAX_BLOCKS / RPI < 512 ? PBHC_ACT_MAX_BLOCKS / RPI : 512;     // two workgroups per CU; partial rows = grid x RPI <= the scratch cap
   if (grid > cap) grid = cap;
   int rpb = (M + grid - 1) / grid;
-  rpb = (rpb + OUTB_TILE - 1) / OUTB_TILE * OUTB_TILE;
+  rpb = (rpb + OUTB_HR - 1) / OUTB_HR * OUTB_HR;
   grid = (M + rpb - 1) / rpb;
   *num_row_blocks = grid * RPI;
   hipStream_t st = (hipStream_t)stream;
-  if (A <= 8) hipLaunchKernelGGL(k_out_layer_bwd<8>, dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
-  else if (A <= 16) hipLaunchKernelGGL(k_out_layer_bwd<16>, dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
-  else if (A <= 24) hipLaunchKernelGGL(k_out_layer_bwd<24>, dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
-  else hipLaunchKernelGGL(k_out_layer_bwd<32>, dim3(grid), dim3(OUTB_T), 0, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  if (K == 128) out_bwd_launch<128>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  else if (K == 256) out_bwd_launch<256>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
+  else out_bwd_launch<0>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
