@@ -178,7 +178,7 @@ class _FusedMLP(torch.autograd.Function):
                 # whose derivative needs a second row stream and an exp per element — 58 / 45 us for 29 / 1 outputs)
                 # (`pbhc_linear_out_bwd`; autograd: two library launches of split-K for 0.14 GFLOP, a column sum, a GEMM and an activation pass)
                 gw = l.weight.grad if direct else torch.empty(n, k_in, device=d.device)
-                part_dw = torch.empty(MAXB * n * k_in, device=d.device)
+                part_dw = torch.empty(MAXB * n * k_in, device=d.device)    # (a local: alive until the finishing launch below has been queued)
                 dn = torch.empty(B, k_in, device=d.device)
                 saved = acts[i - 1]
                 _lib.check(lib.pbhc_linear_out_bwd(d.data_ptr(), ins[i].data_ptr(), None if saved.data_ptr() == ins[i].data_ptr() else saved.data_ptr(),
@@ -189,7 +189,6 @@ class _FusedMLP(torch.autograd.Function):
                 j = jobs[L]
                 j.part, j.out, j.num_row_blocks, j.n = part_dw.data_ptr(), gw.data_ptr(), nb.value, n * k_in
                 njobs = L + 1
-                keep = (part_dw,)                        # (alive until the finishing launch below has been queued)
                 ret_w.append((None, None) if direct else (gw, gb))
                 d = dn
                 have_partials = True
