@@ -16,6 +16,8 @@
 //   * three k-steps of B loads are in flight per wave (register ring of four), the accumulators get bias + activation and are stored as the next
 //     layer's A image (row pitch = 4 mod 32 words: conflict-free ds_write_b32 per 32-lane half); the last layer goes to global memory.
 // Rounding differs from the layer-by-layer path by summation order only (pinned against fp64 by tests/test_gpu_gemm.py).
+// Tried and not kept: requesting a layer's first ring stages before the previous layer's epilogue and barrier (a by-value register ring carried
+// across the tile runs): 37.7 -> 42.8 us — the conditional use of the carried ring makes the first round of every run drain the load queue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
