@@ -301,7 +301,7 @@ class MHPPO:
             self.actor.actor_module._fused = False
             self.critic.critic_module._fused = False
         for k, d in self.algo_obs_dim_dict.items():
-            st.register_key(k, shape=(d,), dtype=torch.float, pad_rows=True)
+            st.register_key(k, shape=(d,), dtype=torch.float, pad_rows=True, tail_slab=True)
             if self._need_next:
                 st.register_key("next_" + k, shape=(d,), dtype=torch.float)
         st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
@@ -315,7 +315,7 @@ class MHPPO:
         st.register_key("action_sigma", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, _lib.padded_width(d), device=self.device)[:, :d] for k, d in self.algo_obs_dim_dict.items()}
+        self._last_obs = {k: st.with_tail(k)[T] for k in self.algo_obs_dim_dict}       # the observations after the last step: slab T of the same buffers
         self._sample_seed = pdist.rank_seed(int(torch.randint(0, 2**62, (1,)).item()))
         self._branch_stream = torch.cuda.Stream(device=self.device)
         self._update_streams = os.environ.get("PBHC_UPDATE_STREAMS", "0") == "1"      # measured slower (37.0 vs 34.5 ms per update): off
@@ -500,17 +500,21 @@ class MHPPO:
                     fused_mlp.release_stack(q)
             if batched:
                 # mh_ppo.py:286-305 for all steps at once: values of every slab, then rewards += gamma * values * time_outs
-                st.values.copy_(self.critic.critic_module(st.critic_obs.flatten(0, 1)).view(T, N, R))
+                # ... and the bootstrap values of GAE from the same launch set: the observations after the last step are slab T of the buffer
+                vals = self.critic.critic_module(st.with_tail("critic_obs").flatten(0, 1)).view(T + 1, N, R)
+                st.values.copy_(vals[:T])
                 st.rewards.addcmul_(st.values, self._time_outs.to(torch.float32), value=float(self.gamma))
             st.step = T
             self._timer.split()
-            self._compute_returns(self._last_obs)
+            self._compute_returns(self._last_obs, last_values=vals[T] if batched else None)
         return self._last_obs
 
-    def _compute_returns(self, last_obs_dict):
+    def _compute_returns(self, last_obs_dict, last_values=None):
         """mh_ppo.py:348-395 in one HIP pass over the [T,N,R] slab."""
         st = self.storage
-        last_values = self.critic.evaluate(last_obs_dict["critic_obs"]).detach().contiguous()
+        if last_values is None:
+            last_values = self.critic.evaluate(last_obs_dict["critic_obs"]).detach()
+        last_values = last_values.contiguous()
         T, N, R = self.num_steps_per_env, self.env.num_envs, self.num_rew_fn
         adv = st.advantages
         _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,

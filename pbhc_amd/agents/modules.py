@@ -131,16 +131,26 @@ class RolloutStorage(nn.Module):
         self.step = 0
         self.stored_keys = []
 
-    def register_key(self, key, shape=(), dtype=torch.float, pad_rows=False):
-        """pad_rows: the [N, C] slab of each step is a view of [N, ceil32(C)] rows, so that the env kernel writes whole 128-B lines."""
+    def register_key(self, key, shape=(), dtype=torch.float, pad_rows=False, tail_slab=False):
+        """pad_rows: the [N, C] slab of each step is a view of [N, ceil32(C)] rows, so that the env kernel writes whole 128-B lines.
+        tail_slab: one more slab behind the T of the buffer (`self.tail[key]`, [N, C]; `self.with_tail(key)`, [T + 1, N, C]) — the observations
+        after the last step live there, so that one forward over [T + 1, N] rows also yields the bootstrap values of GAE."""
         assert not hasattr(self, key), key
         assert isinstance(shape, (list, tuple)), "shape must be a list or tuple"
         if pad_rows and len(shape) == 1:
-            buf = torch.zeros((self.num_transitions_per_env, self.num_envs, _lib.padded_width(shape[0])), dtype=dtype, device=self.device)[..., :shape[0]]
+            T = self.num_transitions_per_env
+            full = torch.zeros((T + (1 if tail_slab else 0), self.num_envs, _lib.padded_width(shape[0])), dtype=dtype, device=self.device)[..., :shape[0]]
+            buf = full[:T]
+            if tail_slab:
+                self.__dict__.setdefault("_full", {})[key] = full
         else:
             buf = torch.zeros((self.num_transitions_per_env, self.num_envs) + tuple(shape), dtype=dtype, device=self.device)
         self.register_buffer(key, buf, persistent=False)
         self.stored_keys.append(key)
+
+    def with_tail(self, key):
+        """[T + 1, N, C]: the T slabs of `key` and its tail slab (register_key(..., tail_slab=True))"""
+        return self.__dict__["_full"][key]
 
     def update_key(self, key, data):
         assert not data.requires_grad
