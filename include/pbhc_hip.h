@@ -395,6 +395,21 @@ int pbhc_sim_fk(const PbhcSkeleton* skel, const float* root_states, const float*
 /* `globals`: caller-owned device double[PBHC_NUM_GLOBALS] (see enum PbhcGlobal), initialised by the caller. */
 int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double* globals, PbhcEnv** out);
 void pbhc_env_destroy(PbhcEnv* env);
+
+/* Config-specialised step kernel (new; nothing of the reference to match — its counterpart there is TorchScript specialising the
+ * rotation helpers per call site, isaac_utils/rotations.py `@torch.jit.script`).  k_env_step reads ~100 config scalars; compiled with the
+ * env's config as compile-time constants (csrc/pbhc_env_step_spec.hip, -DPBHC_STATIC_CFG) the same source is 40 % shorter and ~19 % faster.
+ *   pbhc_env_get_config          the config as pbhc_env_create finalised it: the text a specialised build is generated from
+ *   pbhc_env_attach_specialised  load `so_path` (a build of pbhc_env_step_spec.hip) and use its kernel for this env's steps; refused with
+ *                                PBHC_EINVAL unless the config baked into the object equals this env's member by member (run-time members —
+ *                                pointers, num_envs, seed, ref_init_yaw — excepted: the kernel reads those from the env).  NULL detaches.
+ *   pbhc_env_is_specialised      1 while a specialised kernel is attached
+ *   pbhc_env_config_finalize     the same finalisation without an env or a device (validation + derived members): lets a build step
+ *                                generate the specialised kernels of known configs ahead of time */
+int pbhc_env_get_config(PbhcEnv* env, PbhcEnvConfig* out);
+int pbhc_env_config_finalize(const PbhcEnvConfig* cfg, PbhcEnvConfig* out);
+int pbhc_env_attach_specialised(PbhcEnv* env, const char* so_path);
+int pbhc_env_is_specialised(PbhcEnv* env);
 /* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */
 int pbhc_env_step(PbhcEnv* env, const PbhcStepIO* io, void* stream);
 /* The same step as its two launches, for a caller that keeps the one-workgroup reduction off its critical chain (the rollout of

@@ -325,6 +325,12 @@ class ActorCritic(nn.Module):
     def critic(self):
         return self.critic_module
 
+    def reset(self, dones=None):                 # agent_modules.py:130-134 of the reference: stateless, nothing to reset
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
     @property
     def action_mean(self):
         return self.distribution.mean

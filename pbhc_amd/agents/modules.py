@@ -80,6 +80,12 @@ class PPOActor(nn.Module):
     def actor(self):
         return self.actor_module
 
+    def reset(self, dones=None):                 # API of the reference class (ppo_modules.py:45-49): stateless MLP, nothing to reset
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
     @property
     def action_mean(self):
         return self.distribution.mean
@@ -115,6 +121,9 @@ class PPOCritic(nn.Module):
     @property
     def critic(self):
         return self.critic_module
+
+    def reset(self, dones=None):                 # ppo_modules.py:94-95
+        pass
 
     def evaluate(self, critic_obs, **kwargs):
         return self.critic(critic_obs)
@@ -156,6 +165,17 @@ class RolloutStorage(nn.Module):
         assert not data.requires_grad
         assert self.step < self.num_transitions_per_env, "Rollout buffer overflow"
         getattr(self, key)[self.step].copy_(data)
+
+    def increment_step(self):                    # data_utils.py:50-51 (the reference agents call it once per control step)
+        self.step += 1
+
+    def batch_update_data(self, key, data):      # data_utils.py:59-63
+        assert not data.requires_grad
+        getattr(self, key)[:] = data
+
+    def query_key(self, key):                    # data_utils.py:95-97
+        assert hasattr(self, key), key
+        return getattr(self, key)
 
     def clear(self):
         self.step = 0

@@ -22,6 +22,30 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float norm3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 
+// sin and cos of one argument in ~25 VALU instructions: three-term Cody-Waite reduction by pi/2 (k * c1, k * c2 exact for |k| < 2^13, i.e.
+// |x| < ~1.2e4 rad: joint angles, half headings, slerp arcs) + the Cephes single-precision minimax polynomials on [-pi/4, pi/4]
+// (max error ~1 ulp, like the library's).  The library's sinf / cosf inline a Payne-Hanek large-argument path at every call site — 185
+// static instructions each, ~60 executed per call and two calls where one reduction serves both — which made them 15 % of the step kernel's
+// code.  Explicit fmaf: the file is built with -ffp-contract=off (reference op order elsewhere), the fused steps here are deliberate.
+__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
+  const float k = __builtin_rintf(x * 0.636619772367581343f);
+  float r = __builtin_fmaf(k, -1.5703125f, x);
+  r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
+  r = __builtin_fmaf(k, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * z, r, r);                               // sin(r)
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));  // cos(r)
+  const int q = (int)k;
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ float sin_cw(float x) { float s, c; sincos_cw(x, &s, &c); return s; }
+
 // rotations.py:82-97 / :244-253 (my_quat_rotate):  v(2w^2-1) + 2w(q x v) + 2 q (q.v)
 __device__ __forceinline__ f3 quat_rotate(f4 q, f3 v) {
   float s = 2.0f * q.w * q.w - 1.0f;
@@ -82,8 +106,9 @@ __device__ __forceinline__ f4 slerp(f4 q0, f4 q1, float t) {
   c = fabsf(c);
   float half = acosf(c);
   float s = sqrtf(1.0f - c * c);
-  float ra = sinf((1.0f - t) * half) / s;
-  float rb = sinf(t * half) / s;
+  const float rs = __builtin_amdgcn_rcpf(s);             // (inf for s = 0: that pair takes the `c >= 1` branch below)
+  float ra = sin_cw((1.0f - t) * half) * rs;
+  float rb = sin_cw(t * half) * rs;
   f4 r = mk4(ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w);
   if (fabsf(s) < 0.001f) r = mk4(0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w);
   if (fabsf(c) >= 1.0f) r = q0;
@@ -98,14 +123,17 @@ __device__ __forceinline__ float calc_heading(f4 q) {
 __device__ __forceinline__ f4 quat_from_angle_z(float angle) {
   float th = angle / 2.0f;
   // normalize(axis) = (0,0,1)/max(1,1e-9)
-  f4 q = mk4(0.0f * sinf(th), 0.0f * sinf(th), 1.0f * sinf(th), cosf(th));
+  float sn, cs;
+  sincos_cw(th, &sn, &cs);
+  f4 q = mk4(0.0f * sn, 0.0f * sn, 1.0f * sn, cs);
   return quat_unit(q);
 }
 __device__ __forceinline__ f4 quat_from_angle_axis(float angle, f3 axis) {
   float th = angle / 2.0f;
   f3 a = normalize3(axis);
-  float s = sinf(th);
-  return quat_unit(mk4(a.x * s, a.y * s, a.z * s, cosf(th)));
+  float s, c;
+  sincos_cw(th, &s, &c);
+  return quat_unit(mk4(a.x * s, a.y * s, a.z * s, c));
 }
 // rotations.py:368-387 (+ maths.copysign :16-19)
 __device__ __forceinline__ f3 euler_xyz(f4 q) {
@@ -131,7 +159,9 @@ __device__ __forceinline__ f3 quat_apply(f4 q, f3 b) {
 // torch_utils.py:239-270 yaw_quat (xyzw)
 __device__ __forceinline__ f4 yaw_quat(f4 q) {
   float yaw = atan2f(2.0f * (q.w * q.z + q.x * q.y), 1.0f - 2.0f * (q.y * q.y + q.z * q.z));
-  return quat_unit(mk4(0.0f, 0.0f, sinf(yaw / 2.0f), cosf(yaw / 2.0f)));
+  float sn, cs;
+  sincos_cw(yaw / 2.0f, &sn, &cs);
+  return quat_unit(mk4(0.0f, 0.0f, sn, cs));
 }
 // torch_utils.py:274-296 matrix_from_quat(...)[..., :2] flattened: m00 m01 m10 m11 m20 m21
 __device__ __forceinline__ void quat_to_mat6(f4 q, float* o) {
@@ -145,7 +175,9 @@ __device__ __forceinline__ void quat_to_mat6(f4 q, float* o) {
 __device__ __forceinline__ float quat_angle(f4 q) {
   const float st = sqrtf(1.0f - q.w * q.w);
   float a = 2.0f * acosf(q.w);
-  a = atan2f(sinf(a), cosf(a));
+  float sn, cs;
+  sincos_cw(a, &sn, &cs);
+  a = atan2f(sn, cs);
   return (fabsf(st) > 1e-5f) ? a : 0.0f;
 }
 
@@ -172,8 +204,10 @@ __device__ __forceinline__ m33 matmul33(const m33& a, const m33& b) {
 __device__ __forceinline__ void axis_angle_to_quat_wxyz(float ax, float ay, float az, float* q) {
   float angle = sqrtf(ax * ax + ay * ay + az * az);
   float half = angle * 0.5f;
-  float s = (fabsf(angle) < 1e-6f) ? (0.5f - (angle * angle) / 48.0f) : (sinf(half) / angle);
-  q[0] = cosf(half); q[1] = ax * s; q[2] = ay * s; q[3] = az * s;
+  float sh, ch;
+  sincos_cw(half, &sh, &ch);
+  float s = (fabsf(angle) < 1e-6f) ? (0.5f - (angle * angle) / 48.0f) : (sh / angle);
+  q[0] = ch; q[1] = ax * s; q[2] = ay * s; q[3] = az * s;
 }
 // rotations.py:589-636 best-conditioned candidate, output xyzw
 __device__ __forceinline__ f4 matrix_to_quat_xyzw(const m33& M) {

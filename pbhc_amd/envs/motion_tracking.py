@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import importlib
+import os
 import sys
 from collections.abc import Mapping
 
@@ -133,6 +134,9 @@ class LeggedRobotMotionTracking:
         self._c.ref_init_yaw = self.ref_init_yaw
         self._env = C.c_void_p()
         _lib.check(self._lib.pbhc_env_create(C.byref(self._c), C.byref(self._motion_lib.table), self.globals.data_ptr(), C.byref(self._env)), "pbhc_env_create")
+        # the step kernel specialised to this config (a ~3 s hipcc build on the first env of a config, cached in pbhc_amd/_spec):
+        # PBHC_SPECIALISE=off keeps the generic kernel, =cached never compiles
+        self.specialise(os.environ.get("PBHC_SPECIALISE", "jit"))
         self._totals, self._stat_pending, self._stat_group, self._num_envs_total = None, None, None, float(N)     # enable_global_statistics()
         self._finalize_stream, self._step_done, self._fin_done, self._fin_pending = None, None, None, False        # set_finalize_stream()
         self._init_buffers()
@@ -149,6 +153,19 @@ class LeggedRobotMotionTracking:
         self.reinit_epis_rand = float(config.domain_rand.get("reinit_epis_rand", -1))
         self.reinit_epis_rand_counter = float(-np.log(np.random.rand()) * self.reinit_epis_rand) if self.reinit_epis_rand > 0 else float("inf")
         self.init_done = True
+
+    def specialise(self, mode="jit", verbose=False):
+        """Run this env's steps on a build of k_env_step specialised to its config (pbhc_amd/specialise.py): "jit" compiles on a cache
+        miss (~15 s of hipcc, once per config and source version), "cached" only uses an existing object, "off" returns to the generic
+        kernel.  Same source, same results; returns True when a specialised kernel is attached."""
+        from .. import specialise as _spec
+
+        self._specialise_mode = mode
+        return _spec.attach(self._env, mode, verbose=verbose)
+
+    @property
+    def is_specialised(self):
+        return bool(self._lib.pbhc_env_is_specialised(self._env))
 
     def _load_motions_initial(self):
         self._motion_lib.load_motions(random_sample=not self.is_evaluating)            # motion_tracking.py:176-180
@@ -229,6 +246,8 @@ class LeggedRobotMotionTracking:
         self._env, self._c, self.layout = env, c, L
         self._init_obs_buffers()
         self._build_io()
+        if getattr(self, "_specialise_mode", None) not in (None, "off"):
+            self.specialise(self._specialise_mode)                   # the new env object has a new config: its own specialised build
 
     @property
     def history(self):

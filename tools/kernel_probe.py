@@ -15,6 +15,16 @@ cfg, env, _ = build(N, "cuda:0", 0)
 env.reset_all()
 env.simulator.set_replay(*make_replay_on_device(env, 130, 1))
 lib = _lib.lib()
+print(f"step kernel: {'specialised to the config' if env.is_specialised else 'generic'}")
+dbg = lib
+if env.is_specialised and "-DPBHC_STAMPS" in os.environ.get("PBHC_SPEC_DEFINES", ""):
+    # the specialised object carries its own stamp buffers (PBHC_SPEC_DEFINES=-DPBHC_STAMPS python tools/kernel_probe.py 4096)
+    from pbhc_amd import specialise as _spec
+
+    _c = _lib.PbhcEnvConfig()
+    _lib.check(lib.pbhc_env_get_config(env._env, C.byref(_c)))
+    dbg = C.CDLL(_spec.ensure(_c, "cached"))
+    dbg.pbhc_debug_read_stamps, dbg.pbhc_debug_read_wg_times = dbg.pbhc_spec_read_stamps, dbg.pbhc_spec_read_wg_times
 # experiments on the write traffic (PMC WRITE_SIZE): drop the optional state outputs / the observation noise
 if os.environ.get("PBHC_PROBE_NO_OPT", "0") == "1":
     for k in ("rigid_body_state", "contact_forces", "ref_body_pos_extend", "ref_body_rot_extend", "episode_rew_out"):
@@ -35,9 +45,9 @@ if hasattr(lib, "pbhc_env_profile_overhead"):
     _lib.check(lib.pbhc_env_profile_overhead(env._env, _lib.current_stream(), C.byref(ov)))     # what the event pair reads beyond the kernel (20 us spin calibration)
 ms = sorted(buf[i] - max(ov.value, 0.0) for i in range(cnt.value))
 print(f"k_env_step N={N}: median {ms[len(ms)//2]*1e3:.1f} us  min {ms[0]*1e3:.1f} us  mean {sum(ms)/len(ms)*1e3:.1f} us   (event pair minus its calibrated overhead of {ov.value * 1e3:.1f} us)")
-if hasattr(lib, "pbhc_debug_read_stamps"):
+if hasattr(dbg, "pbhc_debug_read_stamps"):
     st = (C.c_ulonglong * 64)()
-    lib.pbhc_debug_read_stamps(st, 64)
+    dbg.pbhc_debug_read_stamps(st, 64)
     # role A (thread 0 of workgroup 0): stamps 0..12 at its phase boundaries; role B (thread 128): stamps 32+1..32+5
     namesA = ["loads + constants -> LDS", "FK chain", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features",
               "obs rows of role 0 + wait bar3", "(late rows of a reset env)", "J writeback", "partials"]
@@ -47,6 +57,10 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
         dd = st[i + 1] - st[i]
         print(f"    {n:28s} {dd:8d} cyc  {100.0 * dd / tot:5.1f}%")
     print(f"    total {tot} cycles")
+    if st[20]:
+        print(f"    inside FK: relative joint quaternions (one sincos + quat_mul per lane) {st[20] - st[1]}, chain walk {st[21] - st[20]}, stores {st[22] - st[21]}, per-env scalars {st[2] - st[22]}")
+        print(f"    inside E: body loop {st[23] - st[3]}, reductions {st[24] - st[23]}, lane-0 means + termination {st[4] - st[24]}")
+        print(f"    inside F: exps {st[25] - st[5]}, term values {st[26] - st[25]}, episode sums {st[27] - st[26]}, reward row + err {st[6] - st[27]}")
     namesB = ["C scalars (from the start)", "D reference frame", "history -> LDS (then bar1)", "torques + joint-space sums + maps (from bar1)",
               "outputs + obs rows of role 1 (from bar2)"]
     refs = [st[0], st[32 + 1], st[32 + 2], st[3], st[5]]
@@ -55,10 +69,10 @@ if hasattr(lib, "pbhc_debug_read_stamps"):
         dd = st[32 + i + 1] - refs[i]
         print(f"    {n:40s} ends {st[32 + i + 1] - st[0]:8d} cyc after start  (+{dd})")
 
-if hasattr(lib, "pbhc_debug_read_wg_times"):
+if hasattr(dbg, "pbhc_debug_read_wg_times"):
     nwg = (N + 3) // 4
     wt = (C.c_ulonglong * (2 * nwg))()
-    lib.pbhc_debug_read_wg_times(wt, nwg)
+    dbg.pbhc_debug_read_wg_times(wt, nwg)
     import statistics
     t0 = min(wt[2 * i] for i in range(nwg))
     starts = sorted((wt[2 * i] - t0) / 100.0 for i in range(nwg))                     # 100 MHz clock -> us
@@ -68,7 +82,7 @@ if hasattr(lib, "pbhc_debug_read_wg_times"):
     print(f"  workgroups {nwg}: entry  min {starts[0]:.2f} median {q(starts, .5):.2f} p99 {q(starts, .99):.2f} max {starts[-1]:.2f} us after the first")
     print(f"                  exit   min {ends[0]:.2f} median {q(ends, .5):.2f} p99 {q(ends, .99):.2f} max {ends[-1]:.2f} us")
     print(f"                  in-kernel time per workgroup: min {durs[0]:.2f} median {q(durs, .5):.2f} p99 {q(durs, .99):.2f} max {durs[-1]:.2f} us")
-    if hasattr(lib, "pbhc_debug_read_stamps"):
+    if hasattr(dbg, "pbhc_debug_read_stamps"):
         d0 = (wt[1] - wt[0]) / 100.0
         print(f"                  workgroup 0 (the one with the cycle stamps): {d0:.2f} us in the kernel for {st[12] - st[0]} shader cycles between its first and last stamp -> shader clock >= {(st[12] - st[0]) / d0:.0f} MHz")
     rb = env.reset_buf.cpu().view(-1)
