@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 5
+#define PBHC_ABI_VERSION 6
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -159,6 +159,17 @@ enum PbhcLog {
  * (reference: helpers.parse_observation helpers.py:128-152 + sorted-key concat
  *  legged_robot_base.py:787-793 + clip :326-328; group PBHC_MAX_GROUPS-1 is conventionally the
  *  history write-back, history_handler.py:40-44, not clipped) */
+/* The same map as RUNS: `len` consecutive output elements dst.. read `len` consecutive feature words src.. with one scale and one noise
+ * scale (an observation key is a run; adjacent keys with equal scales merge).  The config-specialised step kernel (pbhc_env_step_spec.hip)
+ * unrolls the run list into straight-line code — per element one LDS read at an immediate offset, the scale as a literal, one store —
+ * where the generic kernel walks the per-element map. */
+#define PBHC_MAX_RUNS 96
+typedef struct PbhcObsRun {
+  int32_t dst, src, len;
+  int32_t late;              /* 1: reads a post-reset feature (written after the reset phase for a terminated env) */
+  float scale, noise;
+} PbhcObsRun;
+
 typedef struct PbhcOutMap {
   int32_t dim;               /* number of elements this map writes */
   int32_t clip;              /* 1: clip to +-clip_observations */
@@ -176,6 +187,9 @@ typedef struct PbhcOutMap {
    * list (both of its elements are noise entries) */
   int32_t lds_off;
   int32_t map_words;
+  int32_t num_runs;          /* runs[0..num_runs) cover the row exactly once; -1: too many runs for the table (the specialised kernel then
+                              * walks the per-element map like the generic one) */
+  PbhcObsRun runs[PBHC_MAX_RUNS];
 } PbhcOutMap;
 #define PBHC_MAX_SEGS 16
 

@@ -62,6 +62,7 @@ class GeneralTrackingOracle(MotionTrackingOracle):
         S = self.tar_steps.numel()
         mt = s["episode_length_buf"] * self.dt + s["motion_start_times"]
         times = self.tar_steps * self.dt + mt[:, None]
+        self.fut_times = times                                   # (kept for the tests' conditioned tolerances: which frame pairs were blended)
         ref = self._lookup(times, self.env_origins[:, None, :].expand(-1, S, -1))
         root_rot, root_pos = ref["root_rot"], ref["root_pos"]
         flat_rot = root_rot.reshape(N * S, 4)

@@ -84,16 +84,41 @@ struct Lds {
 // MISC slots
 enum {
   M_HINV = 0,   // 4 heading-inverse quaternion
-  M_TIME = 4, M_PHASE, M_MLEN, M_START, M_RESET, M_TIMEOUT, M_EPLEN, M_CONTACT0, M_CONTACT1, M_CFILT0, M_CFILT1,
+  M_MLEN = 4, M_START, M_RESET, M_TIMEOUT, M_EPLEN, M_CONTACT0, M_CONTACT1, M_CFILT0, M_CFILT1,
   M_RCONTACT0, M_RCONTACT1, M_GRAV, M_FAR, M_END, M_TOUT_LEN, M_LASTEP, M_NEWSTART, M_DELAY, M_FAT0, M_FAT1,
-  M_LASTC0, M_LASTC1, M_ROLL, M_PITCH, M_YAW, M_GX, M_GY, M_GZ,
+  M_LASTC0, M_LASTC1, M_GX, M_GY, M_GZ,
   M_REFZ, M_REFORI, M_BODYZ, M_ADZ, M_AORI,                     // general tracking: termination causes, anchor z / gravity-z differences
   M_CLIPCNT,                                                    // clipped actions of this step (role B -> reduction row)
   M_TCONTACT, M_TLOWH,                                          // termination causes: contact on a terminating body, low base height
   M_TPOSLIM, M_TVELLIM, M_TTAULIM, M_TGATE,                     // ... close to a joint position / velocity / torque limit (role B), any of them
-  M_ORIGIN0, M_ORIGIN1, M_ORIGIN2, M_CLIP_LEN, M_CLIP_DT, M_CLIP_NF, M_CLIP_ROW0      // env origin + clip meta (role B's prologue loads) for role A's reset path
+  M_ORIGIN0, M_ORIGIN1, M_ORIGIN2, M_CLIP_LEN, M_CLIP_DT, M_CLIP_NF, M_CLIP_ROW0,     // env origin + clip meta (role B's prologue loads) for role A's reset path
+  M_PJOINT, M_PEPLEN, M_PETR, M_PETRSQ, M_PREW, M_ZERO                                // partial-sum columns that are computed values; a zero for the unused ones
 };
-static_assert(M_CLIP_ROW0 < 56, "MISC region");
+static_assert(M_ZERO < 56, "MISC region");
+
+// Where column k of an env's partial-sum row comes from: a slot of the env's reduction row (RED) or of its scalar block (MISC).  Lane k of
+// the dynamics wave copies it at the end of the step (one lane writing the ~35 columns in turn was 1.8 k cycles of every workgroup's tail).
+#define PSRC_RED(slot) ((uint16_t)(slot))
+#define PSRC_MISC(slot) ((uint16_t)(0x8000u | (slot)))
+struct PartTab { uint16_t v[PBHC_NP]; };
+constexpr PartTab make_part_tab(bool general, bool close_any) {
+  PartTab t{};
+  for (int k = 0; k < PBHC_NP; ++k) t.v[k] = PSRC_MISC(M_ZERO);
+  for (int k = 0; k < PBHC_NUM_SIGMA; ++k) t.v[P_ERR + k] = PSRC_RED(R_ERR0 + k);
+  t.v[P_UPPER_NORM] = PSRC_RED(R_UPN); t.v[P_LOWER_NORM] = PSRC_RED(R_LON); t.v[P_VR_NORM] = PSRC_RED(R_VRN);
+  t.v[P_JOINT_NORM] = PSRC_MISC(M_PJOINT); t.v[P_CLIP_CNT] = PSRC_RED(R_CLIPCNT);
+  t.v[P_RESET_CNT] = PSRC_MISC(M_RESET); t.v[P_TERM_GRAVITY] = PSRC_MISC(M_GRAV); t.v[P_TERM_FAR] = PSRC_MISC(M_FAR);
+  t.v[P_TERM_TIMEOUT] = PSRC_MISC(M_TIMEOUT); t.v[P_TERM_END] = PSRC_MISC(M_END); t.v[P_RESET_EPLEN] = PSRC_MISC(M_PEPLEN);
+  t.v[P_ETR_SUM] = PSRC_MISC(M_PETR); t.v[P_ETR_SQ] = PSRC_MISC(M_PETRSQ); t.v[P_REW_SUM] = PSRC_MISC(M_PREW);
+  t.v[P_TERM_CONTACT] = PSRC_MISC(M_TCONTACT); t.v[P_TERM_LOWH] = PSRC_MISC(M_TLOWH);
+  if (close_any) { t.v[P_TERM_POSLIM] = PSRC_MISC(M_TPOSLIM); t.v[P_TERM_VELLIM] = PSRC_MISC(M_TVELLIM); t.v[P_TERM_TAULIM] = PSRC_MISC(M_TTAULIM); }
+  if (general) {
+    t.v[P_KEY_NORM] = PSRC_RED(R_KEYN); t.v[P_LUP_NORM] = PSRC_RED(R_LUPN); t.v[P_LLO_NORM] = PSRC_RED(R_LLON); t.v[P_LVR_NORM] = PSRC_RED(R_LVRN);
+    t.v[P_LKEY_NORM] = PSRC_RED(R_LKEYN); t.v[P_TERM_REFZ] = PSRC_MISC(M_REFZ); t.v[P_TERM_REFORI] = PSRC_MISC(M_REFORI); t.v[P_TERM_BODYZ] = PSRC_MISC(M_BODYZ);
+  }
+  return t;
+}
+__device__ const PartTab kPartTab[4] = {make_part_tab(false, false), make_part_tab(false, true), make_part_tab(true, false), make_part_tab(true, true)};
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS ops (lgkmcnt) and leaves global loads AND stores in
 // flight (a __syncthreads() would also drain vmcnt, i.e. stall on the early fire-and-forget stores).  Waves of a workgroup share
@@ -172,7 +197,12 @@ __host__ __device__ __forceinline__ float skel_word(const PbhcSkeleton& sk, int 
   int b = i / SKC_W, w = i - b * SKC_W;
   if (w < 3) return sk.offset[b][w];
   if (w < 7) return sk.local_rot_wxyz[b][(w - 3 + 1) & 3];                 // wxyz -> xyzw
-  if (w < 10) return (b >= 1 && b < sk.num_bodies) ? sk.dof_axis[b - 1][w - 7] : 0.0f;
+  if (w < 10) {                                                              // joint axis, normalised (rotations.py:138-145 normalises it per call)
+    if (!(b >= 1 && b < sk.num_bodies)) return 0.0f;
+    const float* ax = sk.dof_axis[b - 1];
+    const float nrm = fmaxf(sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), 1e-9f);
+    return ax[w - 7] / nrm;
+  }
   int iv = (w == 10) ? sk.chain_len[b] : sk.chain[b][w - 11];
   float fv;
   memcpy(&fv, &iv, sizeof(fv));
@@ -216,8 +246,7 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
   if (valid)
     for (int b = 1 + lane; b < B; b += PBHC_G) {
       const float* k = skc + b * SKC_W;
-      f3 axis = ld3(k + 7);
-      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_axis(q[b - 1], axis)));
+      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_unit_axis(q[b - 1], ld3(k + 7))));
     }
   LDS_BARRIER();
   if (valid)
@@ -253,101 +282,6 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
 // execute in issue order, so the relative joint quaternions written in step 1 are visible to every lane's chain walk, and they can live in
 // `bq` itself: the world quaternions are stored only after EVERY walk of the wave has read its last relative one (up to two bodies per lane,
 // results held in registers until then).
-// The same rigid-body state by pointer jumping over the kinematic chain: every slot starts from the segment of its last joint — (R, p, w, v) of
-// body b RELATIVE to its parent's frame — and in round k prepends the published segment of its 2^k-th ancestor (chain[n-1-2^k]), so a chain of
-// up to 16 joints is closed in 4 dependent rounds instead of 12 levels.  Segments compose like the serial walk (legged-robot FK, the reference's
-// torch_utils forward kinematics in world frame): for x -> y -> z
-//   R = R1 (x) R2,  p = p1 + R1 p2,  w = w1 + R1 w2,  v = v1 + w1 x (R1 p2) + R1 v2
-// (one joint: R = lq (x) rot(axis, q), p = offset, w = (lq axis) qd, v = 0), the world state is root o segment.  The segments are published in
-// the output arrays themselves (bq / bp / bw / bv): DS instructions of a wave execute in order, so a round's reads are issued before the next
-// round's stores.  Quaternions are renormalised after every product, as the serial walk does per level; the result differs from it by
-// rounding order only (~1e-7).
-__device__ __forceinline__ void fk_jump_wave(const float* skc, int B, int Bx, int lane, bool valid, const float* root, const float* q, const float* qd,
-                                             float* bp, float* bq, float* bv, float* bw) {
-  static_assert(PBHC_MAX_BODIES <= 2 * PBHC_G, "two bodies per lane");
-  static_assert(PBHC_MAX_DEPTH <= 16, "four rounds of pointer jumping");
-  if (!valid) return;
-  f3 P[2], V[2], W[2];
-  f4 R[2];
-  int n[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int b = lane + it * PBHC_G;
-    P[it] = mk3(0, 0, 0); V[it] = P[it]; W[it] = P[it]; R[it] = mk4(0, 0, 0, 1); n[it] = 0;
-    if (b < Bx) {
-      const float* kb = skc + b * SKC_W;
-      n[it] = __float_as_int(kb[10]);
-      if (n[it] > 0) {
-        const int pb = __float_as_int(kb[11 + n[it] - 1]);          // the body this slot computes (b itself, or an extended body's parent)
-        const float* ka = skc + pb * SKC_W;
-        const f3 axis = ld3(ka + 7);
-        const f4 lq = ld4(ka + 3);
-        R[it] = quat_mul(lq, quat_from_angle_axis(q[pb - 1], axis));
-        P[it] = ld3(ka);
-        W[it] = mul3(quat_rotate(lq, axis), qd[pb - 1]);
-      }
-      if (b >= 1 && b < B) { st4(bq + 4 * b, R[it]); st3(bp + 3 * b, P[it]); st3(bw + 3 * b, W[it]); st3(bv + 3 * b, V[it]); }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    WAVE_LDS_FENCE();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int b = lane + it * PBHC_G;
-      const int j = n[it] - 1 - (1 << k);
-      if (b < Bx && j >= 0) {
-        const int a = __float_as_int(skc[b * SKC_W + 11 + j]);
-        const f4 Ra = ld4(bq + 4 * a);
-        const f3 Pa = ld3(bp + 3 * a), Wa = ld3(bw + 3 * a), Va = ld3(bv + 3 * a);
-        const f3 rp = quat_rotate(Ra, P[it]);
-        V[it] = add3(Va, add3(cross3(Wa, rp), quat_rotate(Ra, V[it])));
-        W[it] = add3(Wa, quat_rotate(Ra, W[it]));
-        P[it] = add3(Pa, rp);
-        R[it] = quat_unit_fast(quat_mul(Ra, R[it]));
-      }
-    }
-    WAVE_LDS_FENCE();
-    if (k < 3) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int b = lane + it * PBHC_G;
-        if (b >= 1 && b < B && n[it] - 1 - (1 << k) >= 0) { st4(bq + 4 * b, R[it]); st3(bp + 3 * b, P[it]); st3(bw + 3 * b, W[it]); st3(bv + 3 * b, V[it]); }
-      }
-    }
-  }
-  // world state = root o segment, then the fixed extension of the extended bodies
-  const f3 p0 = ld3(root), v0 = ld3(root + 7), w0 = ld3(root + 10);
-  const f4 r0 = ld4(root + 3);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int b = lane + it * PBHC_G;
-    if (b < Bx) {
-      const f3 rp = quat_rotate(r0, P[it]);
-      f3 p = add3(p0, rp);
-      f3 v = add3(v0, add3(cross3(w0, rp), quat_rotate(r0, V[it])));
-      const f3 w = add3(w0, quat_rotate(r0, W[it]));
-      f4 r = n[it] > 0 ? quat_unit_fast(quat_mul(r0, R[it])) : r0;
-      if (b >= B) {
-        const float* kb = skc + b * SKC_W;
-        f3 off = ld3(kb);
-        f4 eq = ld4(kb + 3);
-        f3 pe = add3(quat_rotate(eq, quat_rotate(r, off)), p);
-        v = add3(v, cross3(w, off));
-        r = quat_mul(r, eq);
-        p = pe;
-      }
-      P[it] = p; V[it] = v; W[it] = w; R[it] = r;
-    }
-  }
-  WAVE_LDS_FENCE();
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int b = lane + it * PBHC_G;
-    if (b < Bx) { st3(bp + 3 * b, P[it]); st4(bq + 4 * b, R[it]); st3(bv + 3 * b, V[it]); st3(bw + 3 * b, W[it]); }
-  }
-}
-
 __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, int lane, bool valid, const float* root, const float* q, const float* qd,
                                              float* bp, float* bq, float* bv, float* bw) {
   static_assert(PBHC_MAX_BODIES <= 2 * PBHC_G, "two bodies per lane");
@@ -355,8 +289,7 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
   if (valid)
     for (int b = 1 + lane; b < B; b += PBHC_G) {
       const float* k = skc + b * SKC_W;
-      f3 axis = ld3(k + 7);
-      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_axis(q[b - 1], axis)));
+      st4(relq + 4 * b, quat_mul(ld4(k + 3), quat_from_angle_unit_axis(q[b - 1], ld3(k + 7))));       // (the image's axes are unit vectors: skel_word)
     }
   WAVE_LDS_FENCE();
   STAMP(20);
@@ -372,15 +305,28 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
       const int n = __float_as_int(kb[10]);
       f3 p = ld3(root), v = ld3(root + 7), w = ld3(root + 10);
       f4 r = ld4(root + 3);
+      // The walk is a chain of dependent levels, each needing the joint's constants (an index read, then reads addressed by it): software
+      // pipelined by hand — the index two levels ahead and the constants one level ahead are requested before this level's arithmetic, so
+      // both LDS round trips run under ~500 cycles of VALU work instead of in front of it.  Reads past the chain's end repeat the last joint.
+      int a1 = __float_as_int(kb[11 + min(1, max(n - 1, 0))]);
+      int a0 = __float_as_int(kb[11]);
+      const float* k0 = skc + a0 * SKC_W;
+      f3 off_c = ld3(k0), ax_c = ld3(k0 + 7);
+      f4 rq_c = ld4(relq + 4 * a0);
+      float qd_c = qd[max(a0 - 1, 0)];
       for (int i = 0; i < n; ++i) {
-        const int a = __float_as_int(kb[11 + i]);
-        const float* ka = skc + a * SKC_W;
-        f3 axis = ld3(ka + 7);
-        f3 pn = add3(p, quat_rotate(r, ld3(ka)));
-        f4 rn = quat_unit_fast(quat_mul(r, ld4(relq + 4 * a)));
-        f3 wn = add3(w, mul3(quat_rotate(rn, axis), qd[a - 1]));
+        const int a2 = __float_as_int(kb[11 + min(i + 2, n - 1)]);
+        const float* k1 = skc + a1 * SKC_W;
+        const f3 off_n = ld3(k1), ax_n = ld3(k1 + 7);
+        const f4 rq_n = ld4(relq + 4 * a1);
+        const float qd_n = qd[max(a1 - 1, 0)];
+        WAVE_LDS_FENCE();                                        // (compiler fence: keep the requests above this level's arithmetic)
+        const f3 pn = add3(p, quat_rotate(r, off_c));
+        const f4 rn = quat_unit_fast(quat_mul(r, rq_c));
+        const f3 wn = add3(w, mul3(quat_rotate(rn, ax_c), qd_c));
         v = add3(v, cross3(w, sub3(pn, p)));
         p = pn; r = rn; w = wn;
+        off_c = off_n; ax_c = ax_n; rq_c = rq_n; qd_c = qd_n; a1 = a2;
       }
       if (b >= B) {
         f3 off = ld3(kb);
@@ -538,27 +484,59 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
+constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
+  for (int g = 0; g < c.num_groups; ++g)
+    if (c.groups[g].num_runs < 0) return false;
+  return true;
+}
+// the uniform of element j of row `stream`: the first word of the lane's Philox quad (keyed by env / step / lane), re-keyed by (row, j) and
+// passed through a bijective 32-bit finaliser — every writer of observation noise (list, per-element map, unrolled runs) uses this one
+// function, so the generic and the specialised kernel draw the same noise.  (One word on purpose: choosing among the four by j & 3 turns
+// the quad into an indexed array, i.e. scratch memory.)
+__device__ __forceinline__ float obs_noise_u(const uint32_t* pre, uint32_t stream, uint32_t j) {
+  return u01(mix32(pre[0] ^ (stream * 0x9E3779B9u + j * 0x85EBCA6Bu)));
+}
 __device__ __forceinline__ void obs_write_noisy(const uint32_t* mg, int k0, int k1, int l, int nl, const float* feat, float* __restrict__ outg, unsigned int ob,
-                                                int clip, float clipobs, float noise_cur, uint64_t seed, uint32_t env, uint32_t step_ctr, uint32_t stream,
-                                                const uint32_t* pre) {
+                                                int clip, float clipobs, float noise_cur, uint32_t stream, const uint32_t* pre) {
   const float* segs = (const float*)mg;
   const int nlist = (int)(mg[34] + mg[35]);
   const uint32_t* noisy = mg + PBHC_MAP_HDR + ((nlist + 1) >> 1);
   for (int kb = (k0 & ~3) + 4 * l; kb < k1; kb += 4 * nl) {
-    uint32_t r[4];
-    const uint32_t salt = stream * 0x9E3779B9u + (uint32_t)(kb >> 2) * 0x85EBCA6Bu;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = mix32(pre[u] ^ salt);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (kb + u >= k0 && kb + u < k1) {
         const uint32_t e = noisy[kb + u];
         const uint32_t w = e >> 16;
         const int seg = w >> 12;
-        float v = (feat[w & 0xFFFu] + (u01(r[u]) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
-        if (clip) v = clampf(v, -clipobs, clipobs);
+        float v = (feat[w & 0xFFFu] + (obs_noise_u(pre, stream, e & 0xFFFFu) * 2.0f - 1.0f) * (segs[16 + seg] * noise_cur)) * segs[seg];
+        if (clip) v = __builtin_amdgcn_fmed3f(v, -clipobs, clipobs);
         at(outg, ob + (e & 0xFFFFu)) = v;
       }
+  }
+}
+
+// Observation row as RUNS (PbhcObsRun), for the config-specialised build: `m` is a compile-time constant there, both loops unroll and what
+// is left per element is one LDS read at an immediate offset, the scale as a literal, the clip and one store — no list, no map word, no
+// segment table (the per-element paths above: ~25 instructions per element pair).  WHICH: 0 every run, 1 the runs that read no post-reset
+// feature, 2 the ones that do.  Same arithmetic per element as the map paths: (x + noise) * scale, clip.
+template <int WHICH>
+__device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, float* __restrict__ outg, unsigned int ob,
+                                               float clipobs, float noise_cur, const uint32_t* pre) {
+#pragma unroll
+  for (int r = 0; r < m.num_runs; ++r) {
+    const PbhcObsRun& R = m.runs[r];
+    if ((WHICH == 1 && R.late) || (WHICH == 2 && !R.late)) continue;
+#pragma unroll
+    for (int i0 = 0; i0 < R.len; i0 += PBHC_G) {
+      const int i = i0 + lane;
+      if (i < R.len) {
+        float x = feat[R.src + i];
+        if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)(R.dst + i)) * 2.0f - 1.0f) * (R.noise * noise_cur);
+        x = x * R.scale;
+        if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
+        at(outg, ob + (unsigned int)(R.dst + i)) = x;
+      }
+    }
   }
 }
 
@@ -569,7 +547,9 @@ template <int MODE>
 #ifndef PBHC_MIN_WAVES
 #define PBHC_MIN_WAVES (MODE ? 2 : 4)
 #endif
-__global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
+// (waves_per_eu pins the allocation target too: LDS admits no more than PBHC_MIN_WAVES waves per SIMD, so aiming at a higher occupancy
+// — the compiler stopped at 96 VGPRs and spilled — buys nothing)
+__global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_waves_per_eu(PBHC_MIN_WAVES, PBHC_MIN_WAVES))) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
@@ -607,8 +587,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   typedef unsigned int u32;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
-  float* blockpart = skc + ((Bx * SKC_W + 3) & ~3);           // [EPB][PBHC_NP]
-  uint32_t* mapl = (uint32_t*)(blockpart + PBHC_EPB * PBHC_NP);   // [map_lds_words] compact observation maps, shared by the workgroup
+  uint32_t* mapl = (uint32_t*)(skc + ((Bx * SKC_W + 3) & ~3));    // [map_lds_words] compact observation maps, shared by the workgroup
   const float dt = c.dt;
   const u32 eD = (u32)env * (u32)D;
   const int envc = valid ? env : N - 1;                       // a tail workgroup's missing envs load env N-1 (and store nothing)
@@ -617,7 +596,15 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const int dc = min(lane, D - 1);
   const int hoff = c.feat_off[PBHC_F_HISTORY];
   const int Q = c.queue_len;
-  const int map_words = c.map_lds_words;
+  // how the observation rows are written: unrolled runs (specialised build whose groups all have a run table), else the compact maps
+  // staged in LDS, else (a feature row too large for them) the per-element maps in global memory after bar3
+#ifdef PBHC_STATIC_CFG
+  constexpr bool use_runs = obs_runs_complete(kStaticCfg);
+#else
+  const bool use_runs = false;
+#endif
+  const int map_words = use_runs ? 0 : c.map_lds_words;
+  const bool obs_by_role = use_runs || map_words > 0;
   const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
   STAMP(0);
 
@@ -634,6 +621,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   const float start = io.motion_start_times[envc];
 
   // role-A registers that live across phases
+  float mlenA = 1.0f;
+  uint32_t psrc0 = 0, psrc1 = 0;                              // sources of this lane's two partial-sum columns (kPartTab)
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, dpA = 0.0f, etr_old = 0.0f;
   int pf_tid = 0, pf_tpen = 0, pf_tsrc = -1, pf_colterm = -1;
   long long adelay = 0;
@@ -681,6 +670,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       dpA = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
+      mlenA = io.motion_len[envc];
+      const PartTab& pt = kPartTab[(MODE ? 2 : 0) + (close_any ? 1 : 0)];
+      psrc0 = pt.v[lane]; psrc1 = pt.v[lane + PBHC_G];
     }
 
     {
@@ -695,34 +687,35 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     }
     WAVE_LDS_FENCE();
     // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
-#ifdef PBHC_FK_JUMP                                     // measured: 15.1 k cycles against the serial walk's 12.6 k — kept for the record, parity-green
-    fk_jump_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
-#else
     fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
-#endif
     // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588) ---------
+    // One lane per quantity and ONE code path per function: lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of
+    // the pitch, lanes 4-6 the three base-frame rotations, lane 7 the reference time (lane 0 doing all of it in turn was ~450 instructions
+    // of the chain; roll and pitch only exist where an observation reads them: general tracking).
     if (valid) {
-      f4 rq4 = ld4(root + 3);
-      if (lane == 0) {
-        const float mlen = io.motion_len[envc];
+      const f4 rq4 = ld4(root + 3);
+      if (lane < 3) {
+        float sinr, cosr, sinp, siny, cosy;
+        euler_xyz_args(rq4, &sinr, &cosr, &sinp, &siny, &cosy);
+        const f3 hx = quat_rotate(rq4, mk3(1.0f, 0.0f, 0.0f));                  // calc_heading rotations.py:257-268
+        const float ang = atan2f(lane == 0 ? siny : (lane == 1 ? hx.y : sinr), lane == 0 ? cosy : (lane == 1 ? hx.x : cosr));
+        if (lane == 0) feat[c.feat_off[PBHC_F_RELYAW]] = ang - rt.ref_init_yaw;
+        else if (lane == 1) st4(misc + M_HINV, quat_from_angle_z(-ang));        // calc_heading_quat_inv rotations.py:296-306
+        else if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH]] = ang;
+      } else if (lane == 3) {
+        if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = euler_xyz(rq4).y;
+      } else if (lane <= 6) {
+        // the same rotation of three different vectors
+        const f3 vin = lane == 4 ? ld3(root + 7) : (lane == 5 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
+        const f3 vo = quat_rotate_inverse(rq4, vin);
+        const int off = lane == 4 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 5 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+        st3(feat + off, vo);
+        if (lane == 6) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+      } else if (lane == 7) {
         const float t = (float)(ep1 + 1) * dt + start;
         misc[M_EPLEN] = (float)ep1;
-        misc[M_START] = start; misc[M_MLEN] = mlen;
-        misc[M_TIME] = t;
-        misc[M_PHASE] = t / mlen;
-        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlen;
-        f3 e = euler_xyz(rq4);
-        misc[M_ROLL] = e.x; misc[M_PITCH] = e.y; misc[M_YAW] = e.z;
-        feat[c.feat_off[PBHC_F_RELYAW]] = e.z - rt.ref_init_yaw;
-        if (MODE) { feat[c.feat_off[PBHC_F_ROLL_PITCH]] = e.x; feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = e.y; }
-        st4(misc + M_HINV, quat_from_angle_z(-calc_heading(rq4)));       // calc_heading_quat_inv rotations.py:296-306
-      } else if (lane <= 3) {
-        // lanes 1..3: the same rotation of three different vectors (one code path for the wave instead of three divergent ones)
-        const f3 vin = lane == 1 ? ld3(root + 7) : (lane == 2 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
-        const f3 vo = quat_rotate_inverse(rq4, vin);
-        const int off = lane == 1 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 2 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
-        st3(feat + off, vo);
-        if (lane == 3) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+        misc[M_START] = start; misc[M_MLEN] = mlenA;
+        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlenA;
       }
     }
     STAMP(2);
@@ -1151,7 +1144,30 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   // `late_too`: also the pairs / noisy elements that read post-reset features — valid when this role has them (role A after its phase H;
   // role B for a surviving env, whose no-reset values it wrote itself; for a terminated env role B defers them past bar3).
   const float noise_cur = (float)glob[PBHC_G_NOISE_CURRICULUM];
-#define OBS_GROUPS(ROLE, LATE_TOO)                                                                                                  \
+  // specialised build: the rows as unrolled runs (obs_write_runs); the per-element maps are not even staged
+#ifndef PBHC_STATIC_CFG
+#define OBS_GROUPS_RUNS(ROLE, LATE_TOO)
+#define OBS_GROUPS_LATE_RUNS(ROLE)
+#else
+#define OBS_GROUPS_RUNS(ROLE, LATE_TOO)                                                                                                \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups || c.groups[g].role != (ROLE)) continue;                                                                  \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    if (LATE_TOO) obs_write_runs<0>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                            \
+    else obs_write_runs<1>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                                     \
+  }
+#define OBS_GROUPS_LATE_RUNS(ROLE)                                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups || c.groups[g].role != (ROLE)) continue;                                                                  \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    obs_write_runs<2>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                                          \
+  }
+#endif
+#define OBS_GROUPS_MAP(ROLE, LATE_TOO)                                                                                              \
   for (int g = 0; g < ngroups; ++g) {                                                                                               \
     if (c.groups[g].role != (ROLE)) continue;                                                                                       \
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
@@ -1163,9 +1179,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       obs_write_list<8>(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs); \
     else                                                                                                                            \
       obs_write_list_unaligned(mg, 0, (LATE_TOO) ? nlist : n_early, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);   \
-    obs_write_noisy(mg, 0, (LATE_TOO) ? nn : nn_early, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g, nzb); \
+    obs_write_noisy(mg, 0, (LATE_TOO) ? nn : nn_early, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, 16 + g, nzb); \
   }
-#define OBS_GROUPS_LATE(ROLE)                                                                                                       \
+#define OBS_GROUPS_LATE_MAP(ROLE)                                                                                                   \
   for (int g = 0; g < ngroups; ++g) {                                                                                               \
     if (c.groups[g].role != (ROLE)) continue;                                                                                       \
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
@@ -1177,11 +1193,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       obs_write_list<4>(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, pitch_g, c.groups[g].clip, clipobs);     \
     else                                                                                                                            \
       obs_write_list_unaligned(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);       \
-    obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, rt.seed, env, step_ctr, 16 + g, nzb); \
+    obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, 16 + g, nzb); \
   }
-  float err[PBHC_NUM_SIGMA];
-#pragma unroll
-  for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = 0.0f;
+#define OBS_GROUPS(ROLE, LATE_TOO) do { if (use_runs) { OBS_GROUPS_RUNS(ROLE, LATE_TOO) } else { OBS_GROUPS_MAP(ROLE, LATE_TOO) } } while (0)
+#define OBS_GROUPS_LATE(ROLE) do { if (use_runs) { OBS_GROUPS_LATE_RUNS(ROLE) } else { OBS_GROUPS_LATE_MAP(ROLE) } } while (0)
   float rew_total = 0.0f, etr_val = 0.0f;
 
   if (!roleB) {
@@ -1288,8 +1303,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
         }
         rew_total = v;
       }
-#pragma unroll
-      for (int k = 0; k < PBHC_NUM_SIGMA; ++k) err[k] = red[R_ERR0 + k];
     }
     // the episode_sums stores above and the reset path's loads / stores of the same row below are issued by the same lanes' wave in
     // program order; the reset path waits for them explicitly
@@ -1421,7 +1434,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
     STAMP(8);
     // ---------------- observation rows of the groups assigned to this role (helpers.py:128-152, legged_robot_base.py:787-793,326-331,
     // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)
-    if (valid && map_words > 0) {
+    if (valid && obs_by_role) {
       OBS_GROUPS(0, true);
     }
   } else {
@@ -1495,7 +1508,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
       }
     }
     WAVE_LDS_FENCE();
-    if (valid && map_words > 0) {
+    if (valid && obs_by_role) {
       // a surviving env: every pair; a terminated env: all but the pairs that read post-reset features (after bar3)
       if (misc[M_RESET] != 0.0f || gateB) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
     }
@@ -1506,11 +1519,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   // a terminated env (~1 % of them): the pairs of role B's rows that read post-reset features, by role B itself — it is idle from here to bar4
   // while role A, the chain that sets the kernel's duration, writes the state back (round 2: role A wrote them before bar3, +2.8 k cycles on
   // exactly the workgroups that finish last)
-  if (roleB && valid && map_words > 0 && misc[M_RESET] != 0.0f) { OBS_GROUPS_LATE(1); }
+  if (roleB && valid && obs_by_role && misc[M_RESET] != 0.0f) { OBS_GROUPS_LATE(1); }
 
   // =============== interval 3: state write-back (role A) ================================================================================
   if (valid) {
-    if (map_words > 0) {
+    if (obs_by_role) {
     } else {
       // per-element maps in global memory (a feature row too large for the compact LDS maps): both roles, 64 lanes per env
       const int l64 = lane + (roleB ? PBHC_G : 0);
@@ -1535,7 +1548,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
             const int j = j0 + u * 2 * PBHC_G;
             if (j < dim) {
               float x = feat[si[u]];
-              if (ns[u] != 0.0f) x = x + (rng_uniform(rt.seed, env, step_ctr, 16 + g, j) * 2.0f - 1.0f) * (ns[u] * noise_cur);
+              if (ns[u] != 0.0f) x = x + (obs_noise_u(nzb, 16 + g, (uint32_t)(mdst ? di[u] : j)) * 2.0f - 1.0f) * (ns[u] * noise_cur);
               x = x * sc[u];
               if (clip) x = clampf(x, -c.clip_observations, c.clip_observations);
               out[di[u]] = x;
@@ -1576,37 +1589,30 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) void k_env_step(const Pbh
   }
 
   STAMP(11);
-  // ---------------- workgroup partial sums for the host-side scalars of the reference ------------
-  if (!roleB) {                                              // (the zero fill by all 32 lanes: one lane storing 64 words in turn was 0.9 k cycles of every workgroup's tail)
-    float* bpq0 = blockpart + le * PBHC_NP;
-    for (int k = lane; k < PBHC_NP; k += PBHC_G) bpq0[k] = 0.0f;
-  }
-  WAVE_LDS_FENCE();
-  if (!roleB && lane == 0) {
-    float* bpq = blockpart + le * PBHC_NP;
-    if (valid) {
-      for (int k = 0; k < PBHC_NUM_SIGMA; ++k) bpq[P_ERR + k] = err[k];
-      bpq[P_UPPER_NORM] = red[R_UPN]; bpq[P_LOWER_NORM] = red[R_LON]; bpq[P_VR_NORM] = red[R_VRN];
-      bpq[P_JOINT_NORM] = sqrtf(red[R_JP2]);
-      bpq[P_CLIP_CNT] = red[R_CLIPCNT];
-      bpq[P_RESET_CNT] = misc[M_RESET]; bpq[P_TERM_GRAVITY] = misc[M_GRAV]; bpq[P_TERM_FAR] = misc[M_FAR];
-      bpq[P_TERM_TIMEOUT] = misc[M_TIMEOUT]; bpq[P_TERM_END] = misc[M_END];
-      bpq[P_RESET_EPLEN] = misc[M_RESET] != 0.0f ? misc[M_LASTEP] : 0.0f;
-      bpq[P_ETR_SUM] = etr_val; bpq[P_ETR_SQ] = etr_val * etr_val;
-      bpq[P_REW_SUM] = rew_total;
-      bpq[P_TERM_CONTACT] = misc[M_TCONTACT]; bpq[P_TERM_LOWH] = misc[M_TLOWH];
-      if (close_any) { bpq[P_TERM_POSLIM] = misc[M_TPOSLIM]; bpq[P_TERM_VELLIM] = misc[M_TVELLIM]; bpq[P_TERM_TAULIM] = misc[M_TTAULIM]; }
-      if (MODE) {
-        bpq[P_KEY_NORM] = red[R_KEYN]; bpq[P_LUP_NORM] = red[R_LUPN]; bpq[P_LLO_NORM] = red[R_LLON]; bpq[P_LVR_NORM] = red[R_LVRN];
-        bpq[P_LKEY_NORM] = red[R_LKEYN]; bpq[P_TERM_REFZ] = misc[M_REFZ]; bpq[P_TERM_REFORI] = misc[M_REFORI]; bpq[P_TERM_BODYZ] = misc[M_BODYZ];
-      }
+  // ---------------- partial sums for the host-side scalars of the reference: one row per dynamics WAVE (its two envs added up by one
+  // cross-half exchange), lane <-> column, sources from the table loaded in the prologue.  No workgroup barrier, no LDS staging: the
+  // reference waves are done, and k_env_finalize adds up 2 rows per workgroup in its fixed order.
+  if (!roleB) {
+    if (valid && lane == 0) {
+      misc[M_PJOINT] = sqrtf(red[R_JP2]);
+      misc[M_PEPLEN] = misc[M_RESET] != 0.0f ? misc[M_LASTEP] : 0.0f;
+      misc[M_PETR] = etr_val; misc[M_PETRSQ] = etr_val * etr_val;
+      misc[M_PREW] = rew_total;
+      misc[M_ZERO] = 0.0f;
     }
-  }
-  LDS_BARRIER();                                               // bar4
-  if (threadIdx.x < PBHC_NP) {
-    float v = 0.0f;
-    for (int e = 0; e < PBHC_EPB; ++e) v += blockpart[e * PBHC_NP + threadIdx.x];
-    partials[(u32)blockIdx.x * (u32)PBHC_NP + threadIdx.x] = v;
+    WAVE_LDS_FENCE();
+    float v0 = 0.0f, v1 = 0.0f;
+    if (valid) {
+      v0 = S[(psrc0 & 0x8000u) ? Lds::MISC + (int)(psrc0 & 0x7FFFu) : lo.red + (int)psrc0];
+      v1 = S[(psrc1 & 0x8000u) ? Lds::MISC + (int)(psrc1 & 0x7FFFu) : lo.red + (int)psrc1];
+    }
+    v0 += __shfl_xor(v0, PBHC_G, 2 * PBHC_G);                 // env 0 + env 1 of this wave
+    v1 += __shfl_xor(v1, PBHC_G, 2 * PBHC_G);
+    if ((threadIdx.x & PBHC_G) == 0) {
+      float* prow = partials + ((u32)blockIdx.x * 2u + (u32)wave) * (u32)PBHC_NP;
+      prow[lane] = v0;
+      prow[lane + PBHC_G] = v1;
+    }
   }
   STAMP(12);
   WG_STAMP(1);

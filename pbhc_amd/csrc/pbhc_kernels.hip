@@ -588,7 +588,7 @@ static int finalize_config(const PbhcEnvConfig* cfg, PbhcEnvConfig* fin, int* ld
   }
   {
     // the compact maps must not cost a resident workgroup per CU (160 KB LDS): otherwise the per-element maps stay in global memory
-    const size_t base = ((size_t)PBHC_EPB * *lds_stride + (size_t)((Bx * SKC_W + 3) & ~3) + (size_t)PBHC_EPB * PBHC_NP) * sizeof(float);
+    const size_t base = ((size_t)PBHC_EPB * *lds_stride + (size_t)((Bx * SKC_W + 3) & ~3)) * sizeof(float);
     const size_t with = base + (size_t)cfg->map_lds_words * sizeof(float);
     if (cfg->map_lds_words > 0 && (160 * 1024) / with < (160 * 1024) / base) fin->map_lds_words = 0;
     *lds_bytes = fin->map_lds_words > 0 ? with : base;
@@ -624,7 +624,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->spec_fn = nullptr;
   e->spec_dl = nullptr;
   if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
-  if (hipMalloc(&e->d_partials, (size_t)e->nblocks * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
+  if (hipMalloc(&e->d_partials, (size_t)e->nblocks * 2 * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_skc, SKC_WORDS * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); (void)hipFree(e->d_partials); delete e; return PBHC_ENOMEM; }
   {
     float img[SKC_WORDS];
@@ -804,7 +804,7 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
 // after the fused launch and before the next one (the rollout runs it next to the policy forward, off the step -> policy -> step chain).
 int pbhc_env_step_finish(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   ARG_CHECK(e && io && io->frame_cursor && io->num_frames >= 1);
-  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, (hipStream_t)stream, e->d_cfg, e->d_glob, e->d_partials, e->nblocks, io->frame_cursor,
+  hipLaunchKernelGGL(k_env_finalize, dim3(1), dim3(64 * PBHC_FIN_CHUNKS), 0, (hipStream_t)stream, e->d_cfg, e->d_glob, e->d_partials, 2 * e->nblocks, io->frame_cursor,
                      io->num_frames, (const double*)nullptr, io->totals_out, 0.0);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;

@@ -87,13 +87,20 @@ __device__ __forceinline__ f4 quat_unit(f4 q) {
   n = fmaxf(n, 1e-9f);
   return mk4(q.x / n, q.y / n, q.z / n, q.w / n);
 }
-// The same normalisation with ONE hardware reciprocal (v_rcp_f32, 1 ulp) instead of four correctly rounded divisions (~10 instructions
-// each): for the sim-stub's rigid-body chain — Isaac Gym's job in the reference, so there is no reference op order to mirror — where
-// quat_unit runs once per joint of every body's chain.  Differs from quat_unit by <= 2 ulp per component.
+// The same normalisation with ONE hardware reciprocal square root (v_rsq_f32, 1 ulp) instead of a correctly rounded square root (~15
+// instructions) and four correctly rounded divisions (~10 each): for the sim-stub's rigid-body chain — Isaac Gym's job in the reference, so
+// there is no reference op order to mirror — where it runs once per joint of every body's chain.  Differs from quat_unit by <= 2 ulp per
+// component; the 1e-9 clamp of the norm becomes a 1e-18 clamp of its square (a chain quaternion is a product of unit quaternions).
 __device__ __forceinline__ f4 quat_unit_fast(f4 q) {
-  float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
-  const float r = __builtin_amdgcn_rcpf(n);
+  const float r = __builtin_amdgcn_rsqf(fmaxf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, 1e-18f));
   return mk4(q.x * r, q.y * r, q.z * r, q.w * r);
+}
+// quat_from_angle_axis for a UNIT axis (the skeleton image holds normalised joint axes): (axis sin(a/2), cos(a/2)), unit by construction —
+// the reference form below normalises the axis and the result again (two square roots, seven divisions)
+__device__ __forceinline__ f4 quat_from_angle_unit_axis(float angle, f3 axis) {
+  float s, c;
+  sincos_cw(0.5f * angle, &s, &c);
+  return mk4(axis.x * s, axis.y * s, axis.z * s, c);
 }
 __device__ __forceinline__ f3 normalize3(f3 v) {
   float n = fmaxf(norm3(v), 1e-9f);
@@ -135,16 +142,21 @@ __device__ __forceinline__ f4 quat_from_angle_axis(float angle, f3 axis) {
   sincos_cw(th, &s, &c);
   return quat_unit(mk4(a.x * s, a.y * s, a.z * s, c));
 }
-// rotations.py:368-387 (+ maths.copysign :16-19)
+// rotations.py:368-387 (+ maths.copysign :16-19).  The arguments of the three inverse functions are exposed so that a caller can spread
+// them over lanes (k_env_step evaluates one atan2 per lane); euler_xyz is the plain composition.
+__device__ __forceinline__ void euler_xyz_args(f4 q, float* sinr, float* cosr, float* sinp, float* siny, float* cosy) {
+  *sinr = 2.0f * (q.w * q.x + q.y * q.z);
+  *cosr = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+  *sinp = 2.0f * (q.w * q.y - q.z * q.x);
+  *siny = 2.0f * (q.w * q.z + q.x * q.y);
+  *cosy = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+}
 __device__ __forceinline__ f3 euler_xyz(f4 q) {
-  float sinr = 2.0f * (q.w * q.x + q.y * q.z);
-  float cosr = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+  float sinr, cosr, sinp, siny, cosy;
+  euler_xyz_args(q, &sinr, &cosr, &sinp, &siny, &cosy);
   float roll = atan2f(sinr, cosr);
-  float sinp = 2.0f * (q.w * q.y - q.z * q.x);
   float sgn = (sinp > 0.0f) ? 1.0f : ((sinp < 0.0f) ? -1.0f : 0.0f);
   float pitch = (fabsf(sinp) >= 1.0f) ? (1.5707963267948966f * sgn) : asinf(sinp);
-  float siny = 2.0f * (q.w * q.z + q.x * q.y);
-  float cosy = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
   return mk3(roll, pitch, atan2f(siny, cosy));
 }
 

@@ -232,6 +232,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         tcon.extend([names.index(s_) for s_ in names if n in s_])
     if c.terminate_by_contact and len(tcon) > K["PBHC_MAX_IDX"]:
         raise _lib.PbhcError("too many terminate_after_contacts_on bodies")
+    L.termination_contact = tcon                                                             # (the kernel gets the list only when the switch is on)
     c.num_term_contact = len(tcon) if c.terminate_by_contact else 0
     for i, b_ in enumerate(tcon[:c.num_term_contact]):
         c.term_contact[i] = b_
@@ -529,6 +530,23 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         c.groups[i].src = ts.data_ptr()
         c.groups[i].scale = tsc.data_ptr()
         c.groups[i].noise = tn.data_ptr()
+        # the same map as runs of consecutive (dst, src) with one scale / noise / readiness class (PbhcObsRun): what the config-specialised
+        # kernel unrolls into straight-line code
+        runs = []
+        for j in range(len(src)):
+            late_j = int(feat_class[src[j]]) == 2
+            if runs and runs[-1][0] + runs[-1][2] == dst[j] and runs[-1][1] + runs[-1][2] == src[j] and runs[-1][3] == late_j \
+                    and runs[-1][4] == sc[j] and runs[-1][5] == ns[j]:
+                runs[-1][2] += 1
+            else:
+                runs.append([dst[j], src[j], 1, late_j, sc[j], ns[j]])
+        if len(runs) <= K["PBHC_MAX_RUNS"]:
+            c.groups[i].num_runs = len(runs)
+            for r_, (d_, s_, n_, l_, a_, b_) in enumerate(runs):
+                R = c.groups[i].runs[r_]
+                R.dst, R.src, R.len, R.late, R.scale, R.noise = int(d_), int(s_), int(n_), int(l_), float(a_), float(b_)
+        else:
+            c.groups[i].num_runs = -1
         if compact:
             pairs = seg_tables[i]
             seg_of = {p: k for k, p in enumerate(pairs)}

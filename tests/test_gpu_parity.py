@@ -32,6 +32,20 @@ SLERP = dict(hard=1.2e-3, frac=0.02)
 ANGVEL = dict(hard=1e-2, frac=0.02, tol_override=2e-3)     # env traces only (root angular velocity written by a reset: no frame pair at hand)
 
 
+def slerp_scale_bound(q0, q1, k=4.0):
+    """[..., 1] relative bound on the SCALE of a slerp output of the pair (q0, q1) — what a vector rotated by it inherits twice over.
+    The reference's slerp (rotations.py:210-232) divides sin(t a) by s = sqrt(1 - c^2) with c the fp32 dot product: k ulps of c move
+    1 - c^2 by 2 k 6e-8, i.e. s by k 6e-8 / s^2 relative, while a = acos(c) moves with c itself — so for slowly turning frame pairs the
+    result is q (1 +- k 6e-8 / s^2), not unit, and nothing downstream renormalises it (s = 2.5e-2, a body turning at 1.5 rad/s sampled at
+    30 fps: 4e-4).  Below s = 1.4e-3 the fall-back jump of `slerp_jump_bound` takes over."""
+    q0, q1 = torch.as_tensor(q0).double(), torch.as_tensor(q1).double()
+    q1 = torch.where(((q0 * q1).sum(-1, keepdim=True) < 0), -q1, q1)
+    c = (q0 * q1).sum(-1, keepdim=True).clamp(max=1.0)
+    sh = torch.sqrt(1.0 - c * c)
+    jump = 0.5 * (q1 - q0).norm(dim=-1, keepdim=True) + 2e-5
+    return torch.where(sh < 1.4e-3, jump, (k * 6e-8 / (sh * sh).clamp(min=1e-12)).clamp(max=2e-2)).float()
+
+
 def angvel_tol(ref, dt, k=16.0, base=5e-5, norm=None):
     """elementwise bound for table / looked-up angular velocities: base + k * eps / (dt^2 |omega|), |omega| floored at 1e-3 rad per frame.
     `norm` [..., 1]: the speed that conditions the element when it is not the element's own (see table_speed_floor)."""
