@@ -56,8 +56,9 @@ def algorithmic_bytes_per_env_step(env):
     )
     writes = dict(
         action_queue=Q * D, obs=sum(L.group_dims.values()), hist=L.hist_dim, rew=c.num_rew_cols, episode_sums=c.num_sum_cols,
-        ref_body_extend=7 * Bx, rigid_body_state=13 * B, contact_forces=3 * B, act_state=4 * D, dof_state=2 * D, last_dof=2 * D, root=13,
-        foot_state=5 * F, scalars=2 + 2 + 2 + 1,
+        act_state=4 * D, dof_state=2 * D, last_dof=2 * D, root=13, foot_state=5 * F, scalars=2 + 2 + 2 + 1 + 1,
+        # (not counted, because not moved: the simulator surface's rigid-body state 13 B, its contact forces 3 B and the reference bodies
+        # 7 Bx are re-derived on access since round 3 — 550 words of the 3 010 per env-step that round 2's figure carried)
     )
     motion = 2 * env._motion_lib.row
     if getattr(env, "TRACKING_MODE", 0) == 1 and c.future_num_steps:
@@ -152,12 +153,12 @@ def build(num_envs, device, seed, workload="v1_walk", num_clips=1):
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC summary (profiles/round2_k_env_step_pmc.json, written by
+    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC summary (profiles/round3_k_env_step_pmc.json, written by
     tools/pmc_summary.py from two separate --pmc passes of tools/kernel_probe.py on this 4096-env workload) — only if that summary was
     taken from THESE kernel sources (hash of pbhc_kernels.hip / pbhc_math.h / pbhc_hip.h), else None.  FETCH_SIZE / WRITE_SIZE are in KiB; on
     gfx950 FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md, HBM; calibrated there for 16 B/lane, ours are mostly
     4 B/lane, so the read side is an estimate)."""
-    f = os.path.join(ROOT, "profiles", "round2_k_env_step_pmc.json")
+    f = os.path.join(ROOT, "profiles", "round3_k_env_step_pmc.json")
     if not os.path.exists(f):
         return None
     rec = json.load(open(f))
@@ -305,12 +306,12 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
     buf = (C.c_float * 512)()
     cnt = C.c_int(0)
     _lib.check(lib.pbhc_env_profile_read(env._env, buf, min(512, K * T), C.byref(cnt)))
-    kern_ms_raw = sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)
-    # the dispatch-attached event pair also times the queue-side start / stop handling: calibrated with a kernel of known duration (a 20 us spin)
+    kern_ms = sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)      # the RAW event-pair reading: what roofline.achieved / frac use
+    # what the dispatch-attached pair reads beyond a kernel's execution, from a kernel of known duration (a 20 us spin): published next to
+    # the raw value, not subtracted from it (round 2 subtracted it and read 5-7 % below rocprofv3 of the same launches)
     ov = C.c_float(0.0)
     _lib.check(lib.pbhc_env_profile_overhead(env._env, _lib.current_stream(), C.byref(ov)))
     ev_overhead_ms = max(0.0, float(ov.value))
-    kern_ms = max(kern_ms_raw - ev_overhead_ms, 1e-6)
     words, motion_words, _, _ = algorithmic_bytes_per_env_step(env)
     alg_bytes = 4.0 * (words + motion_words) * N
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -339,7 +340,8 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
                        "envs_per_gpu": N, "global_envs": N * world, "num_steps_per_env": T, "parallelism": f"dp{world}"},
             "rollout_ms": rollout_ms, "update_ms": update_ms,
             "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes() if (N == 4096 and workload == "v1_walk") else None, "kernel_ms": kern_ms, "kernel_ms_event_pair": kern_ms_raw, "event_pair_overhead_ms": ev_overhead_ms, "launches_timed": cnt.value,
+                         "traffic": pmc_traffic_bytes() if (N == 4096 and workload == "v1_walk") else None, "kernel_ms": kern_ms, "kernel_ms_minus_event_overhead": max(kern_ms - ev_overhead_ms, 1e-6), "event_pair_overhead_ms": ev_overhead_ms, "launches_timed": cnt.value,
+                         "kernel_specialised_to_config": bool(env.is_specialised),
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
             "roofline_update": {"bound": "mfma", "achieved": upd_flops / (update_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -337,8 +337,9 @@ typedef struct PbhcStepIO {
   /* simulator-surface state (reference names; simulator/isaacgym/isaacgym.py:574-618) */
   float* root_states;             /* [N,13] */
   float* dof_state;               /* [N,D,2] (pos, vel) */
-  float* rigid_body_state;        /* [N,B,13] pos3 rot4 vel3 ang3, may be NULL */
-  float* contact_forces;          /* [N,B,3], may be NULL */
+  float* rigid_body_state;        /* [N,B,13] pos3 rot4 vel3 ang3, may be NULL: nothing on the training path reads it — the replay stub hands NULL and
+                                   * re-derives it on first access (pbhc_sim_fk of the same replay frame: the same arithmetic) */
+  float* contact_forces;          /* [N,B,3], may be NULL (a copy of the replay frame's contact forces) */
   /* env state (reference names; legged_robot_base.py:39-131, motion_tracking.py:251-263) */
   float* actions; float* last_actions; float* actions_after_delay; float* action_queue; /* [N,D] x3, [N,Q,D] */
   float* last_dof_pos; float* last_dof_vel; float* torques;                              /* [N,D] */
@@ -357,8 +358,9 @@ typedef struct PbhcStepIO {
   /* outputs */
   float* obs[PBHC_MAX_GROUPS];    /* [N,dim_g]; group num_groups-1 may alias `hist` semantics (see PbhcOutMap) */
   float* rew_buf;                 /* [N,num_rew_cols] */
-  float* ref_body_pos_extend;     /* [N,Bx,3] may be NULL */
-  float* ref_body_rot_extend;     /* [N,Bx,4] may be NULL */
+  float* ref_body_pos_extend;     /* [N,Bx,3] may be NULL: extras["ref_body_pos_extend"] is read by evaluation callbacks only — the env hands NULL and */
+  float* ref_body_rot_extend;     /* [N,Bx,4] may be NULL  re-derives both on first access from ref_time_out (pbhc_motion_state: the same lerp / slerp) */
+  float* ref_time_out;            /* [N] may be NULL: the motion time of this step's reference lookup, (episode_length + 1) dt + start BEFORE a reset */
   float* episode_rew_out;         /* [N,num_sum_cols] episode_sums / max_episode_length_s of envs reset this step (else unchanged), may be NULL */
   /* Data-parallel runs: NULL -> the step finalizes its batch statistics itself.  Non-NULL -> device double[PBHC_NUM_TOTALS]: the step
    * only writes this shard's batch sums there (and advances the RNG counter / frame cursor); the caller sums them over ranks and calls
@@ -369,7 +371,10 @@ typedef struct PbhcStepIO {
    * so no line is written twice by different workgroups. */
   int32_t obs_pitch[PBHC_MAX_GROUPS];
   int32_t hist_pitch;
-  int32_t pad1_;
+  /* 1: re-draw the episodic domain randomisation (gain / torque-noise scales, control delay + action queue, default joint angles) of EVERY
+   * env in this step, after its torques and before its observations — `_update_tasks_callback` with domain_rand.reinit_epis_rand > 0
+   * (legged_robot_base.py:390-395 -> _episodic_domain_randomization(all env ids) :599-635).  Same draws as a reset's (Philox streams / ovr_*). */
+  int32_t redraw_all;
 } PbhcStepIO;
 
 typedef struct PbhcEnv PbhcEnv;   /* opaque */

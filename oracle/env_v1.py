@@ -193,12 +193,14 @@ class MotionTrackingOracle:
         self.sigma[key] = min(self.ema[key], self.sigma[key])        # type "origin" (motion_tracking.py:1046-1048)
 
     # ------------------------------------------------------------------------------------
-    def step(self, actions, frame, body_state, u_rfi=None, reset_samples=None, gate_u=None):
+    def step(self, actions, frame, body_state, u_rfi=None, reset_samples=None, gate_u=None, redraw_samples=None):
         """actions [N,D]; frame: dict(root[N,13], dof_pos, dof_vel, contact[N,B,3]) = the replay
         frame the sim switches to at the end of the physics step; body_state: (pos,rot,vel,ang)
         of the B bodies for that frame (oracle.fk.sim_fk of the frame); reset_samples: dict of
         [N,...] tensors (motion_start_times, kp_scale, kd_scale, rfi_lim_scale, rao_scale,
-        action_delay_idx) holding the values the reference drew, consumed for resetting envs."""
+        action_delay_idx) holding the values the reference drew, consumed for resetting envs; redraw_samples: the same kind of dict when
+        domain_rand.reinit_epis_rand fires in this step — `_update_tasks_callback` re-draws the episodic DR of EVERY env
+        (legged_robot_base.py:390-395) between the pre-computed observations and the termination check."""
         s, N, D = self.s, self.N, self.D
         ec, cfg = self.ec, self.cfg
         log = self.log
@@ -272,6 +274,9 @@ class MotionTrackingOracle:
         log["lower_body_diff_norm"] = self.dif_pos[:, self.lower_id].norm(dim=-1).mean()
         log["vr_3point_diff_norm"] = self.dif_pos[:, self.track_id].norm(dim=-1).mean()
         log["joint_pos_diff_norm"] = self.dif_joint_angles.norm(dim=-1).mean()
+        # ---- _update_tasks_callback: reinit_epis_rand (legged_robot_base.py:390-395)
+        if redraw_samples is not None:
+            self._episodic_dr(torch.arange(N), redraw_samples)
         # ---- _check_termination
         reset = torch.zeros(N, dtype=torch.bool)
         by = {}
@@ -368,21 +373,7 @@ class MotionTrackingOracle:
         for k in self.hist:
             self.hist[k][ids] *= 0.0
         # _reset_tasks_callback: episodic DR (legged_robot_base.py:599-635)
-        dr = cfg.domain_rand
-        if dr.randomize_pd_gain:
-            s["kp_scale"][ids] = samp["kp_scale"][ids]
-            s["kd_scale"][ids] = samp["kd_scale"][ids]
-        if dr.randomize_rfi_lim:
-            s["rfi_lim_scale"][ids] = samp["rfi_lim_scale"][ids]
-        if dr.use_rao:
-            s["rao_scale"][ids] = samp["rao_scale"][ids]
-        if dr.randomize_ctrl_delay:
-            s["action_queue"][ids] *= 0.0
-            s["action_delay_idx"][ids] = samp["action_delay_idx"][ids]
-        if dr.get("randomize_default_dof_pos", False):          # legged_robot_base.py:632-635: default = raw default + U(dof_pos_range)
-            if "default_dof_pos" not in s:
-                s["default_dof_pos"] = self.default_dof_pos.repeat(self.N, 1).clone()
-            s["default_dof_pos"][ids] = samp["dof_pos_bias"][ids] + self.default_dof_pos
+        self._episodic_dr(ids, samp)
         rw = cfg.rewards
         if rw.reward_penalty_curriculum:                    # legged_robot_base.py:882-900
             if self.avg_ep_len < rw.reward_penalty_level_down_threshold:
@@ -433,6 +424,25 @@ class MotionTrackingOracle:
         self.episode_extras = {"rew_" + k: self.sums[k][ids] / ec.max_episode_length_s for k in self.sums}
         for k in self.sums:
             self.sums[k][ids] = 0.0
+
+    def _episodic_dr(self, ids, samp):
+        """_episodic_domain_randomization (legged_robot_base.py:599-635) with the reference's draws handed in"""
+        s, cfg = self.s, self.cfg
+        dr = cfg.domain_rand
+        if dr.randomize_pd_gain:
+            s["kp_scale"][ids] = samp["kp_scale"][ids]
+            s["kd_scale"][ids] = samp["kd_scale"][ids]
+        if dr.randomize_rfi_lim:
+            s["rfi_lim_scale"][ids] = samp["rfi_lim_scale"][ids]
+        if dr.use_rao:
+            s["rao_scale"][ids] = samp["rao_scale"][ids]
+        if dr.randomize_ctrl_delay:
+            s["action_queue"][ids] *= 0.0
+            s["action_delay_idx"][ids] = samp["action_delay_idx"][ids]
+        if dr.get("randomize_default_dof_pos", False):          # legged_robot_base.py:632-635: default = raw default + U(dof_pos_range)
+            if "default_dof_pos" not in s:
+                s["default_dof_pos"] = self.default_dof_pos.repeat(self.N, 1).clone()
+            s["default_dof_pos"][ids] = samp["dof_pos_bias"][ids] + self.default_dof_pos
 
     # ------------------------------------------------------------------------------------
     def _default(self, s):

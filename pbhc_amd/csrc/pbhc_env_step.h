@@ -259,11 +259,11 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
         const int a = __float_as_int(kb[11 + i]);
         const float* ka = skc + a * SKC_W;
         f3 axis = ld3(ka + 7);
-        f3 pn = add3(p, quat_rotate(r, ld3(ka)));
-        f4 rn = quat_unit_fast(quat_mul(r, ld4(relq + 4 * a)));
-        f3 wn = add3(w, mul3(quat_rotate(rn, axis), qd[a - 1]));
-        v = add3(v, cross3(w, sub3(pn, p)));
-        p = pn; r = rn; w = wn;
+        const f3 rp = fk_rotate(r, ld3(ka));
+        f4 rn = fk_mul_unit(r, ld4(relq + 4 * a));
+        f3 wn = fk_axpy(w, qd[a - 1], fk_rotate(rn, axis));
+        v = fk_add_cross(v, w, rp);
+        p = add3(p, rp); r = rn; w = wn;
       }
       if (b >= B) {
         f3 off = ld3(kb);
@@ -321,11 +321,11 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
         const f4 rq_n = ld4(relq + 4 * a1);
         const float qd_n = qd[max(a1 - 1, 0)];
         WAVE_LDS_FENCE();                                        // (compiler fence: keep the requests above this level's arithmetic)
-        const f3 pn = add3(p, quat_rotate(r, off_c));
-        const f4 rn = quat_unit_fast(quat_mul(r, rq_c));
-        const f3 wn = add3(w, mul3(quat_rotate(rn, ax_c), qd_c));
-        v = add3(v, cross3(w, sub3(pn, p)));
-        p = pn; r = rn; w = wn;
+        const f3 rp = fk_rotate(r, off_c);                      // (pbhc_math.h: the chain's arithmetic is fused on purpose)
+        const f4 rn = fk_mul_unit(r, rq_c);
+        const f3 wn = fk_axpy(w, qd_c, fk_rotate(rn, ax_c));
+        v = fk_add_cross(v, w, rp);
+        p = add3(p, rp); r = rn; w = wn;
         off_c = off_n; ax_c = ax_n; rq_c = rq_n; qd_c = qd_n; a1 = a2;
       }
       if (b >= B) {
@@ -621,7 +621,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   const float start = io.motion_start_times[envc];
 
   // role-A registers that live across phases
-  float mlenA = 1.0f;
   uint32_t psrc0 = 0, psrc1 = 0;                              // sources of this lane's two partial-sum columns (kPartTab)
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, dpA = 0.0f, etr_old = 0.0f;
   int pf_tid = 0, pf_tpen = 0, pf_tsrc = -1, pf_colterm = -1;
@@ -670,7 +669,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       dpA = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
-      mlenA = io.motion_len[envc];
       const PartTab& pt = kPartTab[(MODE ? 2 : 0) + (close_any ? 1 : 0)];
       psrc0 = pt.v[lane]; psrc1 = pt.v[lane + PBHC_G];
     }
@@ -688,36 +686,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
     fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
-    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588) ---------
-    // One lane per quantity and ONE code path per function: lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of
-    // the pitch, lanes 4-6 the three base-frame rotations, lane 7 the reference time (lane 0 doing all of it in turn was ~450 instructions
-    // of the chain; roll and pitch only exist where an observation reads them: general tracking).
-    if (valid) {
-      const f4 rq4 = ld4(root + 3);
-      if (lane < 3) {
-        float sinr, cosr, sinp, siny, cosy;
-        euler_xyz_args(rq4, &sinr, &cosr, &sinp, &siny, &cosy);
-        const f3 hx = quat_rotate(rq4, mk3(1.0f, 0.0f, 0.0f));                  // calc_heading rotations.py:257-268
-        const float ang = atan2f(lane == 0 ? siny : (lane == 1 ? hx.y : sinr), lane == 0 ? cosy : (lane == 1 ? hx.x : cosr));
-        if (lane == 0) feat[c.feat_off[PBHC_F_RELYAW]] = ang - rt.ref_init_yaw;
-        else if (lane == 1) st4(misc + M_HINV, quat_from_angle_z(-ang));        // calc_heading_quat_inv rotations.py:296-306
-        else if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH]] = ang;
-      } else if (lane == 3) {
-        if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = euler_xyz(rq4).y;
-      } else if (lane <= 6) {
-        // the same rotation of three different vectors
-        const f3 vin = lane == 4 ? ld3(root + 7) : (lane == 5 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
-        const f3 vo = quat_rotate_inverse(rq4, vin);
-        const int off = lane == 4 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 5 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
-        st3(feat + off, vo);
-        if (lane == 6) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
-      } else if (lane == 7) {
-        const float t = (float)(ep1 + 1) * dt + start;
-        misc[M_EPLEN] = (float)ep1;
-        misc[M_START] = start; misc[M_MLEN] = mlenA;
-        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlenA;
-      }
-    }
     STAMP(2);
   } else {
     LOAD_CLIP_META();
@@ -732,6 +700,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     f4 rq0 = mk4(0, 0, 0, 1), rq1 = rq0;
     float rd0 = 0, rd1 = 0, rdv0 = 0, rdv1 = 0, rc0 = 0, rc1 = 0;
     tref = (float)(ep1 + 1) * dt + start;                       // motion_tracking.py:554,588
+    if (io.ref_time_out && valid && lane == 0) io.ref_time_out[env] = tref;     // (what a lazy extras["ref_body_*_extend"] is rebuilt from)
     {
       int f0, f1;
       frame_blend(tref, m_len, m_nf, m_dt, &f0, &f1, &blend);
@@ -768,6 +737,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
     pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
     adelayB = io.action_delay_idx[envc];
+    const float frootB = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
+    const float mlenB = io.motion_len[envc];
     didx = c.randomize_ctrl_delay ? (int)adelayB : 0;
     bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
     {
@@ -876,6 +847,42 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
     clipcnt = group_sum(clipcnt);
     WAVE_LDS_FENCE();
+    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588) ---------
+    // Here, on the reference waves, which reach bar1 ~3 k cycles before the dynamics waves (whose FK chain sets the kernel's duration: on
+    // those waves these ~2 k cycles were pure critical path).  The root state of the new frame comes from this role's own load of it; the
+    // LDS copy is written by both roles with identical words.
+    if (valid && lane < 13) root[lane] = frootB;
+    WAVE_LDS_FENCE();
+    // One lane per quantity and ONE code path per function: lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of
+    // the pitch, lanes 4-6 the three base-frame rotations, lane 7 the reference time (lane 0 doing all of it in turn was ~450 instructions
+    // of the chain; roll and pitch only exist where an observation reads them: general tracking).
+    if (valid) {
+      const f4 rq4 = ld4(root + 3);
+      if (lane < 3) {
+        float sinr, cosr, sinp, siny, cosy;
+        euler_xyz_args(rq4, &sinr, &cosr, &sinp, &siny, &cosy);
+        const f3 hx = quat_rotate(rq4, mk3(1.0f, 0.0f, 0.0f));                  // calc_heading rotations.py:257-268
+        const float ang = atan2f(lane == 0 ? siny : (lane == 1 ? hx.y : sinr), lane == 0 ? cosy : (lane == 1 ? hx.x : cosr));
+        if (lane == 0) feat[c.feat_off[PBHC_F_RELYAW]] = ang - rt.ref_init_yaw;
+        else if (lane == 1) st4(misc + M_HINV, quat_from_angle_z(-ang));        // calc_heading_quat_inv rotations.py:296-306
+        else if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH]] = ang;
+      } else if (lane == 3) {
+        if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = euler_xyz(rq4).y;
+      } else if (lane <= 6) {
+        // the same rotation of three different vectors
+        const f3 vin = lane == 4 ? ld3(root + 7) : (lane == 5 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
+        const f3 vo = quat_rotate_inverse(rq4, vin);
+        const int off = lane == 4 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 5 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+        st3(feat + off, vo);
+        if (lane == 6) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+      } else if (lane == 7) {
+        const float t = (float)(ep1 + 1) * dt + start;
+        misc[M_EPLEN] = (float)ep1;
+        misc[M_START] = start; misc[M_MLEN] = mlenB;
+        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlenB;
+      }
+    }
+    WAVE_LDS_FENCE();
     philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar1 next
     STAMPB(3);
   }
@@ -981,16 +988,19 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       s_bodyz = group_max(s_bodyz);
     }
     STAMP(24);
+    // the means over body sets: multiplications by the set sizes' reciprocals (literals in the specialised build; a correctly rounded
+    // division is ~10 instructions, and this lane-0 block sits on the chain — the quotient differs from x / n by <= 1 ulp)
+    const float inv_upper = 1.0f / (float)c.num_upper, inv_lower = 1.0f / (float)c.num_lower, inv_track = 1.0f / (float)c.num_track;
+    const float inv_feet = 1.0f / (float)NF, inv_bx = 1.0f / (float)Bx, inv_key = MODE ? 1.0f / (float)c.num_key : 1.0f;
     if (valid && lane == 0) {
       if (MODE) {
-        const float nk = (float)c.num_key;
-        red[R_KEY] = s_key / nk; red[R_KEYN] = s_keyn / nk; red[R_LKEY] = s_lkey / nk; red[R_LKEYN] = s_lkeyn / nk; red[R_LKROT] = s_lkrot / nk;
-        red[R_KVEL] = s_kvel / nk; red[R_KANG] = s_kang / nk;
-        red[R_LUPN] = s_lupn / (float)c.num_upper; red[R_LLON] = s_llon / (float)c.num_lower; red[R_LVRN] = s_lvrn / (float)c.num_track;
+        red[R_KEY] = s_key * inv_key; red[R_KEYN] = s_keyn * inv_key; red[R_LKEY] = s_lkey * inv_key; red[R_LKEYN] = s_lkeyn * inv_key; red[R_LKROT] = s_lkrot * inv_key;
+        red[R_KVEL] = s_kvel * inv_key; red[R_KANG] = s_kang * inv_key;
+        red[R_LUPN] = s_lupn * inv_upper; red[R_LLON] = s_llon * inv_lower; red[R_LVRN] = s_lvrn * inv_track;
       }
-      red[R_UP] = s_up / (float)c.num_upper; red[R_LO] = s_lo / (float)c.num_lower; red[R_VR] = s_vr / (float)c.num_track;
-      red[R_FEET] = s_feet / (float)NF; red[R_ROT] = s_rot / (float)Bx; red[R_VEL] = s_vel / (float)Bx; red[R_ANG] = s_ang / (float)Bx;
-      red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn / (float)c.num_upper; red[R_LON] = s_lon / (float)c.num_lower; red[R_VRN] = s_vrn / (float)c.num_track;
+      red[R_UP] = s_up * inv_upper; red[R_LO] = s_lo * inv_lower; red[R_VR] = s_vr * inv_track;
+      red[R_FEET] = s_feet * inv_feet; red[R_ROT] = s_rot * inv_bx; red[R_VEL] = s_vel * inv_bx; red[R_ANG] = s_ang * inv_bx;
+      red[R_MAXNORM] = s_maxn; red[R_UPN] = s_upn * inv_upper; red[R_LON] = s_lon * inv_lower; red[R_VRN] = s_vrn * inv_track;
       if (!MODE) for (int k = PBHC_S_KEY_BODY_POS; k < PBHC_NUM_SIGMA; ++k) red[R_ERR0 + k] = 0.0f;
       // ---- _check_termination (legged_robot_base.py:408-489, motion_tracking.py:330-357)
       float grav = 0.0f, far = 0.0f, tlen = 0.0f, tend = 0.0f;
@@ -1311,8 +1321,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // ---------------- phase G: reset_envs_idx for terminated envs (legged_robot_base.py:491-517,
     // 599-686; motion_tracking.py:265-287,369-378,445-543) ------------------------------------------
     const bool do_reset = valid && misc[M_RESET] != 0.0f;
+    // io.redraw_all (domain_rand.reinit_epis_rand fired, legged_robot_base.py:390-395): the episodic DR block of the reset path for EVERY env,
+    // a surviving env keeping everything else — after this step's torques, before its observations, as `_update_tasks_callback` sits
+    const bool do_dr = do_reset || (valid && io.redraw_all != 0);
     if (valid && lane == 0) { misc[M_LASTEP] = misc[M_EPLEN]; misc[M_DELAY] = (float)adelay; }
-    if (do_reset) {
+    if (do_dr) {
       // env origin + clip meta: role B's prologue loads, handed over in LDS before bar1
       const f3 origin = mk3(misc[M_ORIGIN0], misc[M_ORIGIN1], misc[M_ORIGIN2]);
       const float m_len = misc[M_CLIP_LEN], m_dt = misc[M_CLIP_DT];
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const float ns = io.ovr_start_time ? io.ovr_start_time[env] : ue[0] * mlen;   // sample_time motion_lib_base.py:486-495
       const float t2 = (0.0f + 1.0f) * dt + ns;
       float lk_b = 0.0f, lq0 = 0.0f, lq1 = 0.0f, lv0 = 0.0f, lv1 = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lr0 = 0.0f, lr1 = 0.0f;
-      if (!MODE) {
+      if (!MODE && do_reset) {
         int f0, f1;
         frame_blend(t2, m_len, m_nf, m_dt, &f0, &f1, &lk_b);
         const float* r0 = tbl.frames + (size_t)(m_row0 + f0) * tbl.row;
@@ -1341,7 +1354,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         lr0 = r0[col]; lr1 = r1[col];
       }
       for (int dd = lane; dd < D; dd += PBHC_G) {
-        act[dd] = 0.0f; actd[dd] = 0.0f;
+        if (do_reset) { act[dd] = 0.0f; actd[dd] = 0.0f; }
         float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
         pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, dd, ur);
         if (c.randomize_pd_gain) {
@@ -1365,25 +1378,30 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         }
       }
       if (lane == 0) {
-        misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
-        misc[M_CONTACT0] = 0.0f; misc[M_CONTACT1] = 0.0f; misc[M_CFILT0] = 0.0f; misc[M_CFILT1] = 0.0f;
-        float old_start = misc[M_START];
-        float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
-        io.end_time_ratio_buf[env] = etr;
-        etr_val = etr;
-        io.motion_len[env] = mlen;
-        io.motion_start_times[env] = ns;
-        misc[M_NEWSTART] = ns;
+        if (do_reset) {
+          misc[M_FAT0] = 0.0f; misc[M_FAT1] = 0.0f;
+          misc[M_CONTACT0] = 0.0f; misc[M_CONTACT1] = 0.0f; misc[M_CFILT0] = 0.0f; misc[M_CFILT1] = 0.0f;
+          float old_start = misc[M_START];
+          float etr = (misc[M_LASTEP] * dt + old_start) / misc[M_MLEN];
+          io.end_time_ratio_buf[env] = etr;
+          etr_val = etr;
+          io.motion_len[env] = mlen;
+          io.motion_start_times[env] = ns;
+          misc[M_NEWSTART] = ns;
+        } else {
+          etr_val = etr_old;
+        }
         if (c.randomize_ctrl_delay) {
           long long nd = io.ovr_delay ? io.ovr_delay[env]
                                       : (long long)c.ctrl_delay_range[0] + (long long)(ue[1] * (float)(c.ctrl_delay_range[1] + 1 - c.ctrl_delay_range[0]));
           io.action_delay_idx[env] = nd;
           misc[M_DELAY] = (float)nd;
         }
-        misc[M_EPLEN] = 0.0f;
+        if (do_reset) misc[M_EPLEN] = 0.0f;
       }
       WAVE_LDS_FENCE();
-      if (MODE) {
+      if (!do_reset) {
+      } else if (MODE) {
         // general tracking: _reset_dofs looks up at ep_len*dt + start = start (general_tracking.py:463-476), _reset_root_states at
         // (ep_len+1)*dt + start (kick_motion_res :398,486-496): dofs from the first lookup, root from the second
         motion_lookup_meta(tbl, D, Bx, lane, m_len, m_nf, m_dt, m_row0, 0.0f * dt + misc[M_NEWSTART], origin, false, q, qd, misc + M_RCONTACT0, rp, rq, rv, rw);
@@ -1402,7 +1420,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         if (lane == 0) st4(rq, slerp(q0r, q1r, lk_b));
       }
       WAVE_LDS_FENCE();
-      if (lane == 0) {
+      if (do_reset && lane == 0) {
         st3(root, ld3(rp));
         st4(root + 3, quat_mul(mk4(0.f, 0.f, 0.f, 1.f), ld4(rq)));       // quat_mul(small_random_quaternions(max_angle=0), root_rot)
         st3(root + 7, ld3(rv));
@@ -1414,7 +1432,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     STAMP(7);
     // ---------------- phase H: post-reset features (role B wrote the no-reset values before bar2) ------------------------------------
-    if (do_reset) {
+    if (do_dr) {
       const int o_q = c.feat_off[PBHC_F_DOF_POS], o_qd = c.feat_off[PBHC_F_DOF_VEL], o_a = c.feat_off[PBHC_F_ACTIONS];
       const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
       for (int dd = lane; dd < D; dd += PBHC_G) {
@@ -1510,7 +1528,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     if (valid && obs_by_role) {
       // a surviving env: every pair; a terminated env: all but the pairs that read post-reset features (after bar3)
-      if (misc[M_RESET] != 0.0f || gateB) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
+      if (misc[M_RESET] != 0.0f || gateB || io.redraw_all != 0) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
     }
     STAMPB(5);
   }
@@ -1519,7 +1537,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // a terminated env (~1 % of them): the pairs of role B's rows that read post-reset features, by role B itself — it is idle from here to bar4
   // while role A, the chain that sets the kernel's duration, writes the state back (round 2: role A wrote them before bar3, +2.8 k cycles on
   // exactly the workgroups that finish last)
-  if (roleB && valid && obs_by_role && misc[M_RESET] != 0.0f) { OBS_GROUPS_LATE(1); }
+  if (roleB && valid && obs_by_role && (misc[M_RESET] != 0.0f || io.redraw_all != 0)) { OBS_GROUPS_LATE(1); }
 
   // =============== interval 3: state write-back (role A) ================================================================================
   if (valid) {
@@ -1557,9 +1575,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         }
       }
     }
-    if (!roleB) {
-      STAMP(10);
-      // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405) ---
+    if (roleB) {
+      // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405), by the reference waves: everything it
+      // stores is final in LDS since bar3 (a reset's new state included), these waves have nothing else left, and the arrays are the ones
+      // they loaded in their prologue — while the dynamics waves go straight on to the partial sums (1.3 k cycles off the chain)
       for (int dd = lane; dd < D; dd += PBHC_G) {
         at(io.actions, eD + dd) = act[dd];
         at(io.last_actions, eD + dd) = act[dd];
@@ -1588,6 +1607,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
   }
 
+  STAMP(10);
   STAMP(11);
   // ---------------- partial sums for the host-side scalars of the reference: one row per dynamics WAVE (its two envs added up by one
   // cross-half exchange), lane <-> column, sources from the table loaded in the prologue.  No workgroup barrier, no LDS staging: the

@@ -160,6 +160,32 @@ __device__ __forceinline__ f3 euler_xyz(f4 q) {
   return mk3(roll, pitch, atan2f(siny, cosy));
 }
 
+// ---- arithmetic of the sim-stub's rigid-body chain (fk_walk / fk_walk_wave), CONTRACTED on purpose.  The rest of this file is built with
+// -ffp-contract=off because it mirrors the reference's op order; the rigid-body state, though, was Isaac Gym's output in the reference —
+// there is no reference arithmetic to mirror — and the chain is the longest dependent stretch of k_env_step: with fused multiply-adds a
+// level of the walk is ~75 VALU instructions instead of ~130 (rotate 18 instead of 30, Hamilton product 16 instead of 28).
+#pragma clang fp contract(fast)
+// v + 2 w (u x v) + 2 u x (u x v), u = q.xyz, for a unit q
+__device__ __forceinline__ f3 fk_rotate(f4 q, f3 v) {
+  const float tx = 2.0f * (q.y * v.z - q.z * v.y), ty = 2.0f * (q.z * v.x - q.x * v.z), tz = 2.0f * (q.x * v.y - q.y * v.x);
+  return mk3(v.x + q.w * tx + (q.y * tz - q.z * ty), v.y + q.w * ty + (q.z * tx - q.x * tz), v.z + q.w * tz + (q.x * ty - q.y * tx));
+}
+// Hamilton product a (x) b, xyzw, renormalised with one hardware rsq (as quat_unit_fast)
+__device__ __forceinline__ f4 fk_mul_unit(f4 a, f4 b) {
+  const float x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  const float y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  const float z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  const float w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  const float r = __builtin_amdgcn_rsqf(fmaxf(x * x + y * y + z * z + w * w, 1e-18f));
+  return mk4(x * r, y * r, z * r, w * r);
+}
+// a + s b, a + b x c
+__device__ __forceinline__ f3 fk_axpy(f3 a, float s, f3 b) { return mk3(a.x + s * b.x, a.y + s * b.y, a.z + s * b.z); }
+__device__ __forceinline__ f3 fk_add_cross(f3 a, f3 b, f3 c) {
+  return mk3(a.x + (b.y * c.z - b.z * c.y), a.y + (b.z * c.x - b.x * c.z), a.z + (b.x * c.y - b.y * c.x));
+}
+#pragma clang fp contract(off)
+
 // ---- general-tracking helpers (humanoidverse/utils/torch_utils.py) ------------------------------
 // torch_utils.py:51-57 quat_apply: b + w t + xyz x t, t = 2 (xyz x b)
 __device__ __forceinline__ f3 quat_apply(f4 q, f3 b) {

@@ -57,6 +57,66 @@ class EpisodeExtras(Mapping):
         return len(self.materialise())
 
 
+class StepExtras(dict):
+    """The env's `extras` mapping (one object, refilled every step, like the reference's `self.extras`).  `ref_body_pos_extend` /
+    `ref_body_rot_extend` — the reference motion's extended body poses of the last step (motion_tracking.py:645-650) — are read by
+    evaluation callbacks only, so the fused step does not store them: the kernel leaves the motion time of its lookup (4 B per env instead
+    of 756) and the two tensors are rebuilt by the same lerp / slerp (pbhc_motion_state) when one of them is read — valid until the next
+    `step()`, exactly as long as the reference's env-owned tensors are."""
+    LAZY = {"ref_body_pos_extend": 0, "ref_body_rot_extend": 1}
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+
+    def _fill(self):
+        pos, rot = self._env._reference_bodies()
+        dict.__setitem__(self, "ref_body_pos_extend", pos)
+        dict.__setitem__(self, "ref_body_rot_extend", rot)
+
+    def invalidate(self):
+        for k in self.LAZY:
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, k):
+        if k in self.LAZY and dict.get(self, k) is None:
+            self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+
+class ReinitSchedule:
+    """domain_rand.reinit_epis_rand > 0: the episodic domain randomisation of EVERY env is re-drawn at exponentially distributed intervals
+    (legged_robot_base.py:142,390-395): the counter starts at 0 — the first re-draw fires in the very first step — and every firing draws
+    the next interval with ONE np.random.rand.  Host logic only (tests/test_reinit_schedule.py replays the reference's lines)."""
+
+    def __init__(self, mean_interval):
+        self.mean = float(mean_interval)
+        self.counter = 0.0 if self.mean > 0 else float("inf")
+
+    def due(self, common_step_counter):
+        """`common_step_counter`: the value AFTER this step's increment (the reference tests it in `_update_tasks_callback`, behind
+        `_update_counters_each_step`)."""
+        if common_step_counter >= self.counter:
+            self.counter = common_step_counter + float(-np.log(np.random.rand(1))[0] * self.mean)
+            return True
+        return False
+
+
 def get_class(path):
     mod, name = path.rsplit(".", 1)
     return getattr(importlib.import_module(mod), name)
@@ -143,7 +203,7 @@ class LeggedRobotMotionTracking:
         self._init_obs_buffers()
         self._build_io()
         self.log_dict = {}
-        self.extras = {}
+        self.extras = StepExtras(self)
         self.common_step_counter = 0
         self._resample_motion_times(torch.arange(N, device=dev))
         if config.get("resample_motion_when_training", False):
@@ -151,7 +211,7 @@ class LeggedRobotMotionTracking:
         # domain_rand.reinit_epis_rand > 0: the episodic DR of EVERY env is re-drawn at exponentially distributed intervals
         # (legged_robot_base.py:149-151,390-395)
         self.reinit_epis_rand = float(config.domain_rand.get("reinit_epis_rand", -1))
-        self.reinit_epis_rand_counter = float(-np.log(np.random.rand()) * self.reinit_epis_rand) if self.reinit_epis_rand > 0 else float("inf")
+        self._reinit = ReinitSchedule(self.reinit_epis_rand)
         self.init_done = True
 
     def specialise(self, mode="jit", verbose=False):
@@ -217,8 +277,8 @@ class LeggedRobotMotionTracking:
         self.time_out_buf = torch.zeros(N, dtype=torch.bool, device=dev)
         self.motion_ids = torch.arange(N, device=dev)
         self.rew_buf = f(N, L.num_rew_fn) if self.config.use_vec_reward else f(N)
-        Bx = self.skeleton.num_bodies_ext
-        self.ref_body_pos_extend, self.ref_body_rot_extend = f(N, Bx, 3), f(N, Bx, 4)
+        self._ref_time = f(N)                                # motion time of the last step's reference lookup (lazy reference bodies)
+        self._ref_bodies = None
         self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(D)], device=dev).repeat(N, 1)
         self.raw_default_dof_pos = self.default_dof_pos.clone()                    # legged_robot_base.py:81-93
         self.p_gains = torch.tensor([self._c.p_gains[i] for i in range(D)], device=dev)
@@ -272,7 +332,8 @@ class LeggedRobotMotionTracking:
         io = _lib.PbhcStepIO()
         p = lambda t: t.data_ptr()
         io.root_states, io.dof_state = p(s.robot_root_states), p(s.dof_state)
-        io.rigid_body_state, io.contact_forces = p(s._rigid_body_state), p(s.contact_forces)
+        # the simulator surface's rigid-body state and contact forces: re-derived by the stub on first access (ReplaySimStub.mark_step)
+        io.rigid_body_state, io.contact_forces = None, None
         io.actions, io.last_actions, io.actions_after_delay, io.action_queue = p(self.actions), p(self.last_actions), p(self.actions_after_delay), p(self.action_queue)
         io.last_dof_pos, io.last_dof_vel, io.torques = p(self.last_dof_pos), p(self.last_dof_vel), p(self.torques)
         io.feet_air_time, io.contacts, io.contacts_filt = p(self.feet_air_time), p(self.contacts), p(self.contacts_filt)
@@ -297,12 +358,26 @@ class LeggedRobotMotionTracking:
         io.obs[len(L.group_names) - 1] = p(self._hist)
         io.obs_pitch[len(L.group_names) - 1] = io.hist_pitch = self._hist.stride(0)
         io.rew_buf = p(self.rew_buf)
-        io.ref_body_pos_extend, io.ref_body_rot_extend = p(self.ref_body_pos_extend), p(self.ref_body_rot_extend)
+        io.ref_body_pos_extend, io.ref_body_rot_extend = None, None          # lazy: rebuilt from ref_time_out on first access (StepExtras)
+        io.ref_time_out = p(self._ref_time)
         io.episode_rew_out = p(self._episode_rew_out)
         io.totals_out = self._totals.data_ptr() if getattr(self, "_totals", None) is not None else None
         self._io = io
         self._overrides = {}
         self._replay_version = -1
+
+    def set_eager_outputs(self, on=True):
+        """Have the fused step STORE the optional outputs (rigid-body state, contact forces, reference bodies) instead of leaving them to be
+        re-derived on access: for a consumer that reads them every step (an evaluation callback), and for the test that holds the two forms
+        equal.  `env._eager` holds the four tensors."""
+        N, B, Bx, dev = self.num_envs, self.num_bodies, self.skeleton.num_bodies_ext, self.device
+        if on:
+            self._eager = dict(rigid_body_state=torch.zeros(N, B, 13, device=dev), contact_forces=torch.zeros(N, B, 3, device=dev),
+                               ref_body_pos_extend=torch.zeros(N, Bx, 3, device=dev), ref_body_rot_extend=torch.zeros(N, Bx, 4, device=dev))
+        else:
+            self._eager = None
+        for k in ("rigid_body_state", "contact_forces", "ref_body_pos_extend", "ref_body_rot_extend"):
+            setattr(self._io, k, self._eager[k].data_ptr() if on else None)
 
     def set_obs_outputs(self, tensors):
         """Point the observation outputs of the next step(s) at caller-owned `[N, dim]` tensors (e.g. the rollout-buffer slab of
@@ -384,8 +459,26 @@ class LeggedRobotMotionTracking:
         else:
             self.motion_start_times[env_ids] = self._motion_lib.sample_time(self.motion_ids[env_ids])
 
+    def _reference_bodies(self):
+        """(ref_body_pos_extend [N,Bx,3], ref_body_rot_extend [N,Bx,4]) of the LAST step: the lookup the fused kernel did at `_ref_time`
+        (before a reset), repeated with the stand-alone lookup kernel — cached until the next step"""
+        if self._ref_bodies is None:
+            ref = self._motion_lib.get_motion_state(self.motion_ids, self._ref_time, offset=self.env_origins)
+            self._ref_bodies = (ref["rg_pos_t"], ref["rg_rot_t"])
+        return self._ref_bodies
+
+    @property
+    def ref_body_pos_extend(self):
+        return self._reference_bodies()[0]
+
+    @property
+    def ref_body_rot_extend(self):
+        return self._reference_bodies()[1]
+
     def resample_motion(self, keep_reset_buf=False):
         """motion_tracking.py:385-389 / general_tracking.py:291-297"""
+        if self.common_step_counter > 0:
+            self._reference_bodies()                 # the last step's lazy reference bodies belong to the OLD slot -> clip table: freeze them
         self._motion_lib.load_motions(random_sample=True, max_len=self.max_len)
         self.curr_motion_ids = self._motion_lib.slot_clip
         self._reset_all_state(keep_reset_buf=keep_reset_buf)
@@ -490,6 +583,12 @@ class LeggedRobotMotionTracking:
             io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
             self._replay_version = s.replay_version
         io.frame_index = s.take_host_frame()
+        # _update_tasks_callback's re-draw of every env's episodic DR (legged_robot_base.py:390-395): decided on the host, done by the kernel
+        # in this very step (after its torques, before its observations — where the reference does it)
+        io.redraw_all = int(self._reinit.due(self.common_step_counter + 1))
+        self._ref_bodies = None                      # the lazy members of last step's extras end here
+        self.extras.invalidate()
+        s.mark_step(io.frame_index)                  # the stub's rigid-body state / contact forces of this step: re-derived on first access
         # the previous step's lazy extras["episode"]: gather it now if somebody kept it (its buffers are about to be overwritten)
         prev = self.extras.pop("episode", None)
         if isinstance(prev, EpisodeExtras) and prev._data is None and sys.getrefcount(prev) > 2:
@@ -521,16 +620,11 @@ class LeggedRobotMotionTracking:
         # env.  The reference does it inside the step, before termination and reward of that step; here it follows the fused launch, i.e.
         # it takes effect one control step later — once every resample_time_interval (50 000 - 100 000 steps in the shipped configs).
         # The dones returned for this step stay the kernel's own (the reference's resample_motion does not touch reset_buf).
-        if self.common_step_counter >= self.reinit_epis_rand_counter:             # legged_robot_base.py:390-395 (after the fused launch: from the next step on)
-            self._episodic_domain_randomization_all()
-            self.reinit_epis_rand_counter = self.common_step_counter + float(-np.log(np.random.rand()) * self.reinit_epis_rand)
         if self.config.get("resample_motion_when_training", False) and self.common_step_counter % self.resample_time_interval == 0:
             self.resample_motion(keep_reset_buf=True)
         else:
             self.extras["episode"] = EpisodeExtras(self)
         self.extras["time_outs"] = self.time_out_buf
-        self.extras["ref_body_pos_extend"] = self.ref_body_pos_extend
-        self.extras["ref_body_rot_extend"] = self.ref_body_rot_extend
         self.extras["to_log"] = self.log_dict
         self.extras["episode_rew"] = self._episode_rew_out
         return self.obs_buf_dict, self.rew_buf, self.reset_buf, self.extras

@@ -117,13 +117,11 @@ class ReplaySimStub:
         self.dof_state = torch.zeros(N * D, 2, device=dev)
         self.dof_pos = self.dof_state.view(N, D, 2)[..., 0]
         self.dof_vel = self.dof_state.view(N, D, 2)[..., 1]
-        self.contact_forces = torch.zeros(N, B, 3, device=dev)
-        self._rigid_body_state = torch.zeros(N, B, 13, device=dev)
-        self._rigid_body_pos = self._rigid_body_state[..., 0:3]
-        self._rigid_body_rot = self._rigid_body_state[..., 3:7]
-        self._rigid_body_vel = self._rigid_body_state[..., 7:10]
-        self._rigid_body_ang_vel = self._rigid_body_state[..., 10:13]
-        self._rigid_body_rot[..., 3] = 1.0
+        # rigid-body state and contact forces: LAZY under the fused step (see mark_step) — the storage, and what they are pending on
+        self._cf_buf = torch.zeros(N, B, 3, device=dev)
+        self._rb_buf = torch.zeros(N, B, 13, device=dev)
+        self._rb_buf[..., 6] = 1.0
+        self._pending = None
         self.refresh_sim_tensors()
 
     # ---- replay ----------------------------------------------------------------------------
@@ -165,10 +163,46 @@ class ReplaySimStub:
         self._host_frame = (k + 1) % self.replay_len
         return k
 
+    # ---- rigid-body state / contact forces of the simulator surface (reference names, isaacgym.py:574-618) -----------------------------
+    # Nothing on the training path reads them, so the fused step does not store them (9.4 MB per step at 4096 envs): the env tells the stub
+    # which replay frame the step consumed (mark_step) and the tensors are re-derived on first access — pbhc_sim_fk of that frame, i.e. the
+    # arithmetic the fused kernel ran, and a copy of the frame's contact forces.  Values are those of the frame BEFORE a reset wrote new
+    # root / dof states, as the reference's tensors are until its next refresh.
+    def mark_step(self, frame_index):
+        self._pending = (self.replay, frame_index)
+
+    def _materialise(self):
+        p = self._pending
+        if p is None:
+            return
+        self._pending = None
+        rep, k = p
+        if k < 0:                                    # device-side cursor (the step advanced it): the frame it consumed is the one before
+            k = (int(self.frame_cursor.item()) - 1) % rep["root"].shape[0]
+        _lib.check(_lib.lib().pbhc_sim_fk(C.byref(self._csk), rep["root"][k].data_ptr(), rep["dof_pos"][k].data_ptr(), rep["dof_vel"][k].data_ptr(),
+                                          1, self.num_envs, self._rb_buf.data_ptr(), _lib.current_stream()), "pbhc_sim_fk")
+        self._cf_buf.copy_(rep["contact"][k])
+
+    @property
+    def _rigid_body_state(self):
+        self._materialise()
+        return self._rb_buf
+
+    @property
+    def contact_forces(self):
+        self._materialise()
+        return self._cf_buf
+
+    _rigid_body_pos = property(lambda self: self._rigid_body_state[..., 0:3])
+    _rigid_body_rot = property(lambda self: self._rigid_body_state[..., 3:7])
+    _rigid_body_vel = property(lambda self: self._rigid_body_state[..., 7:10])
+    _rigid_body_ang_vel = property(lambda self: self._rigid_body_state[..., 10:13])
+
     def refresh_sim_tensors(self):
         """Rigid-body pose/twist of the current (root, q, q-dot) via the HIP FK kernel."""
+        self._pending = None
         _lib.check(_lib.lib().pbhc_sim_fk(C.byref(self._csk), self.robot_root_states.data_ptr(), self.dof_pos.data_ptr(),
-                                          self.dof_vel.data_ptr(), 2, self.num_envs, self._rigid_body_state.data_ptr(),
+                                          self.dof_vel.data_ptr(), 2, self.num_envs, self._rb_buf.data_ptr(),
                                           _lib.current_stream()), "pbhc_sim_fk")
 
     def apply_torques_at_dof(self, torques):
@@ -183,7 +217,8 @@ class ReplaySimStub:
         self.robot_root_states.copy_(self.replay["root"][k])
         self.dof_pos.copy_(self.replay["dof_pos"][k])
         self.dof_vel.copy_(self.replay["dof_vel"][k])
-        self.contact_forces.copy_(self.replay["contact"][k])
+        self._pending = None
+        self._cf_buf.copy_(self.replay["contact"][k])
         self.refresh_sim_tensors()
 
     def set_actor_root_state_tensor(self, set_env_ids, root_states):

@@ -371,7 +371,8 @@ def _lib_K():
     return _lib.K
 
 
-def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False, gates=None):
+def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False, gates=None,
+                        redraw_steps=()):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
@@ -426,7 +427,11 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
             samp["dof_pos_bias"] = 0.1 * (torch.rand(N, 23, generator=gen) - 0.5)
         frame = dict(root=root[k + 1], dof_pos=qp[k + 1], dof_vel=qv[k + 1], contact=cf[k + 1])
         body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
-        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp, gate_u=gates[k] if gates else None)
+        redraw = k in redraw_steps
+        o_obs, o_rew, o_reset, o_ex = orc.step(act, frame, body, u_rfi=u, reset_samples=samp, gate_u=gates[k] if gates else None,
+                                               redraw_samples=samp if redraw else None)
+        if redraw:                                       # reinit_epis_rand fires in THIS step (the schedule itself: tests/test_reinit_schedule.py)
+            env._reinit.mean, env._reinit.counter = 1e12, float(env.common_step_counter + 1)
         env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
                                rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]),
                                dof_pos_bias=tg(samp["dof_pos_bias"]) if default_bias else None,
@@ -442,6 +447,13 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         close(env.torques, orc.s["torques"], 3e-5, w + "torques", rtol=1e-5)
         for name, view in env.history.items():
             close(view, orc.hist[name], 3e-5, w + "hist " + name)
+        if redraw_steps:                                 # the episodic DR state of EVERY env after a re-draw (and of the reset ones otherwise)
+            for a_, b_ in ((env._kp_scale, "kp_scale"), (env._kd_scale, "kd_scale"), (env._rfi_lim_scale, "rfi_lim_scale"), (env._rao_scale, "rao_scale")):
+                close(a_, orc.s[b_], 1e-7, w + b_)
+            assert torch.equal(env.action_delay_idx.cpu(), orc.s["action_delay_idx"]), w + "action_delay_idx"
+            close(env.action_queue, orc.s["action_queue"], 1e-7, w + "action_queue")
+            if redraw:
+                assert float((orc.s["kp_scale"] - samp["kp_scale"]).abs().max()) == 0.0 and float(orc.s["action_queue"].abs().max()) == 0.0
         if gates:
             log = env.read_log()
             cause = ("dof_pos_limit", "dof_vel_limit", "torque_limit")[k] if k < 3 else None
@@ -474,6 +486,41 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         assert ep["end_epis_length"].shape[0] == len(ids)
         for name, v in want.items():
             close(ep[name].float(), v.float(), 3e-5, f"step {k}: extras episode {name}", rtol=2e-4)
+
+
+def test_reinit_epis_rand_redraws_every_env_inside_the_step():
+    """domain_rand.reinit_epis_rand (legged_robot_base.py:390-395 -> :599-635): in the step where the schedule fires, the gain / torque-noise
+    scales, the control delay and the action queue of EVERY env are re-drawn after that step's torques and before its observations (the
+    privileged dr_kp / dr_kd / dr_ctrl_delay observations of the same step show the new values; the next step's torques use them)."""
+    _env_step_vs_oracle(64, 4, redraw_steps=(1, 2))
+
+
+def test_lazy_simulator_surface_and_reference_bodies_equal_the_stored_ones():
+    """The fused step stores neither the simulator surface's rigid-body state / contact forces nor extras['ref_body_*_extend'] unless asked
+    (PbhcStepIO: NULL); read afterwards they are re-derived from the replay frame / the step's reference time.  Both forms of the same
+    step: the kernel's own stores (set_eager_outputs) against the lazy tensors — bit for bit where both sides run the same un-fused
+    arithmetic (reference lerp / slerp, contact copy), to 2e-6 for the rigid-body chain, whose fused multiply-adds (pbhc_math.h, fk_*) the
+    compiler may pair differently in the stand-alone FK kernel and in the step kernel."""
+    cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 96)
+    obs = env.reset_all()
+    import bench
+
+    env.simulator.set_replay(*bench.make_replay_on_device(env, 8, 3))
+    env.set_eager_outputs(True)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for k in range(5):
+        if k == 2:
+            env.episode_length_buf[::5] = 10 ** 6          # resets: the surface keeps the PRE-reset frame, the reference bodies the pre-reset time
+        obs, rew, reset, extras = env.step({"actions": 0.3 * torch.randn(96, env.num_dof, device=DEV, generator=gen)})
+        torch.cuda.synchronize()
+        e = env._eager
+        close(env.simulator._rigid_body_state, e["rigid_body_state"], 2e-6, f"step {k} lazy rigid-body state", rtol=2e-6)
+        assert torch.equal(env.simulator.contact_forces, e["contact_forces"]), k
+        assert torch.equal(extras["ref_body_pos_extend"], e["ref_body_pos_extend"]), k
+        assert torch.equal(extras["ref_body_rot_extend"], e["ref_body_rot_extend"]), k
+        close(env.simulator._rigid_body_pos, e["rigid_body_state"][..., 0:3], 2e-6, f"step {k} lazy rigid-body pos", rtol=2e-6)
+        if k == 2:
+            assert int(reset.sum()) >= 19
 
 
 def test_gae_matches_reference_storage():

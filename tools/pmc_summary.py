@@ -4,7 +4,7 @@ that bench.py reports `roofline.traffic` only for the code that was actually pro
   cd /tmp && export TMPDIR=/tmp      # on the GPU box, separate passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/kernel_probe.py 4096
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/kernel_probe.py 4096
-  python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round2_k_env_step_pmc.json
+  python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round3_k_env_step_pmc.json
 """
 import csv
 import glob
@@ -15,7 +15,7 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["pbhc_amd/csrc/pbhc_kernels.hip", "pbhc_amd/csrc/pbhc_math.h", "include/pbhc_hip.h"]
+SOURCES = ["pbhc_amd/csrc/pbhc_kernels.hip", "pbhc_amd/csrc/pbhc_env_step.h", "pbhc_amd/csrc/pbhc_env_step_spec.hip", "pbhc_amd/csrc/pbhc_math.h", "include/pbhc_hip.h"]
 
 
 def _code_only(text):
