@@ -484,6 +484,16 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
+constexpr bool cfg_has_term(const PbhcEnvConfig& c, int id) {
+  for (int i = 0; i < c.num_terms; ++i)
+    if (c.term_id[i] == id) return true;
+  return false;
+}
+__device__ __forceinline__ bool is_special_term(int id) {     // the reward terms k_env_step evaluates by formula (the others: one slot of the reduction row)
+  return id == PBHC_R_TELEOP_CONTACT_MASK || id == PBHC_R_TELEOP_CONTACT_MASK_V2 || id == PBHC_R_TELEOP_BODY_POSITION_EXTEND || id == PBHC_R_PENALTY_ORIENTATION ||
+         id == PBHC_R_FEET_AIR_TIME || id == PBHC_R_PENALTY_FEET_CONTACT_FORCES || id == PBHC_R_PENALTY_STUMBLE || id == PBHC_R_PENALTY_SLIPPAGE ||
+         id == PBHC_R_FOOT_SLIP_PENALTY || id == PBHC_R_ALIVE;
+}
 constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
   for (int g = 0; g < c.num_groups; ++g)
     if (c.groups[g].num_runs < 0) return false;
@@ -528,14 +538,15 @@ __device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t str
     if ((WHICH == 1 && R.late) || (WHICH == 2 && !R.late)) continue;
 #pragma unroll
     for (int i0 = 0; i0 < R.len; i0 += PBHC_G) {
-      const int i = i0 + lane;
-      if (i < R.len) {
-        float x = feat[R.src + i];
-        if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)(R.dst + i)) * 2.0f - 1.0f) * (R.noise * noise_cur);
-        x = x * R.scale;
-        if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
-        at(outg, ob + (unsigned int)(R.dst + i)) = x;
-      }
+      // lanes past the run's end repeat its last element (the same value to the same address): no exec-mask region per partial
+      // iteration, so the whole row is ONE basic block and the LDS reads of many iterations are in flight together (with a branch per
+      // run tail every iteration waited out its own LDS round trip: ~100 cycles each)
+      const int i = min(i0 + lane, R.len - 1);
+      float x = feat[R.src + i];
+      if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)(R.dst + i)) * 2.0f - 1.0f) * (R.noise * noise_cur);
+      x = x * R.scale;
+      if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
+      at(outg, ob + (unsigned int)(R.dst + i)) = x;
     }
   }
 }
@@ -629,6 +640,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   float pf_last_act = 0.0f, pf_last_qd = 0.0f;
   float tref = 0.0f;
   float qold[PBHC_MAX_QUEUE];
+  float hreg[PBHC_HREG];                                      // role B: the env's history row, requested before bar1, copied to LDS after it
   // Philox quads computed ahead of their use, while the wave waits for its loads: the first quad of every group's noise list (both roles;
   // role A needs role B's rows too after a reset), and role A's reset draws
   uint32_t nzb[4];
@@ -714,13 +726,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       rd0 = r0[dc]; rd1 = r1[dc]; rdv0 = r0[D + dc]; rdv1 = r1[D + dc];
       rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
-    float hreg[PBHC_HREG];
-    {
-      const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
-      const int hlast = c.hist_dim - 1;
-#pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
-    }
     float creg[128 / PBHC_G];
     {
       const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
@@ -802,12 +807,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       }
     }
     STAMPB(2);
-    // ---- the history row -> feature row (its loads were issued behind the reference rows; they have long landed)
-    if (valid) {
+    // ---- the history row (40 % of this role's loaded bytes, read by nobody before bar2) is REQUESTED here, behind the loads that bar1 waits
+    // for — issued with them it sat in the same in-order queue and the burst of all workgroups' prologues landed ~2 k cycles later —
+    // and copied to the feature row after bar1
+    {
+      const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
+      const int hlast = c.hist_dim - 1;
 #pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
-      if (c.hist_dim > PBHC_HREG * PBHC_G)
-        copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
+      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
     }
     // per-dof constants of the config: one batch of loads at the head of the interval
     k_tl = c.torque_limits[dc]; k_dp = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
@@ -1025,15 +1032,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f || tcontact != 0.0f || tlowh != 0.0f) ? 1.0f : 0.0f;
     }
     WAVE_LDS_FENCE();
-    // a terminated env's history is zero in the observations of this very step (history_handler.py:33-38 via reset_envs_idx): zeroed
-    // here, before bar2, so that both roles' observation passes of interval 2b see it
-    if (valid && misc[M_RESET] != 0.0f)
-      for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
     philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar2 next
     STAMP(4);
   } else {
     // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the
     // post-reset features of a NON-terminated env (what phase H of role A computes after a reset), the observation maps -> LDS ========
+    if (valid) {                                                 // the history row -> feature row
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
+      if (c.hist_dim > PBHC_HREG * PBHC_G)
+        copy_g2l(feat + hoff + PBHC_HREG * PBHC_G, io.hist + (size_t)env * (io.hist_pitch ? io.hist_pitch : c.hist_dim) + PBHC_HREG * PBHC_G, c.hist_dim - PBHC_HREG * PBHC_G, lane);
+    }
     uint32_t mreg[PBHC_MAPREG];
     if (map_words > 0) {
       const int wl = threadIdx.x & (2 * PBHC_G * 2 - 1);            // 0..127 over the two role-B waves
@@ -1108,8 +1117,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       g_tau = (ug[2] < c.term_close_prob[2]) ? group_max(g_tau) : 0.0f;
       gateB = valid && (g_pos != 0.0f || g_vel != 0.0f || g_tau != 0.0f);
       if (valid && lane == 0) { misc[M_TPOSLIM] = g_pos; misc[M_TVELLIM] = g_vel; misc[M_TTAULIM] = g_tau; misc[M_TGATE] = gateB ? 1.0f : 0.0f; }
-      if (gateB)                                            // this env terminates: its history is zero in this step's observations (as role A does for its causes)
-        for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
     }
     if (valid && lane == 0) {
       red[R_MAXJP] = s_maxjp; red[R_JP2] = s_jp2; red[R_JPM] = s_jp2 / (float)D; red[R_JVM] = s_jv2 / (float)D; red[R_TAU2] = s_tau2; red[R_ARATE] = s_ar; red[R_QD2] = s_qd2;
@@ -1145,6 +1152,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   STAMP(5);
   if (close_any && !roleB) {                                   // role A: role B's causes join the reset flag (every later reader of M_RESET in this wave follows)
     if (valid && lane == 0 && misc[M_TGATE] != 0.0f) misc[M_RESET] = 1.0f;
+    WAVE_LDS_FENCE();
+  }
+  // a terminated env's history is zero in the observations of this very step (history_handler.py:33-38 via reset_envs_idx).  The copy of
+  // the history row into the feature row is role B's, between bar1 and bar2; each role zeroes it for itself here, ahead of its own
+  // observation passes (both store zeros: no order between the two is needed)
+  if (valid && (misc[M_RESET] != 0.0f || (roleB && gateB))) {
+    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
     WAVE_LDS_FENCE();
   }
 
@@ -1221,55 +1235,87 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     if (valid) {
       const float pen_scale = pf_pen_scale;
       float myrew = 0.0f;
-      if (lane < c.num_terms) {
-        float raw = 0.0f;
+      {
+        // Most terms are one value of the reduction row: `term_src` (filled by pbhc_env_create, see term_source()) is its LDS slot.  The
+        // terms that combine several values are evaluated STRAIGHT-LINE for the whole wave — operands fetched up front by broadcast LDS
+        // reads (one round trip), every value computed by every lane, each lane keeping the one its term id names — instead of a switch per
+        // lane, whose cases ran one after the other, each behind its own LDS reads (1.7 k cycles of the chain).  The specialised build drops
+        // the terms its config does not have (TERM folds to a literal there).
+#ifdef PBHC_STATIC_CFG
+#define TERM(name) cfg_has_term(kStaticCfg, PBHC_R_##name)
+#else
+#define TERM(name) true
+#endif
         const int id = pf_tid;
         const float* ex = red + R_EXP0;
         const float* ft = red + R_FOOT0;
-        // Most terms are one value of the reduction row: `term_src` (filled by pbhc_env_create, see term_source()) is its LDS slot.
-        // Only the terms that combine several values keep a case.
-        if (pf_tsrc >= 0) raw = red[pf_tsrc];
-        else switch (id) {
-          case PBHC_R_TELEOP_CONTACT_MASK: {
-            float e = 0.0f;
-            for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
-            raw = 1.0f - e / (float)NF;
-          } break;
-          case PBHC_R_TELEOP_CONTACT_MASK_V2: {
-            float e = 0.0f;
-            for (int f = 0; f < NF; ++f) e += fabsf(misc[M_CFILT0 + f] - misc[M_RCONTACT0 + f]);
-            raw = 0.5f - e / (float)NF;
-          } break;
-          case PBHC_R_TELEOP_BODY_POSITION_EXTEND: raw = ex[PBHC_S_LOWER_BODY_POS] * c.body_pos_lower_weight + ex[PBHC_S_UPPER_BODY_POS] * c.body_pos_upper_weight; break;
-          case PBHC_R_PENALTY_ORIENTATION: raw = misc[M_GX] * misc[M_GX] + misc[M_GY] * misc[M_GY]; break;
-          case PBHC_R_FEET_AIR_TIME: {   // stateful (motion_tracking.py:1307-1319)
-            for (int f = 0; f < NF; ++f) {
-              bool contact = ft[4 * f + 2] > 1.0f;
-              bool cfilt = contact || (misc[M_LASTC0 + f] != 0.0f);
-              float fat = misc[M_FAT0 + f];
-              float first = (fat > 0.0f && cfilt) ? 1.0f : 0.0f;
-              fat = fat + dt;
-              raw += (fat - c.desired_feet_air_time) * first;
-              misc[M_FAT0 + f] = cfilt ? fat * 0.0f : fat;
-            }
-          } break;
-          case PBHC_R_PENALTY_FEET_CONTACT_FORCES:
-            for (int f = 0; f < NF; ++f) raw += fmaxf(ft[4 * f] - c.max_contact_force, 0.0f);
-            break;
-          case PBHC_R_PENALTY_STUMBLE:
-            for (int f = 0; f < NF; ++f)
-              if (ft[4 * f + 1] > 5.0f * fabsf(ft[4 * f + 2])) raw = 1.0f;
-            break;
-          case PBHC_R_PENALTY_SLIPPAGE:
-            for (int f = 0; f < NF; ++f) raw += ft[4 * f + 3] * (ft[4 * f] > 1.0f ? 1.0f : 0.0f);
-            break;
-          case PBHC_R_FOOT_SLIP_PENALTY:
-            for (int f = 0; f < NF; ++f) raw += (ft[4 * f] > 1.0f ? 1.0f : 0.0f) * ft[8 + f];
-            break;
-          case PBHC_R_ALIVE: raw = 1.0f; break;
-          default: raw = 0.0f;
+        float raw = red[max(pf_tsrc, 0)];
+        float cfl[PBHC_MAX_FEET], rcn[PBHC_MAX_FEET], lsc[PBHC_MAX_FEET], fat[PBHC_MAX_FEET];
+        float fF[PBHC_MAX_FEET], fXY[PBHC_MAX_FEET], fZ[PBHC_MAX_FEET], fV[PBHC_MAX_FEET], fVxy[PBHC_MAX_FEET];
+#pragma unroll
+        for (int f = 0; f < PBHC_MAX_FEET; ++f) {
+          const int g = min(f, NF - 1);
+          cfl[f] = misc[M_CFILT0 + g]; rcn[f] = misc[M_RCONTACT0 + g]; lsc[f] = misc[M_LASTC0 + g]; fat[f] = misc[M_FAT0 + g];
+          fF[f] = ft[4 * g]; fXY[f] = ft[4 * g + 1]; fZ[f] = ft[4 * g + 2]; fV[f] = ft[4 * g + 3]; fVxy[f] = ft[8 + g];
         }
-        myrew = raw * pf_tscale;
+        const float gx = misc[M_GX], gy = misc[M_GY], exl = ex[PBHC_S_LOWER_BODY_POS], exu = ex[PBHC_S_UPPER_BODY_POS];
+        if (TERM(TELEOP_CONTACT_MASK) || TERM(TELEOP_CONTACT_MASK_V2)) {
+          float e = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF) e += fabsf(cfl[f] - rcn[f]);
+          const float q = e / (float)NF;
+          raw = id == PBHC_R_TELEOP_CONTACT_MASK ? 1.0f - q : (id == PBHC_R_TELEOP_CONTACT_MASK_V2 ? 0.5f - q : raw);
+        }
+        if (TERM(TELEOP_BODY_POSITION_EXTEND)) {
+          const float v = exl * c.body_pos_lower_weight + exu * c.body_pos_upper_weight;
+          raw = id == PBHC_R_TELEOP_BODY_POSITION_EXTEND ? v : raw;
+        }
+        if (TERM(PENALTY_ORIENTATION)) raw = id == PBHC_R_PENALTY_ORIENTATION ? gx * gx + gy * gy : raw;
+        if (TERM(FEET_AIR_TIME)) {                               // stateful (motion_tracking.py:1307-1319): the air times advance only where the term is configured
+          float v = 0.0f, nf[PBHC_MAX_FEET];
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) {
+            const bool cfilt = fZ[f] > 1.0f || lsc[f] != 0.0f;
+            const float first = (fat[f] > 0.0f && cfilt) ? 1.0f : 0.0f;
+            const float t = fat[f] + dt;
+            if (f < NF) v += (t - c.desired_feet_air_time) * first;
+            nf[f] = cfilt ? t * 0.0f : t;
+          }
+          const bool mine = id == PBHC_R_FEET_AIR_TIME && lane < c.num_terms;
+          if (mine) {
+#pragma unroll
+            for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF) misc[M_FAT0 + f] = nf[f];
+          }
+          raw = id == PBHC_R_FEET_AIR_TIME ? v : raw;
+        }
+        if (TERM(PENALTY_FEET_CONTACT_FORCES)) {
+          float v = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF) v += fmaxf(fF[f] - c.max_contact_force, 0.0f);
+          raw = id == PBHC_R_PENALTY_FEET_CONTACT_FORCES ? v : raw;
+        }
+        if (TERM(PENALTY_STUMBLE)) {
+          float v = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF && fXY[f] > 5.0f * fabsf(fZ[f])) v = 1.0f;
+          raw = id == PBHC_R_PENALTY_STUMBLE ? v : raw;
+        }
+        if (TERM(PENALTY_SLIPPAGE)) {
+          float v = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF) v += fV[f] * (fF[f] > 1.0f ? 1.0f : 0.0f);
+          raw = id == PBHC_R_PENALTY_SLIPPAGE ? v : raw;
+        }
+        if (TERM(FOOT_SLIP_PENALTY)) {
+          float v = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f) if (f < NF) v += (fF[f] > 1.0f ? 1.0f : 0.0f) * fVxy[f];
+          raw = id == PBHC_R_FOOT_SLIP_PENALTY ? v : raw;
+        }
+        if (TERM(ALIVE)) raw = id == PBHC_R_ALIVE ? 1.0f : raw;
+#undef TERM
+        if (pf_tsrc < 0 && !is_special_term(id)) raw = 0.0f;     // (an id with neither a slot nor a formula: 0, as before)
+        myrew = lane < c.num_terms ? raw * pf_tscale : 0.0f;
         if (pf_tpen) myrew = myrew * pen_scale;
       }
       STAMP(26);
