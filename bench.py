@@ -352,12 +352,37 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
         if dp:
             out["collectives"] = {"backend": backend, "all_reduces_per_iter": coll["all_reduce"] / K, "all_reduce_bytes_per_iter": coll["all_reduce_bytes"] / K,
                                   "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": 4 * n_grad,
-                                  "note": "per PPO iteration and rank: 2 gradient-segment all-reduces + 1 KL scalar per optimiser step (20), 1 advantage-moment "
-                                          "exchange, 1 x 512-byte env-statistics exchange per control step (24); grad_allreduce_ms = one stand-alone all-reduce "
-                                          "of the whole gradient bucket, max over ranks"}
+                                  "note": "per PPO iteration and rank: 1 averaged all-reduce of the actor + critic gradient bucket per optimiser step (20; the "
+                                          "minibatch KL mean rides in its last slot), 1 advantage-moment exchange, 1 exchange of the env statistics (1 KB) per "
+                                          "rollout; grad_allreduce_ms = one stand-alone all-reduce of the whole gradient bucket, max over ranks"}
     del algo, env
     torch.cuda.empty_cache()
     return out
+
+
+def dp1_rehearsal(a, device, primary_ms):
+    """What the data-parallel code path costs before any wire time: the SAME workload once more in this process under a ONE-rank RCCL
+    process group (PBHC_DIST_FORCE: broadcast of the weights, the averaged gradient-bucket all-reduce per optimiser step, the advantage-
+    moment and env-statistics exchanges, all next to the rollout's hipGraph replays with a live communicator) for 5 iterations."""
+    import socket
+
+    os.environ["PBHC_DIST_FORCE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+    dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    try:
+        r = measure(a.workload, a.clips, a.envs, 5, 2, 0, 1, True, device, "nccl", primary=False)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("PBHC_DIST_FORCE", None)
+    c = r["collectives"]
+    return {"ms_per_step": r["ms_per_step"], "overhead_ms_per_iteration": r["ms_per_step"] - primary_ms, "rollout_ms": r["rollout_ms"], "update_ms": r["update_ms"],
+            "steps": 5, "warmup": 2, "backend": "nccl", "ranks": 1, "all_reduces_per_iter": c["all_reduces_per_iter"],
+            "all_reduce_bytes_per_iter": c["all_reduce_bytes_per_iter"], "grad_allreduce_ms": c["grad_allreduce_ms"], "grad_bucket_bytes": c["grad_bucket_bytes"],
+            "note": "one-rank RCCL group in the same process: the exchanges' launch / ordering cost without wire time (round 2: 65 all-reduces, +2.9 ms)"}
 
 
 def main():
@@ -368,6 +393,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (general tracking, 256 clips) measurement appended to the default run")
+    ap.add_argument("--no-dp-rehearsal", action="store_true", help="skip the one-rank RCCL rehearsal of the data-parallel path appended to the default run")
     ap.add_argument("--workload", default="v1_walk", choices=sorted(WORKLOADS.keys()))
     ap.add_argument("--clips", type=int, default=1, help="synthetic motion library of this many clips (general-tracking workloads)")
     a = ap.parse_args()
@@ -408,6 +434,8 @@ def main():
             sec = measure("v2_teacher29", 256, a.envs, 3, 2, rank, world, False, device, backend, primary=False)
             out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "rollout_ms", "update_ms", "roofline", "roofline_update", "config")}
             out["secondary"]["note"] = "BASELINE.json configs[2] (4096 envs, G1 29-DoF, mixed motion library with per-env phase sampling): not the judged metric"
+        if world == 1 and not dp and a.workload == "v1_walk" and not a.no_dp_rehearsal:
+            out["dp1_rehearsal"] = dp1_rehearsal(a, device, out["ms_per_step"])
         if world == 1 and not a.no_cpu_baseline and a.workload == "v1_walk":
             out["cpu_baseline"] = cpu_baseline(num_envs_sample=a.envs)
         print(json.dumps(out), flush=True)

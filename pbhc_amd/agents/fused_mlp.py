@@ -46,6 +46,14 @@ def grad_direct(seq, on=True):
     if not hasattr(seq, "_fused_live"):
         seq._fused_live = weakref.WeakSet()
         seq._fused_shared = False
+        seq._zero_epoch, seq._stored_epoch = 0, -1
+
+
+def grads_zeroed(seq):
+    """The owner has just zeroed the gradient buffer behind `seq`'s `.grad`s: the NEXT backward through the stack may store (overwrite);
+    any further backward before the next zeroing accumulates through autograd — two sequential backward() calls between two zeroings
+    (an auxiliary loss, gradient accumulation) therefore add up, as they do for any other module."""
+    seq._zero_epoch = getattr(seq, "_zero_epoch", 0) + 1
 
 
 def supported(module_seq):
@@ -158,7 +166,9 @@ class _FusedMLP(torch.autograd.Function):
         if ctx.live is not None:
             if len(seq._fused_live) > 1:
                 seq._fused_shared = True
-            may_direct = not seq._fused_shared
+            may_direct = not seq._fused_shared and seq._stored_epoch != seq._zero_epoch      # the first backward since the owner's zeroing
+            if may_direct:
+                seq._stored_epoch = seq._zero_epoch
         offs = []
         for l in lin:
             offs.append(off)
@@ -167,7 +177,8 @@ class _FusedMLP(torch.autograd.Function):
         for i in reversed(range(L)):
             l = lin[i]
             n = l.out_features
-            direct = may_direct and l.weight.grad is not None and l.weight.grad.is_contiguous() and l.bias.grad is not None and l.bias.grad.is_contiguous()
+            direct = (may_direct and l.weight.requires_grad and l.bias.requires_grad and l.weight.grad is not None and l.weight.grad.is_contiguous()
+                      and l.bias.grad is not None and l.bias.grad.is_contiguous())
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
             part = scratch[offs[i]:offs[i] + MAXB * n]
             k_in = l.in_features

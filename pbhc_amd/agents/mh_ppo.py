@@ -198,8 +198,11 @@ class MHPPO:
         self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
         self.world_size, self.rank = pdist.world(), pdist.rank()
         self._dp = pdist.active()                    # data-parallel exchanges on (more than one rank, or a forced one-rank rehearsal)
-        if self._dp and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
-            self.env.enable_global_statistics()          # sigma / episode-length curricula from the batch of all ranks' envs
+        self._dp_buckets = int(os.environ.get("PBHC_DP_GRAD_BUCKETS", "1"))
+        # algo.config.sync_env_statistics: "rollout" (default; True means the same) | "step" (exact single-process equivalence) | False
+        self._stat_mode = {True: "rollout", False: None, None: None}.get(config.get("sync_env_statistics", "rollout"), config.get("sync_env_statistics", "rollout"))
+        if self._dp and self._stat_mode and hasattr(self.env, "enable_global_statistics"):
+            self.env.enable_global_statistics(mode=self._stat_mode)     # sigma / episode-length curricula from the batch of all ranks' envs
         _ = self.env.reset_all()
 
     def _init_config(self):
@@ -290,9 +293,19 @@ class MHPPO:
         from . import fused_mlp
         from .modules import BaseModule
 
+        self._direct_stacks = []
         for m in list(self.actor.modules()) + list(self.critic.modules()):
             if isinstance(m, BaseModule):
                 fused_mlp.grad_direct(m.module)
+                self._direct_stacks.append(m.module)
+
+    def _zero_grads(self):
+        """zero the flat gradient buffer and tell the declared stacks (their next backward may store instead of accumulate)"""
+        from . import fused_mlp
+
+        self._gflat.zero_()
+        for q in self._direct_stacks:
+            fused_mlp.grads_zeroed(q)
 
     def _setup_storage(self):
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
@@ -505,6 +518,8 @@ class MHPPO:
                 st.values.copy_(vals[:T])
                 st.rewards.addcmul_(st.values, self._time_outs.to(torch.float32), value=float(self.gamma))
             st.step = T
+            if self._dp and self._stat_mode == "rollout":
+                env.sync_globals()                     # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()
             self._compute_returns(self._last_obs, last_values=vals[T] if batched else None)
         return self._last_obs
@@ -576,7 +591,7 @@ class MHPPO:
         B = mu.shape[0]
         if B != self._mb:
             raise _lib.PbhcError("minibatch size changed")
-        self._gflat.zero_()
+        self._zero_grads()
         so, sn = self._std_slice
         adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
         on_device_lr = adapt if not self._dp else 0
@@ -589,16 +604,22 @@ class MHPPO:
                                      self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
         na, nc = self._n_actor, self._n_critic
         if self._dp:
-            # The critic's gradient segment (3.8 MB: the larger one) is all-reduced while the ACTOR's backward runs; only the actor's 1.45 MB
-            # exchange is left exposed before the optimiser step.  The minibatch KL mean sits in the slot behind the critic's segment: one
-            # collective carries both (the adaptive learning-rate rule, mh_ppo.py:455-466, needs the mean over ALL ranks' samples).
+            # ONE all-reduce per optimiser step (north_star: "a single RCCL all-reduce of policy gradients per PPO update"): actor + critic
+            # segments and, in the slot behind them, the minibatch KL mean (the adaptive learning-rate rule, mh_ppo.py:455-466, needs the
+            # mean over ALL ranks' samples) — averaged by the collective itself (ReduceOp.AVG), 5.2 MB, latency-bound on xGMI.
+            # PBHC_DP_GRAD_BUCKETS=2: the round-2 form — the critic's 3.8 MB exchanged while the actor's backward runs, the actor's 1.45 MB
+            # exposed — one more collective launch per step for ~25 us of hidden wire time; bench.py's dp1_rehearsal is the meter.
             self._gflat[na + nc:na + nc + 1].copy_(self._loss_scalars[3:4])
-            torch.autograd.backward([value], [self._grad_value])
-            h_c = pdist.all_reduce(self._gflat[na:na + nc + 1], async_op=True)
-            torch.autograd.backward([mu], [self._grad_mu])
-            h_a = pdist.all_reduce(self._gflat[:na], async_op=True)
-            h_a.wait(); h_c.wait()
-            self._gflat.div_(self.world_size)
+            if self._dp_buckets == 2:
+                torch.autograd.backward([value], [self._grad_value])
+                h_c = pdist.all_reduce(self._gflat[na:na + nc + 1], async_op=True)
+                torch.autograd.backward([mu], [self._grad_mu])
+                h_a = pdist.all_reduce(self._gflat[:na], async_op=True)
+                h_a.wait(); h_c.wait()
+                self._gflat.div_(self.world_size)
+            else:
+                torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+                pdist.allreduce_mean_(self._gflat[:na + nc + 1])
             if adapt:
                 pdist.kl_lr_rule_(self._lr, self._gflat[na + nc], self.desired_kl, reduced=True)
         else:
@@ -653,7 +674,7 @@ class MHPPO:
             l2c2_p = self.cfg_l2c2.lambda_policy * (b["actions"] - u_mu).pow(2).mean()
         actor_loss = surrogate - self.entropy_coef * entropy_loss + l2c2_p
         critic_loss = self.value_loss_coef * value_loss + l2c2_v
-        self._gflat.zero_()
+        self._zero_grads()
         actor_loss.backward()
         critic_loss.backward()
         if self._dp:

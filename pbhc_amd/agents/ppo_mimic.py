@@ -104,8 +104,10 @@ class PPO:
         self._ep_stats = torch.zeros(3, dtype=torch.float64, device=self.device)
         self.world_size, self.rank = pdist.world(), pdist.rank()
         self._dp = pdist.active()                    # data-parallel exchanges on (more than one rank, or a forced one-rank rehearsal)
-        if self._dp and config.get("sync_env_statistics", True) and hasattr(self.env, "enable_global_statistics"):
-            self.env.enable_global_statistics()          # sigma / episode-length curricula from the batch of all ranks' envs
+        # algo.config.sync_env_statistics: "rollout" (default; True means the same) | "step" (exact single-process equivalence) | False
+        self._stat_mode = {True: "rollout", False: None, None: None}.get(config.get("sync_env_statistics", "rollout"), config.get("sync_env_statistics", "rollout"))
+        if self._dp and self._stat_mode and hasattr(self.env, "enable_global_statistics"):
+            self.env.enable_global_statistics(mode=self._stat_mode)     # sigma / episode-length curricula from the batch of all ranks' envs
         _ = self.env.reset_all()
         self.learn = self.learn_RL if not self.train_distill else self.learn_distill
 
@@ -243,9 +245,22 @@ class PPO:
         from . import fused_mlp
         from .modules import BaseModule
 
+        self._direct_stacks = {"main": [], "hist": []}
+        lo = self._gflat.data_ptr()
         for m in self.alg.modules():
             if isinstance(m, BaseModule):
                 fused_mlp.grad_direct(m.module)
+                off = (next(m.module.parameters()).grad.data_ptr() - lo) // 4
+                self._direct_stacks["main" if off < self._n_main else "hist"].append(m.module)
+
+    def _zero_grads(self, which):
+        """zero one segment of the flat gradient buffer ("main": everything but the history encoder, "hist": the history encoder) and tell
+        the declared stacks living in it that their next backward may store instead of accumulate"""
+        from . import fused_mlp
+
+        (self._gflat[: self._n_main] if which == "main" else self._gflat[self._n_main:]).zero_()
+        for q in self._direct_stacks[which]:
+            fused_mlp.grads_zeroed(q)
 
     def _setup_storage(self):
         st = self.storage = RolloutStorage(self.env.num_envs, self.num_steps_per_env, self.device)
@@ -377,6 +392,8 @@ class PPO:
                                                  0.0, st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
                                                  self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
             st.step = T
+            if self._dp and self._stat_mode == "rollout":
+                self.env.sync_globals()                # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()
         return self._last_obs
 
@@ -395,7 +412,7 @@ class PPO:
     def _update_distill(self, b, loss):
         mu = self.alg.act_inference(b, hist_encoding=True)
         bc = (b["teacher_actions"] - mu).norm(p=2, dim=1).mean()
-        self._gflat[: self._n_main].zero_()
+        self._zero_grads("main")
         bc.backward()
         if self._dp:
             pdist.allreduce_mean_(self._gflat[: self._n_main])
@@ -462,6 +479,8 @@ class PPO:
                 cur.wait_stream(br)
                 env.set_finalize_stream(None)
             st.step = T
+            if self._dp and self._stat_mode == "rollout":
+                self.env.sync_globals()                # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()
             self._compute_returns(self._last_obs)
         return self._last_obs
@@ -530,7 +549,7 @@ class PPO:
         if B != self._mb:
             raise _lib.PbhcError("minibatch size changed")
         sigma = alg.sigma().detach().contiguous()
-        self._gflat[: self._n_main].zero_()
+        self._zero_grads("main")
         adapt = int(self.desired_kl is not None and self.schedule == "adaptive")
         flags = (adapt if not self._dp else 0) | 2                      # bit 1: the ppo_mimic KL form
         st = _lib.current_stream()
@@ -566,7 +585,7 @@ class PPO:
         with torch.no_grad():
             priv_latent = a.priv_encoding(b["priv_obs"])
         hist_loss = (priv_latent - a.history_encoding(b["prop_history"])).norm(p=2, dim=1).mean()
-        self._gflat[self._n_main:].zero_()
+        self._zero_grads("hist")
         hist_loss.backward()
         if self._dp:
             pdist.allreduce_mean_(self._gflat[self._n_main:])

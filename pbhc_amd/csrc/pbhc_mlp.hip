@@ -19,6 +19,7 @@
 // Tried and not kept: requesting a layer's first ring stages before the previous layer's epilogue and barrier (a by-value register ring carried
 // across the tile runs): 37.7 -> 42.8 us — the conditional use of the carried ring makes the first round of every run drain the load queue.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -282,10 +283,16 @@ static int mlp_launch(const float* x, int ldx, const float* const* weights, cons
   if (a.pitch1 == 0) a.pitch1 = 4;
   const size_t lds = (size_t)MLP_ROWS * (size_t)(a.pitch0 + a.pitch1) * sizeof(float);
   MLP_ARG(lds <= 160 * 1024);
-  static size_t lds_allowed = 64 * 1024;                   // raised once per process on the first wide stack (the first rollout runs outside any capture)
-  if (lds > lds_allowed) {
-    MLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    lds_allowed = 160 * 1024;
+  if (lds > 64 * 1024) {
+    // the attribute is per DEVICE: raised once on each device that runs a wide stack (the first rollout runs outside any capture)
+    static std::atomic<unsigned long long> raised{0};       // bit d: device d has it
+    int dev = 0;
+    MLP_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+      MLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised.fetch_or(bit, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(k_mlp_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_T), lds, (hipStream_t)stream, a);
   MLP_HIP(hipGetLastError());

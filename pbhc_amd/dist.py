@@ -2,8 +2,8 @@
 the tests).  The reference is single-process; these three exchanges make G ranks x N envs behave like ONE
 batch of G*N envs:
 
-  * `allreduce_mean_`      ONE all-reduce of the flat actor+critic gradient buffer per optimiser step (≈5 MB fp32;
-                           latency-bound on a 7 x 153 GB/s xGMI mesh, so a single un-chunked collective);
+  * `allreduce_mean_`      ONE all-reduce (RCCL: ReduceOp.AVG, no separate division) of the flat actor+critic gradient buffer per
+                           optimiser step (≈5 MB fp32; latency-bound on a 7 x 153 GB/s xGMI mesh, so a single un-chunked collective);
   * `global_normalize_`    advantage mean / unbiased std over all ranks' T*N samples (mh_ppo.py:392-394) from three
                            moments (sum, sum of squares, count) in one tiny all-reduce;
   * `kl_lr_rule_`          the adaptive-KL learning-rate rule (mh_ppo.py:455-466) on the all-reduced KL mean, so every
@@ -91,10 +91,21 @@ def host_generator(device):
     return _GENERATORS[key]
 
 
-def allreduce_mean_(flat: torch.Tensor):
-    if active():
-        all_reduce(flat)
-        flat.div_(world())
+def _avg_supported(group=None):
+    """RCCL reduces with ReduceOp.AVG in the collective itself (no second pass over the bucket); gloo has no AVG"""
+    return dist.get_backend(group) == "nccl"
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None):
+    """in-place mean over the ranks: ONE collective (RCCL: ReduceOp.AVG; gloo: sum, then a division)"""
+    if active(group):
+        if _avg_supported(group):
+            COUNTERS["all_reduce"] += 1
+            COUNTERS["all_reduce_bytes"] += flat.numel() * flat.element_size()
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+        else:
+            all_reduce(flat, group=group)
+            flat.div_(world(group))
     return flat
 
 

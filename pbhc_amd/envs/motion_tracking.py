@@ -398,22 +398,35 @@ class LeggedRobotMotionTracking:
             setattr(self._io, k, None if v is None else v.data_ptr())
 
     # ---- data-parallel runs: batch statistics over ALL ranks' envs ---------------------------
-    def enable_global_statistics(self, group=None):
+    def enable_global_statistics(self, group=None, mode="rollout"):
         """One process per GPU, envs sharded over ranks: adaptive sigma, average episode length, the curricula keyed on it and the logged
-        means are batch statistics of the reference's single process (motion_tracking.py:1030-1048, legged_robot_base.py:875-900).  With this
-        on, each step writes its shard's batch sums (PBHC_NUM_TOTALS doubles), they are summed over the ranks by one tiny all-reduce that
-        overlaps the next policy forward, and `pbhc_env_finalize` applies them — right before the next step launches, which is the first
-        consumer.  Every rank then holds the same sigma / curriculum state as ONE process with all the envs would."""
+        means are batch statistics of the reference's single process (motion_tracking.py:1030-1048, legged_robot_base.py:875-900).
+          mode "rollout" (default): every step updates them from THIS rank's shard (4096 envs: already a tight estimate), and
+                 `sync_globals()` — called by the agents once per rollout — replaces every rank's copy by the mean over the ranks: ONE
+                 1 KB all-reduce per PPO iteration, nothing on the step -> policy -> step chain;
+          mode "step": each step writes its shard's batch sums (PBHC_NUM_TOTALS doubles), ONE 512-byte all-reduce sums them over the ranks
+                 while the next policy forward runs, and `pbhc_env_finalize` applies them right before the next step launches: every rank
+                 then holds exactly the sigma / curriculum state ONE process with all the envs would (tests/test_gpu_dist.py) — at 24
+                 latency-critical collectives per iteration."""
         if not pdist.active(group):
             return False
+        assert mode in ("rollout", "step"), mode
         self._flush_statistics()
-        self._stat_group = group
-        n = torch.tensor([float(self.num_envs)], dtype=torch.float64, device=self.device)
-        pdist.all_reduce(n, group=group)
-        self._num_envs_total = float(n)
-        self._totals = torch.zeros(K["PBHC_NUM_TOTALS"], dtype=torch.float64, device=self.device)
-        self._io.totals_out = self._totals.data_ptr()
+        self._stat_group, self._stat_mode = group, mode
+        if mode == "step":
+            n = torch.tensor([float(self.num_envs)], dtype=torch.float64, device=self.device)
+            pdist.all_reduce(n, group=group)
+            self._num_envs_total = float(n)
+            self._totals = torch.zeros(K["PBHC_NUM_TOTALS"], dtype=torch.float64, device=self.device)
+            self._io.totals_out = self._totals.data_ptr()
         return True
+
+    def sync_globals(self):
+        """mode "rollout": the batch-statistics state (sigma, EMA, curricula, log means: the `globals` vector) becomes the mean over the ranks"""
+        if getattr(self, "_stat_mode", None) != "rollout":
+            return
+        self.wait_finalize()
+        pdist.allreduce_mean_(self.globals, group=self._stat_group)
 
     def set_finalize_stream(self, stream):
         """Run every step's one-workgroup reduction (`pbhc_env_step_finish`: sigma EMA, curricula, log means, step counter) on `stream`

@@ -40,9 +40,10 @@ def test_bench_secondary_object_is_configs_2():
 
 
 def test_rccl_code_path_on_one_rank():
-    """PBHC_DIST_FORCE=1: a ONE-rank RCCL process group takes the data-parallel code path — broadcast of the initial weights, async gradient-
-    segment all-reduces overlapping the critic's backward, the advantage-moment and KL exchanges, the per-step 512-byte env-statistics
-    all-reduce + `pbhc_env_finalize`, all next to hipGraph replays of the policy forward.  What a one-GPU box can rehearse of the N-GPU run."""
+    """PBHC_DIST_FORCE=1: a ONE-rank RCCL process group takes the data-parallel code path — broadcast of the initial weights, ONE averaged
+    all-reduce of the actor + critic gradient bucket (KL mean in its last slot) per optimiser step, the advantage-moment exchange and the
+    once-per-rollout exchange of the env statistics, all next to hipGraph replays of the policy forward.  What a one-GPU box can rehearse
+    of the N-GPU run."""
     env = dict(os.environ, PBHC_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -52,7 +53,7 @@ def test_rccl_code_path_on_one_rank():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     c = r["collectives"]
     assert c["backend"] == "nccl" and r["n_gpus"] == 1
-    # per iteration: 20 optimiser steps x 2 gradient segments (the KL scalar rides in the critic's) + 1 advantage-moment exchange + 24 env-statistics exchanges
-    assert c["all_reduces_per_iter"] == 20 * 2 + 1 + 24, c
+    # per iteration: 20 optimiser steps x 1 gradient bucket (the KL scalar rides in it) + 1 advantage-moment exchange + 1 env-statistics exchange
+    assert c["all_reduces_per_iter"] == 20 + 1 + 1, c
     # actor 380-512-256-128-23 (+ std) and critic 630-768-512-128-R, R = reward columns of the walk config (19 terms + termination = 20)
     assert c["grad_bucket_bytes"] == 4 * (362286 + 944000 + 129 * 20) and c["grad_allreduce_ms"] > 0

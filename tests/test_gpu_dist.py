@@ -123,7 +123,7 @@ def _env_rank_main(rank, world, port, out_path):
         cfg, env = build_hip_env("v1_g1_23dof_horse_stance.yaml", n)
         gs = {k: g[k][sl] for k in ("env_origins", "base_com_bias", "link_mass_scale", "friction_coeffs", "base_mass_scale") if k in g}
         load_state_into_hip_env(env, _slice_envs(state_dict_from_golden(g), sl, N), gs)
-        assert env.enable_global_statistics() and env._num_envs_total == N
+        assert env.enable_global_statistics(mode="step") and env._num_envs_total == N       # exact single-process equivalence, step by step
         tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
         env.simulator.set_replay(*[tg(g[k][:, sl]) for k in ("replay_root", "replay_dof_pos", "replay_dof_vel", "replay_contact")])
         K = _lib.K
@@ -176,6 +176,55 @@ def test_env_statistics_over_two_ranks_follow_the_single_process_trace(tmp_path)
             close(torch.tensor(r["upper"]), g["step__log__upper_body_diff_norm"][k], 1e-4, w + "log upper_body_diff_norm")
             close(torch.tensor(r["grav"]), g["step__log__terminate_by_gravity"][k], 1e-4, w + "log terminate_by_gravity")
     assert moved > 0            # sigma did change during the trace
+
+
+def _rollout_mode_rank_main(rank, world, port, out_path):
+    from tests.helpers import load_env_golden, load_state_into_hip_env, state_dict_from_golden
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        g = load_env_golden("horse")
+        T, N, D = g["actions_in"].shape
+        n = N // world
+        sl = slice(rank * n, (rank + 1) * n)
+        cfg, env = build_hip_env("v1_g1_23dof_horse_stance.yaml", n)
+        gs = {k: g[k][sl] for k in ("env_origins", "base_com_bias", "link_mass_scale", "friction_coeffs", "base_mass_scale") if k in g}
+        load_state_into_hip_env(env, _slice_envs(state_dict_from_golden(g), sl, N), gs)
+        assert env.enable_global_statistics() and env._totals is None                          # default mode: "rollout"
+        tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        env.simulator.set_replay(*[tg(g[k][:, sl]) for k in ("replay_root", "replay_dof_pos", "replay_dof_vel", "replay_contact")])
+        from pbhc_amd import dist as pdist
+
+        pdist.reset_counters()
+        for k in range(T):
+            st = lambda name, dt=torch.float32: tg(g["step__state__" + name][k][sl]).to(dt)
+            env.set_injected_draws(u_rfi=tg(g["step__u_rfi"][k][sl]), start_time=st("motion_start_times"), kp=st("kp_scale"), kd=st("kd_scale"),
+                                   rfi_lim=st("rfi_lim_scale"), rao=st("rao_scale"), delay=st("action_delay_idx", torch.long))
+            env.step({"actions": tg(g["actions_in"][k][sl])})
+        assert pdist.COUNTERS["all_reduce"] == 0                                                # nothing exchanged inside the rollout
+        env.wait_finalize()
+        before = env.globals.cpu().clone()
+        env.sync_globals()
+        torch.cuda.synchronize()
+        assert pdist.COUNTERS["all_reduce"] == 1
+        torch.save(dict(before=before, after=env.globals.cpu().clone()), out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rollout_mode_averages_the_statistics_once_per_rollout(tmp_path):
+    """sync_env_statistics "rollout" (the default): inside a rollout every rank updates sigma / the curricula / the log means from its OWN
+    shard and no collective runs; `sync_globals()` — one 1 KB all-reduce per PPO iteration — then leaves the mean over the ranks on every
+    rank.  The two shards of the reference's 32-env trace diverge (different envs), so the mean differs from both."""
+    world = 2
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_rollout_mode_rank_main, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(out + f".{k}", weights_only=False) for k in range(world)]
+    mean = 0.5 * (r[0]["before"] + r[1]["before"])
+    assert float((r[0]["before"] - r[1]["before"]).abs().max()) > 1e-6
+    for k in range(world):
+        assert torch.allclose(r[k]["after"], mean, rtol=1e-12, atol=0.0), k
 
 
 # ---- equal seeds on every rank must not replicate the random streams ---------------------------------------------------------

@@ -925,21 +925,36 @@ def test_fused_mlp_keeps_autograd_accumulation():
         # (1) applied twice in ONE graph
         (m(x1).square().sum() + m(x2).sum()).backward()
         close(flat, want_twice, 2e-4, f"declare={declare}: module applied twice in one graph", rtol=1e-4)
+        def zero():                                        # the owner's pattern: zero the buffer, tell the declared stacks (MHPPO._zero_grads)
+            flat.zero_()
+            if declare:
+                for b in m.modules():
+                    if isinstance(b, BaseModule):
+                        fused_mlp.grads_zeroed(b.module)
+
         # (2) one application after zeroing (the agents' pattern): the direct store when declared
-        flat.zero_()
+        zero()
         m(x1).square().sum().backward()
         close(flat, want_once, 2e-4, f"declare={declare}: single application", rtol=1e-4)
-        if not declare:
-            # (3) a second backward WITHOUT zeroing accumulates (undeclared stacks never overwrite)
+        # (3) a second backward WITHOUT zeroing accumulates — undeclared stacks never overwrite, and a declared one stores only on the
+        # FIRST backward after its owner's zeroing (an auxiliary loss / gradient accumulation between two zeroings)
+        m(x1).square().sum().backward()
+        close(flat, 2.0 * want_once, 4e-4, f"declare={declare}: two backwards without zeroing", rtol=1e-4)
+        # (3b) a frozen parameter with a .grad view receives no store
+        if declare:
+            zero()
+            lin0 = next(q for q in m.module if isinstance(q, torch.nn.Linear))
+            lin0.weight.requires_grad_(False)
             m(x1).square().sum().backward()
-            close(flat, 2.0 * want_once, 4e-4, "two backwards without zeroing", rtol=1e-4)
+            assert float(lin0.weight.grad.abs().max()) == 0.0
+            lin0.weight.requires_grad_(True)
         # (4) two graphs alive together, backward one after the other
-        flat.zero_()
+        zero()
         ya, yb = m(x1).square().sum(), m(x2).sum()
         ya.backward(); yb.backward()
         close(flat, want_twice, 2e-4, f"declare={declare}: two live graphs", rtol=1e-4)
         # ... and the direct path is back afterwards
-        flat.zero_()
+        zero()
         m(x1).square().sum().backward()
         close(flat, want_once, 2e-4, f"declare={declare}: single application again", rtol=1e-4)
 
