@@ -499,9 +499,10 @@ constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
     if (c.groups[g].num_runs < 0) return false;
   return true;
 }
-// the uniform of element j of row `stream`: the first word of the lane's Philox quad (keyed by env / step / lane), re-keyed by (row, j) and
-// passed through a bijective 32-bit finaliser — every writer of observation noise (list, per-element map, unrolled runs) uses this one
-// function, so the generic and the specialised kernel draw the same noise.  (One word on purpose: choosing among the four by j & 3 turns
+// the uniform of element j of row `stream`: the first word of the env's Philox quad of this step (keyed by env / step only: every lane
+// computes the same one, so the value does not depend on WHICH lane writes element j), re-keyed by (row, j) and passed through a bijective
+// 32-bit finaliser — every writer of observation noise (list, per-element map, unrolled runs) uses this one function, so the generic and
+// the specialised kernel draw the same noise, and a test can restate it on the host (tests/helpers.py: expected_obs_noise).  (One word on purpose: choosing among the four by j & 3 turns
 // the quad into an indexed array, i.e. scratch memory.)
 __device__ __forceinline__ float obs_noise_u(const uint32_t* pre, uint32_t stream, uint32_t j) {
   return u01(mix32(pre[0] ^ (stream * 0x9E3779B9u + j * 0x85EBCA6Bu)));
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       }
     }
     WAVE_LDS_FENCE();
-    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar1 next
+    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar1 next
     STAMPB(3);
   }
   LDS_BARRIER();                                               // bar1: A's body state and B's reference frame / scalars are in LDS
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f || tcontact != 0.0f || tlowh != 0.0f) ? 1.0f : 0.0f;
     }
     WAVE_LDS_FENCE();
-    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, (uint32_t)lane, nzb);       // noise base: this wave waits for bar2 next
+    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar2 next
     STAMP(4);
   } else {
     // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the

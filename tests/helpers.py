@@ -207,3 +207,35 @@ def fresh_episode_state(orc):
         flat["sigma__" + k] = orc.sigma[k]
     flat.update(reward_penalty_scale=1.0, average_episode_length=0.0, motion_far_threshold=1.5)
     return flat
+
+
+# ---- the step kernel's observation noise, restated on the host (csrc/pbhc_math.h philox4x32 + csrc/pbhc_env_step.h obs_noise_u) -------------
+# The reference draws torch.rand_like per observation group and step (helpers.py:128-152): its stream cannot be reproduced, so noise-on
+# parity is checked against the KERNEL's own generator: Philox4x32-7 keyed (seed, env, step counter, 16, 0) -> first word -> re-keyed by
+# (row, element) -> bijective finaliser -> 24-bit uniform.
+def _philox4x32_7_word0(seed, env_ids, step_ctr):
+    M = np.uint64(0xFFFFFFFF)
+    k0 = np.full(env_ids.shape, seed & 0xFFFFFFFF, np.uint64)
+    k1 = np.full(env_ids.shape, (seed >> 32) & 0xFFFFFFFF, np.uint64)
+    c0, c1 = env_ids.astype(np.uint64), np.full(env_ids.shape, step_ctr, np.uint64)
+    c2, c3 = np.full(env_ids.shape, 16, np.uint64), np.zeros(env_ids.shape, np.uint64)
+    for _ in range(7):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n1, n2, n3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M, p0 & M
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0.astype(np.uint64)
+
+
+def expected_obs_noise(seed, env_ids, step_ctr, group_index, noise, scale, noise_cur=1.0):
+    """[len(env_ids), dim] additive term (2u - 1) * noise[j] * noise_cur * scale[j] the step kernel puts on element j of observation row
+    `group_index` (position in env.layout.group_names) at RNG step counter `step_ctr`."""
+    M = np.uint64(0xFFFFFFFF)
+    p0 = _philox4x32_7_word0(int(seed), np.asarray(env_ids, np.int64), int(step_ctr))[:, None]            # [n, 1]
+    j = np.arange(len(noise), dtype=np.uint64)[None, :]
+    x = (p0 ^ ((np.uint64(16 + group_index) * np.uint64(0x9E3779B9) + j * np.uint64(0x85EBCA6B)) & M)) & M
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M
+    x ^= x >> np.uint64(16)
+    u = (x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy((u * np.float32(2.0) - np.float32(1.0)) * (np.asarray(noise, np.float32) * np.float32(noise_cur))[None, :] * np.asarray(scale, np.float32)[None, :])

@@ -352,6 +352,138 @@ def _multi_clip_vs_oracle(N, T, M, library_seed=3):
     assert nreset >= 48
 
 
+def test_general_tracking_config5_shard_with_noise_and_dr_matches_oracle():
+    """BASELINE configs[4] at its per-GPU shard: 4096 envs, G1 29-DoF, a 1024-clip synthetic library (the AMASS / LAFAN sets are not
+    shipped), observation noise ON (config/obs/motion_tracking/obs_ppo_teacher.yaml:86-113) and the shipped domain randomisation
+    (config/domain_rand/main.yaml) ON — against the oracle, not only through statistics.  The HIP side ingests all 1024 clips and steps all
+    4096 envs; the oracle (Python FK per clip) holds the tables of the first 40 clips and steps the ~160 envs whose slot maps to one of
+    them, on the same replay tensors, with the reset / torque-noise draws injected on both sides.  Batch statistics (adaptive sigma, the
+    curricula) are those of all 4096 envs on the HIP side: the oracle is handed them after every step (their own parity: the full-size
+    test above).  Observation noise: the oracle computes the noise-free rows, the kernel's own generator is restated on the host
+    (tests/helpers.expected_obs_noise) and added — every element then has to agree to the usual bound."""
+    import bench
+    from oracle.env_v2 import GeneralTrackingOracle
+    from oracle.fk import sim_fk
+    from oracle.motion_lib import MotionLib as OML
+    from pbhc_amd import _lib
+    from pbhc_amd import motion_lib as ML
+    from pbhc_amd.envs.env_config import SIGMA_KEYS
+    from tests.helpers import clip_from_env_golden, expected_obs_noise, fixture_config, skel_from_golden
+
+    N, T, M, MSUB = 4096, 2, 1024, 40
+    cfgname = "v2_g1_29dof_teacher.yaml"
+    g = dict(np.load(os.path.join(GOLDEN, "env_v2_teacher29.npz")))
+    clips = bench.synth_library(clip_from_env_golden(g), M, seed=11)
+    orig = ML.load_motion_file
+    ML.load_motion_file = lambda path: [(f"c{i}", c) for i, c in enumerate(clips)]
+    try:
+        cfg, env = build_hip_env(cfgname, N, general=True, noise_off=False, overrides={"domain_rand.push_robots": False})
+    finally:
+        ML.load_motion_file = orig
+    assert any(float(v) > 0 for v in cfg.obs.noise_scales.values()) and cfg.domain_rand.randomize_pd_gain and cfg.domain_rand.randomize_ctrl_delay
+    K = _lib.K
+    slot_clip = env._motion_lib.slot_clip.cpu().clone()
+    ids = (slot_clip < MSUB).nonzero().flatten()
+    n = len(ids)
+    assert 64 <= n <= 512 and len(set(slot_clip.tolist())) > 900, (n, len(set(slot_clip.tolist())))
+    skel = skel_from_golden("g1_29dof")
+    oml = OML(skel, clips[:MSUB])
+    ocfg = fixture_config(cfgname, n, {"domain_rand.push_robots": False})          # noise scales zeroed: the oracle's rows are noise-free
+    sim = env.simulator
+    dr = dict(base_com_bias=sim._base_com_bias.cpu()[ids], link_mass_scale=sim._link_mass_scale.cpu()[ids], friction_coeffs=sim.friction_coeffs.cpu()[ids],
+              base_mass_scale=sim._base_mass_scale.cpu()[ids])
+    orc = GeneralTrackingOracle(ocfg, skel, oml, n, dr)
+    orc.env_origins = env.env_origins.cpu()[ids]
+    orc.ref_init_yaw = env.ref_init_yaw
+    orc.slot_clip = slot_clip[ids].clone()
+    D = 29
+    gen = torch.Generator().manual_seed(15)
+    mlen = env._motion_lib.get_motion_length(env.motion_ids).cpu()
+    start = torch.rand(N, generator=gen) * mlen
+    start[ids[:12]] = mlen[ids[:12]] - 0.05                  # motion-end time-outs among the compared envs
+    ep = torch.randint(0, 50, (N,), generator=gen)
+    full = {k: (v.new_zeros((N,) + tuple(v.shape[1:])) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n else v) for k, v in orc.s.items()}
+    full["motion_start_times"] = start; full["episode_length_buf"] = ep; full["last_episode_length_buf"] = ep.clone(); full["motion_len"] = mlen.clone()
+    full["kp_scale"] = 0.9 + 0.2 * torch.rand(N, D, generator=gen); full["kd_scale"] = 0.9 + 0.2 * torch.rand(N, D, generator=gen)
+    full["rfi_lim_scale"] = 0.5 + torch.rand(N, D, generator=gen); full["rao_scale"] = 0.1 * (torch.rand(N, D, generator=gen) - 0.5)
+    full["action_delay_idx"] = torch.randint(0, 3, (N,), generator=gen)
+    # the replay window of ALL envs from the HIP lookup (reference state + noise), state 0 = the initial simulator state
+    env._episode_length_buf.copy_(ep.to(DEV)); env.motion_start_times.copy_(start.to(DEV)); env.motion_len.copy_(mlen.to(DEV))
+    root, qp, qv, cf = [t.cpu() for t in bench.make_replay_on_device(env, T + 1, seed=21)]
+    full["root_states"], full["dof_pos"], full["dof_vel"], full["contact_forces"] = root[0], qp[0], qv[0], cf[0]
+    flat = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in full.items()}
+    for k in orc.sums:
+        flat["sum__" + k] = np.zeros(N, np.float32)
+    for k in orc.hist:
+        flat["hist__" + k] = (0.1 * torch.randn((N,) + tuple(orc.hist[k].shape[1:]), generator=gen)).numpy()
+    for k in orc.sigma:
+        flat["sigma__" + k] = orc.sigma[k]
+    flat.update(reward_penalty_scale=1.0, average_episode_length=0.0, motion_far_threshold=1.5)
+    sub = lambda v: v[ids.numpy()] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == N else v
+    orc.load_state({k: sub(v) for k, v in flat.items()})
+    load_state_into_hip_env(env, flat)
+    tg = lambda a: a.contiguous().to(DEV)
+    env.simulator.set_replay(tg(root[1:]), tg(qp[1:]), tg(qv[1:]), tg(cf[1:]))
+    L = env.layout
+    nreset = 0
+    for k in range(T):
+        act = 0.5 * torch.randn(N, D, generator=gen)
+        u = torch.rand(N, D, generator=gen)
+        samp = dict(motion_start_times=torch.rand(N, generator=gen) * mlen, kp_scale=0.9 + 0.2 * torch.rand(N, D, generator=gen),
+                    kd_scale=0.9 + 0.2 * torch.rand(N, D, generator=gen), rfi_lim_scale=0.5 + torch.rand(N, D, generator=gen),
+                    rao_scale=0.1 * (torch.rand(N, D, generator=gen) - 0.5), action_delay_idx=torch.randint(0, 3, (N,), generator=gen))
+        frame = dict(root=root[k + 1][ids], dof_pos=qp[k + 1][ids], dof_vel=qv[k + 1][ids], contact=cf[k + 1][ids])
+        body = sim_fk(skel, frame["root"], frame["dof_pos"], frame["dof_vel"])
+        o_obs, o_rew, o_reset, o_ex = orc.step(act[ids], frame, body, u_rfi=u[ids], reset_samples={a: b[ids] for a, b in samp.items()})
+        env.set_injected_draws(u_rfi=tg(u), start_time=tg(samp["motion_start_times"]), kp=tg(samp["kp_scale"]), kd=tg(samp["kd_scale"]),
+                               rfi_lim=tg(samp["rfi_lim_scale"]), rao=tg(samp["rao_scale"]), delay=tg(samp["action_delay_idx"]))
+        env.wait_finalize()
+        step_ctr = int(env.globals[K["PBHC_G_STEP_COUNTER"]])
+        noise_cur = float(env.globals[K["PBHC_G_NOISE_CURRICULUM"]])
+        obs, rew, reset, extras = env.step({"actions": tg(act)})
+        torch.cuda.synchronize()
+        w = f"step {k}: "
+        assert torch.equal(reset.cpu()[ids], o_reset), w + f"reset mismatch {int((reset.cpu()[ids] != o_reset).sum())}"
+        nreset += int(o_reset.sum())
+        close(rew[ids.to(DEV)], o_rew, 3e-5, w + "rew", rtol=2e-4)
+        tols = _conditioned_obs_tolerances(cfg, env, orc, oml, o_obs)
+        seen_noise = 0.0
+        def by_dst(gi):                                            # (noise, scale) of a row indexed by the element's position in the row
+            td, _, tsc, tn = L.map_tensors[gi]
+            dim = int(td.max()) + 1
+            ns, sc = np.zeros(dim, np.float32), np.ones(dim, np.float32)
+            ns[td.cpu().numpy()], sc[td.cpu().numpy()] = tn.cpu().numpy(), tsc.cpu().numpy()
+            return ns, sc
+
+        clipv = float(env._c.clip_observations)
+        for gi, gname in enumerate(L.group_names[:-1]):
+            add = expected_obs_noise(env._seed, ids.numpy(), step_ctr, gi, *by_dst(gi), noise_cur)
+            want = (o_obs[gname] + add).clamp(-clipv, clipv)
+            seen_noise = max(seen_noise, float(add.abs().max()))
+            close(obs[gname][ids.to(DEV)], want, tols[gname] + 2e-6, w + gname + " (noise on)")
+        assert seen_noise > 1e-3                                 # noise was on, and of visible size
+        # the history: every key's newest entry carries ITS OWN draw (the write-back is a group of its own, helpers.py:128-152 is called once
+        # per group); checked against the oracle's noise-free history + the restated noise, then handed to the oracle for the next step
+        gi = len(L.group_names) - 1
+        addh = expected_obs_noise(env._seed, ids.numpy(), step_ctr, gi, *by_dst(gi), noise_cur)
+        for name, view in env.history.items():
+            o0 = L.hist_off[name]
+            hv = view.cpu()[ids]
+            exp = orc.hist[name].clone()
+            exp[:, 0] = exp[:, 0] + addh[:, o0:o0 + exp.shape[-1]]   # (a reset env too: its history was zeroed BEFORE this step's entry was added)
+            close(hv, exp, 3e-5, w + "hist " + name, rtol=3e-5)
+            orc.hist[name] = hv.clone()
+        # batch statistics of ALL envs -> the oracle (see the docstring)
+        gl = env.globals.cpu().numpy()
+        for i, name in enumerate(SIGMA_KEYS):
+            if name in orc.sigma:
+                orc.sigma[name], orc.ema[name] = float(gl[K["PBHC_G_SIGMA"] + i]), float(gl[K["PBHC_G_EMA"] + i])
+        orc.penalty_scale = float(gl[K["PBHC_G_PENALTY_SCALE"]])
+        orc.avg_ep_len = torch.tensor(float(gl[K["PBHC_G_AVG_EP_LEN"]]), dtype=torch.float32)
+        orc.motion_far_thr = float(gl[K["PBHC_G_MOTION_FAR_THR"]])
+    assert nreset >= 12
+
+
 def test_ppo_mimic_distillation_matches_reference(tmp_path):
     """Student distillation (teacher_model_path + dagger_only): the teacher observation groups are added to the existing env, the teacher
     actor is loaded from a checkpoint + config.yaml, and one _training_step_distill on the reference's rollout buffer / permutation
