@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 6
+#define PBHC_ABI_VERSION 7
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -204,7 +204,10 @@ typedef struct PbhcEnvConfig {
   /* timing (base_task.py:37-39) */
   float dt;
   float max_episode_length;
-  /* control (legged_robot_base.py:795-838) */
+  /* control (legged_robot_base.py:795-838): control_type 0 "P" (position targets), 1 "V" (velocity targets: kp (a - qd) - kd (qd - last_qd) / sim_dt),
+   * 2 "T" (scaled actions are the torques), :809-817; sim_dt = 1 / simulator fps (base_task.py:34) */
+  int32_t control_type;
+  float sim_dt;
   float p_gains[PBHC_MAX_DOF], d_gains[PBHC_MAX_DOF], action_scale[PBHC_MAX_DOF], default_dof_pos[PBHC_MAX_DOF];
   float torque_limits[PBHC_MAX_DOF], dof_vel_limits[PBHC_MAX_DOF];
   float hard_dof_pos_limits[PBHC_MAX_DOF][2], soft_dof_pos_limits[PBHC_MAX_DOF][2];
@@ -501,7 +504,7 @@ int pbhc_act_bwd_bias(const float* dy, const float* saved, int B, int n, int act
 /* The same in two halves, so that a whole network's bias gradients are finished by ONE launch: pbhc_act_bwd_partials does the slab pass
  * and leaves per-row-block column sums in `scratch` (returns their count in *num_row_blocks); pbhc_colsum_final sums up to
  * PBHC_MAX_COLSUM_JOBS such scratch areas into their grad_bias vectors (fixed order, deterministic). */
-#define PBHC_MAX_COLSUM_JOBS 8
+#define PBHC_MAX_COLSUM_JOBS 16
 typedef struct PbhcColsumJob {
   const float* part;   /* [num_row_blocks, n] */
   float* out;          /* [n] */

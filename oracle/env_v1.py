@@ -172,7 +172,15 @@ class MotionTrackingOracle:
         s = self.s
         dr = self.cfg.domain_rand
         a = actions * self.action_scale
-        tq = s["kp_scale"] * self.p_gains * (a + self._default(s) - s["dof_pos"]) - s["kd_scale"] * self.d_gains * s["dof_vel"]
+        ct = self.cfg.robot.control.control_type                      # legged_robot_base.py:809-817
+        if ct == "P":
+            tq = s["kp_scale"] * self.p_gains * (a + self._default(s) - s["dof_pos"]) - s["kd_scale"] * self.d_gains * s["dof_vel"]
+        elif ct == "V":
+            tq = s["kp_scale"] * self.p_gains * (a - s["dof_vel"]) - s["kd_scale"] * self.d_gains * (s["dof_vel"] - s["last_dof_vel"]) / self.sim_dt
+        elif ct == "T":
+            tq = a
+        else:
+            raise NameError(f"Unknown controller type: {ct}")
         if dr.randomize_torque_rfi:
             tq = tq + (u_rfi * 2.0 - 1.0) * dr.rfi_lim * s["rfi_lim_scale"] * self.torque_limits
         if dr.use_rao:

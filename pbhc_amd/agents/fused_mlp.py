@@ -67,8 +67,10 @@ def supported(module_seq):
     return not any(isinstance(a, nn.ELU) and a.alpha != 1.0 for a in acts)
 
 
-def _wgrad(d, x, out):
-    """out[n, k] = d^T[n, B] x[B, k]: the split-rows MFMA kernel (`pbhc_linear_wgrad`) where its shape rules allow, else the library form."""
+def _wgrad(d, x, out, defer=None):
+    """out[n, k] = d^T[n, B] x[B, k]: the split-rows MFMA kernel (`pbhc_linear_wgrad`) where its shape rules allow, else the library form.
+    `defer`: a list; a split-K result's [P, n, k] partials are appended to it as (partials, out) instead of being summed here — the caller
+    sums every deferred pair in its ONE finishing launch (pbhc_colsum_final)."""
     n, k = out.shape
     B = d.shape[0]
     if FUSED_GEMM and FUSED_WGRAD and d.is_cuda and d.dtype == torch.float32 and out.is_contiguous() and d.is_contiguous() and x.is_contiguous():
@@ -78,10 +80,10 @@ def _wgrad(d, x, out):
             scratch = torch.empty(P * n * k, device=d.device)
             _lib.check(lib.pbhc_linear_wgrad(d.data_ptr(), x.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, n, k, _lib.current_stream()), "pbhc_linear_wgrad")
             return out
-    return _wgrad_library(d, x, out)
+    return _wgrad_library(d, x, out, defer)
 
 
-def _wgrad_library(d, x, out):
+def _wgrad_library(d, x, out, defer=None):
     """out[n, k] = d^T[n, B] x[B, k].  With B (minibatch rows, 24 576) >> n, k the single GEMM has few output tiles and a very long K loop:
     rocBLAS / hipBLASLt run it on part of the chip (128 x 256: 53 us = 30 TFLOP/s on MI355X).  Split over P row chunks it is a batched GEMM that
     fills the 256 CUs, followed by a [P, n, k] sum (23 us for the same shape); measured with tools/wgrad_splitk_probe.py."""
@@ -96,6 +98,9 @@ def _wgrad_library(d, x, out):
     if P == 0 or B % P or B // P < 256:
         return torch.mm(d.t(), x, out=out)
     part = torch.bmm(d.view(P, B // P, n).transpose(1, 2), x.view(P, B // P, k))
+    if defer is not None and out.is_contiguous():
+        defer.append((part, out))                          # summed by the caller's finishing launch (one launch for the whole backward
+        return out                                         # instead of one torch.sum per layer: 5 x 6 us per optimiser step)
     return torch.sum(part, 0, out=out)
 
 
@@ -154,8 +159,10 @@ class _FusedMLP(torch.autograd.Function):
         widths = [l.out_features for l in lin]
         MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
         scratch = torch.empty(MAXB * sum(widths), device=d.device)       # per-layer row-block column sums, finished by ONE launch below
-        jobs = (_lib._S["PbhcColsumJob"] * (L + 1))()               # one per layer's bias gradient (+ the output layer's weight gradient)
-        njobs = L
+        MAXJ = _lib.K["PBHC_MAX_COLSUM_JOBS"]
+        jobs = (_lib._S["PbhcColsumJob"] * MAXJ)()                  # one per layer's bias gradient (+ the output layer's weight gradient, + the
+        njobs = L                                                   # split-K partials of the hidden layers' weight gradients)
+        deferred = []
         nb = C.c_int(0)
         ret_w = []
         off = 0
@@ -209,11 +216,12 @@ class _FusedMLP(torch.autograd.Function):
                                                      part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
             j = jobs[L - 1 - i]
             j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
+            room = deferred if (njobs + len(deferred) + 2 <= MAXJ) else None      # (+ the output layer's own extra job)
             if direct:
-                _wgrad(d, ins[i], l.weight.grad)
+                _wgrad(d, ins[i], l.weight.grad, room)
                 ret_w.append((None, None))
             else:
-                ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device)), gb))
+                ret_w.append((_wgrad(d, ins[i], torch.empty(n, l.in_features, device=d.device), room), gb))
             have_partials = False
             if i > 0 and ctx.fused and l.weight.is_contiguous() and B <= 128 * MAXB:      # (row blocks of 128 at most: the column-sum scratch holds MAXB of them)
                 # d_below = (d W) * act'(output of the layer below) + its row-block column sums, in the GEMM's epilogue
@@ -225,6 +233,10 @@ class _FusedMLP(torch.autograd.Function):
                 have_partials = True
             elif i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
+        for part_w, out_w in deferred:                              # [P, n, k] partials -> the weight gradient: the same fixed-order column sum
+            j = jobs[njobs]
+            j.part, j.out, j.num_row_blocks, j.n = part_w.data_ptr(), out_w.data_ptr(), part_w.shape[0], out_w.numel()
+            njobs += 1
         _lib.check(lib.pbhc_colsum_final(jobs, njobs, st), "pbhc_colsum_final")
         if ctx.live is not None:
             seq._fused_live.discard(ctx.live)

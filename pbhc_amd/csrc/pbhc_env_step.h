@@ -839,7 +839,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
             }
         }
         actd[d] = delayed;
-        float tq = kp * k_pg * (delayed * k_as + k_dp - qp) - kd * k_dg * qv;
+        const float a_sc = delayed * k_as;
+        float tq;
+        if (c.control_type == 0) tq = kp * k_pg * (a_sc + k_dp - qp) - kd * k_dg * qv;
+        else if (c.control_type == 1) tq = kp * k_pg * (a_sc - qv) - kd * k_dg * (qv - pf_last_qd) / c.sim_dt;      // "V" (legged_robot_base.py:812-813)
+        else tq = a_sc;                                                                                                 // "T" (:814-815)
         if (c.randomize_torque_rfi) tq = tq + (u_rfi * 2.0f - 1.0f) * c.rfi_lim * rfs * tl;
         if (c.use_rao) tq = tq + ras * tl;
         if (c.clip_torques) tq = clampf(tq, -tl, tl);

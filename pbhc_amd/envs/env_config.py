@@ -120,8 +120,10 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     c.max_episode_length_s = float(ec.max_episode_length_s)
     # ---- control
     ctrl = rc.control
-    if ctrl.control_type != "P":
-        raise NotImplementedError(f"control_type {ctrl.control_type!r} (only 'P' is on the hot path)")
+    if ctrl.control_type not in ("P", "V", "T"):
+        raise NameError(f"Unknown controller type: {ctrl.control_type}")            # legged_robot_base.py:817
+    c.control_type = {"P": 0, "V": 1, "T": 2}[ctrl.control_type]
+    c.sim_dt = 1.0 / sim.fps
     for i, name in enumerate(rc.dof_names):
         c.default_dof_pos[i] = float(rc.init_state.default_joint_angles[name])
         found = False

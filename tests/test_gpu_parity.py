@@ -231,12 +231,19 @@ def test_sim_fk_matches_oracle():
 CASES = [("horse", "v1_g1_23dof_horse_stance.yaml"), ("walk", "v1_g1_23dof_walk.yaml")]
 
 
+@pytest.mark.parametrize("tag,cfgname,overrides", [("walk_ctrlV", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "V"}),
+                                                   ("walk_ctrlT", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "T"})])
+def test_env_step_matches_reference_trace_of_a_switch(tag, cfgname, overrides):
+    """control types "V" and "T" (legged_robot_base.py:809-817; no shipped yaml uses them): the reference's own traces"""
+    test_env_step_matches_reference_trace(tag, cfgname, overrides)
+
+
 @pytest.mark.parametrize("tag,cfgname", CASES)
-def test_env_step_matches_reference_trace(tag, cfgname):
+def test_env_step_matches_reference_trace(tag, cfgname, overrides=None):
     """The fused HIP step replays the reference's own trace (same inputs, injected draws)."""
     g = load_env_golden(tag)
     T, N, D = g["actions_in"].shape
-    cfg, env = build_hip_env(cfgname, N)
+    cfg, env = build_hip_env(cfgname, N, overrides=overrides)
     assert env.reward_names == list(g["reward_names"])
     load_state_into_hip_env(env, state_dict_from_golden(g), g)
     dev = env.device
