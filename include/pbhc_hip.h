@@ -97,6 +97,11 @@ enum PbhcRewardTerm {
   PBHC_R_KEY_BODY_ANG_VELOCITY,
   PBHC_R_TELEOP_ROOT_VEL,
   PBHC_R_TELEOP_ROOT_POSE,
+  /* foot orientation terms of the base env (legged_robot_base.py:1030-1075; no shipped yaml weights them) */
+  PBHC_R_FEET_HEADING_ALIGNMENT,
+  PBHC_R_FEET_HEADING_ALIGNMENT_CONTACT,
+  PBHC_R_PENALTY_FEET_ORI,
+  PBHC_R_PENALTY_FEET_ORI_CONTACT,
   PBHC_R_NUM_TERMS
 };
 
@@ -208,6 +213,7 @@ typedef struct PbhcEnvConfig {
    * 2 "T" (scaled actions are the torques), :809-817; sim_dt = 1 / simulator fps (base_task.py:34) */
   int32_t control_type;
   float sim_dt;
+  int32_t foot_ori_terms;                    /* 1: a feet_heading_alignment* / penalty_feet_ori* term is configured (per-foot heading and tilt are computed) */
   float p_gains[PBHC_MAX_DOF], d_gains[PBHC_MAX_DOF], action_scale[PBHC_MAX_DOF], default_dof_pos[PBHC_MAX_DOF];
   float torque_limits[PBHC_MAX_DOF], dof_vel_limits[PBHC_MAX_DOF];
   float hard_dof_pos_limits[PBHC_MAX_DOF][2], soft_dof_pos_limits[PBHC_MAX_DOF][2];

@@ -574,6 +574,41 @@ class MotionTrackingOracle:
         cf = self.s["contact_forces"][:, self.feet]
         return torch.any(torch.norm(cf[..., :2], dim=2) > 5 * torch.abs(cf[..., 2]), dim=1)
 
+    # ---- foot orientation terms (legged_robot_base.py:1030-1079; quat_apply / quat_rotate_inverse: utils/torch_utils.py, wrap_to_pi rotations.py:50-53)
+    def _foot_heading_diffs(self):
+        fwd = torch.tensor([1.0, 0.0, 0.0]).repeat(self.N, 1)
+        rot = self.body_x[1]
+        root_f = R.quat_apply(self.s["root_states"][:, 3:7], fwd)
+        h_root = torch.atan2(root_f[:, 1], root_f[:, 0])
+        out = []
+        for f in self.feet:
+            ff = R.quat_apply(rot[:, f], fwd)
+            a = torch.atan2(ff[:, 1], ff[:, 0]) - h_root
+            a = a % (2 * np.pi)
+            a = a - 2 * np.pi * (a > np.pi)
+            out.append(torch.abs(a))
+        return out
+
+    def _foot_tilts(self):
+        rot = self.body_x[1]
+        return [torch.sum(torch.square(R.quat_rotate_inverse(rot[:, f], self.gravity_vec)[:, :2]), dim=1) ** 0.5 for f in self.feet]
+
+    def _reward_feet_heading_alignment(self):
+        l, r = self._foot_heading_diffs()
+        return l + r
+
+    def _reward_feet_heading_alignment_contact(self):
+        l, r = self._foot_heading_diffs()
+        return l * self.s["contacts_filt"][:, 0] + r * self.s["contacts_filt"][:, 1]
+
+    def _reward_penalty_feet_ori(self):
+        l, r = self._foot_tilts()
+        return l + r
+
+    def _reward_penalty_feet_ori_contact(self):
+        l, r = self._foot_tilts()
+        return l * self.s["contacts_filt"][:, 0] + r * self.s["contacts_filt"][:, 1]
+
     def _reward_penalty_slippage(self):
         foot_vel = self.body_x[2][:, self.feet]
         return torch.sum(torch.norm(foot_vel, dim=-1) * (torch.norm(self.s["contact_forces"][:, self.feet, :], dim=-1) > 1.0), dim=1)

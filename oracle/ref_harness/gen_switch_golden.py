@@ -1,6 +1,7 @@
 """Reference traces for config switches no shipped yaml enables (small: 8 envs x 4 steps of the unmodified reference's
 LeggedRobotMotionTracking.step on the walk clip, recorded exactly like gen_env_golden.py's traces):
   env_v1_walk_ctrlV.npz / env_v1_walk_ctrlT.npz    robot.control.control_type "V" / "T" (legged_robot_base.py:809-817)
+  env_v1_walk_feetori.npz                          reward terms feet_heading_alignment(_contact), penalty_feet_ori(_contact) (:1030-1079) weighted
 
     PYTHONPATH=/root/repo python oracle/ref_harness/gen_switch_golden.py      (build container only)
 """
@@ -9,10 +10,19 @@ from oracle.ref_harness import gen_env_golden as G1
 WALK = "motion_data/g1_walk_45cms_23dof.pkl"
 
 
-def main():
+FEET_ORI = {"rewards.reward_scales.feet_heading_alignment": -0.5, "rewards.reward_scales.feet_heading_alignment_contact": -0.3,
+            "rewards.reward_scales.penalty_feet_ori": -0.2, "rewards.reward_scales.penalty_feet_ori_contact": -0.4}
+
+
+def main(which=("walk_ctrlV", "walk_ctrlT", "walk_feetori")):
     for tag, ct in (("walk_ctrlV", "V"), ("walk_ctrlT", "T")):
-        G1.run_trace(G1.V1_CFG, tag, N=8, T=4, motion_file=WALK, extra=dict(G1.WALK_EXTRA, **{"robot.control.control_type": ct}), seed=21)
+        if tag in which:
+            G1.run_trace(G1.V1_CFG, tag, N=8, T=4, motion_file=WALK, extra=dict(G1.WALK_EXTRA, **{"robot.control.control_type": ct}), seed=21)
+    if "walk_feetori" in which:
+        G1.run_trace(G1.V1_CFG, "walk_feetori", N=8, T=4, motion_file=WALK, extra=dict(G1.WALK_EXTRA, **FEET_ORI), seed=22)
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+
+    main(tuple(sys.argv[1:]) or ("walk_ctrlV", "walk_ctrlT", "walk_feetori"))

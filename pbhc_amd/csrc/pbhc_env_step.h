@@ -56,8 +56,8 @@ enum {
   R_MAXNORM = R_ERR0 + PBHC_NUM_SIGMA, R_UPN, R_LON, R_VRN, R_JP2, R_TAU2, R_ARATE, R_QD2, R_QACC2, R_LIMPOS, R_LIMVEL, R_LIMTAU, R_COLL, R_CLIPCNT,
   R_KEYN, R_LKEYN, R_LUPN, R_LLON, R_LVRN, R_BODYZ,                 // general tracking: log norms, body_z flag
   R_EXP0,                                  // [PBHC_NUM_SIGMA] exp(-err_k / sigma_k)
-  R_FOOT0 = R_EXP0 + PBHC_NUM_SIGMA,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2)
-  R_NUM = R_FOOT0 + 10
+  R_FOOT0 = R_EXP0 + PBHC_NUM_SIGMA,       // per foot f: +4f: |F|, |F_xy|, F_z, |v|   (+8: |v_xy| x2; +10: |heading - root heading| x2; +12: |gravity_xy| in the foot frame x2)
+  R_NUM = R_FOOT0 + 14
 };
 static_assert(R_NUM <= 80, "RED region");
 
@@ -492,7 +492,8 @@ constexpr bool cfg_has_term(const PbhcEnvConfig& c, int id) {
 __device__ __forceinline__ bool is_special_term(int id) {     // the reward terms k_env_step evaluates by formula (the others: one slot of the reduction row)
   return id == PBHC_R_TELEOP_CONTACT_MASK || id == PBHC_R_TELEOP_CONTACT_MASK_V2 || id == PBHC_R_TELEOP_BODY_POSITION_EXTEND || id == PBHC_R_PENALTY_ORIENTATION ||
          id == PBHC_R_FEET_AIR_TIME || id == PBHC_R_PENALTY_FEET_CONTACT_FORCES || id == PBHC_R_PENALTY_STUMBLE || id == PBHC_R_PENALTY_SLIPPAGE ||
-         id == PBHC_R_FOOT_SLIP_PENALTY || id == PBHC_R_ALIVE;
+         id == PBHC_R_FOOT_SLIP_PENALTY || id == PBHC_R_ALIVE || id == PBHC_R_FEET_HEADING_ALIGNMENT || id == PBHC_R_FEET_HEADING_ALIGNMENT_CONTACT ||
+         id == PBHC_R_PENALTY_FEET_ORI || id == PBHC_R_PENALTY_FEET_ORI_CONTACT;
 }
 constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
   for (int g = 0; g < c.num_groups; ++g)
@@ -1108,6 +1109,18 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         red[R_FOOT0 + 4 * f + 2] = fc[2];
         red[R_FOOT0 + 4 * f + 3] = norm3(ld3(fv));
         red[R_FOOT0 + 8 + f] = sqrtf(fv[0] * fv[0] + fv[1] * fv[1]);
+        if (c.foot_ori_terms) {
+          // per-foot heading against the root's (feet_heading_alignment*, legged_robot_base.py:1030-1045,1054-1069) and tilt
+          // (penalty_feet_ori*, :1047-1052,1071-1079): torch_utils.quat_apply of the forward axis, atan2, wrap_to_pi (rotations.py:50-53)
+          const f4 fq = ld4(bq + 4 * c.feet[f]);
+          const f3 ff = quat_apply(fq, mk3(1.0f, 0.0f, 0.0f)), rf = quat_apply(ld4(root + 3), mk3(1.0f, 0.0f, 0.0f));
+          float dh = fmodf(atan2f(ff.y, ff.x) - atan2f(rf.y, rf.x), 6.2831855f);       // torch's %: the sign of the divisor
+          if (dh < 0.0f) dh += 6.2831855f;
+          if (dh > 3.1415927f) dh -= 6.2831855f;
+          red[R_FOOT0 + 10 + f] = fabsf(dh);
+          const f3 fg = quat_rotate_inverse(fq, mk3(0.0f, 0.0f, -1.0f));
+          red[R_FOOT0 + 12 + f] = sqrtf(fg.x * fg.x + fg.y * fg.y);
+        }
       }
     }
     GSUM(s_jp2); GSUM(s_jv2); GSUM(s_tau2); GSUM(s_ar); GSUM(s_qd2); GSUM(s_qacc2); GSUM(s_lpos); GSUM(s_lvel); GSUM(s_ltau); GSUM(s_coll);
@@ -1256,12 +1269,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         const float* ft = red + R_FOOT0;
         float raw = red[max(pf_tsrc, 0)];
         float cfl[PBHC_MAX_FEET], rcn[PBHC_MAX_FEET], lsc[PBHC_MAX_FEET], fat[PBHC_MAX_FEET];
-        float fF[PBHC_MAX_FEET], fXY[PBHC_MAX_FEET], fZ[PBHC_MAX_FEET], fV[PBHC_MAX_FEET], fVxy[PBHC_MAX_FEET];
+        float fF[PBHC_MAX_FEET], fXY[PBHC_MAX_FEET], fZ[PBHC_MAX_FEET], fV[PBHC_MAX_FEET], fVxy[PBHC_MAX_FEET], fHd[PBHC_MAX_FEET], fOri[PBHC_MAX_FEET];
 #pragma unroll
         for (int f = 0; f < PBHC_MAX_FEET; ++f) {
           const int g = min(f, NF - 1);
           cfl[f] = misc[M_CFILT0 + g]; rcn[f] = misc[M_RCONTACT0 + g]; lsc[f] = misc[M_LASTC0 + g]; fat[f] = misc[M_FAT0 + g];
           fF[f] = ft[4 * g]; fXY[f] = ft[4 * g + 1]; fZ[f] = ft[4 * g + 2]; fV[f] = ft[4 * g + 3]; fVxy[f] = ft[8 + g];
+          fHd[f] = c.foot_ori_terms ? ft[10 + g] : 0.0f; fOri[f] = c.foot_ori_terms ? ft[12 + g] : 0.0f;
         }
         const float gx = misc[M_GX], gy = misc[M_GY], exl = ex[PBHC_S_LOWER_BODY_POS], exu = ex[PBHC_S_UPPER_BODY_POS];
         if (TERM(TELEOP_CONTACT_MASK) || TERM(TELEOP_CONTACT_MASK_V2)) {
@@ -1318,6 +1332,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
           raw = id == PBHC_R_FOOT_SLIP_PENALTY ? v : raw;
         }
         if (TERM(ALIVE)) raw = id == PBHC_R_ALIVE ? 1.0f : raw;
+        if (c.foot_ori_terms) {                                  // legged_robot_base.py:1030-1079: left + right, the *_contact forms weighted by contacts_filt
+          float vh = 0.0f, vhc = 0.0f, vo = 0.0f, voc = 0.0f;
+#pragma unroll
+          for (int f = 0; f < PBHC_MAX_FEET; ++f)
+            if (f < NF) { vh += fHd[f]; vhc += fHd[f] * cfl[f]; vo += fOri[f]; voc += fOri[f] * cfl[f]; }
+          raw = id == PBHC_R_FEET_HEADING_ALIGNMENT ? vh : (id == PBHC_R_FEET_HEADING_ALIGNMENT_CONTACT ? vhc : (id == PBHC_R_PENALTY_FEET_ORI ? vo : (id == PBHC_R_PENALTY_FEET_ORI_CONTACT ? voc : raw)));
+        }
 #undef TERM
         if (pf_tsrc < 0 && !is_special_term(id)) raw = 0.0f;     // (an id with neither a slot nor a formula: 0, as before)
         myrew = lane < c.num_terms ? raw * pf_tscale : 0.0f;

@@ -285,6 +285,8 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         if key not in K or (mode == 0 and name in V2_ONLY_TERMS):
             raise NotImplementedError(f"reward term {name!r} has no HIP implementation")
         c.term_id[i] = K[key]
+        if name in ("feet_heading_alignment", "feet_heading_alignment_contact", "penalty_feet_ori", "penalty_feet_ori_contact"):
+            c.foot_ori_terms = 1
         c.term_scale[i] = float(scales[name])
         c.term_penalty[i] = int(name in pen_names and bool(rw.reward_penalty_curriculum))
         c.term_sum_col[i] = L.sum_names.index(name)

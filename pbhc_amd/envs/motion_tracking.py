@@ -363,8 +363,35 @@ class LeggedRobotMotionTracking:
         io.episode_rew_out = p(self._episode_rew_out)
         io.totals_out = self._totals.data_ptr() if getattr(self, "_totals", None) is not None else None
         self._io = io
+        self._io_epoch = getattr(self, "_io_epoch", 0) + 1        # captured graphs of the step hold these addresses: a new epoch invalidates them
         self._overrides = {}
         self._replay_version = -1
+
+    def set_profiling(self, on=True):
+        """per-launch HIP event pairs on k_env_step (bench.py's roofline meter; read with pbhc_env_profile_read).  While it is on the step
+        launches through the hipExt call, which a stream capture cannot record: `rollout_graph_safe` says no."""
+        _lib.check(self._lib.pbhc_env_profile(self._env, 1 if on else 0), "pbhc_env_profile")
+        self._profiling = bool(on)
+
+    def rollout_graph_safe(self, num_steps):
+        """May the next `num_steps` control steps run as ONE captured graph?  Only if nothing in them needs the host: no per-step exchange of
+        the batch statistics (data-parallel "step" mode), no re-draw / motion-resample event due inside the window, no per-launch event
+        pairs, a replay window in place (the steps then read the frame index from the device-side cursor)."""
+        if getattr(self, "_profiling", False) or self._totals is not None or self.simulator.replay is None or self.reinit_epis_rand > 0:
+            return False
+        if self.config.get("resample_motion_when_training", False):
+            nxt = (self.common_step_counter // self.resample_time_interval + 1) * self.resample_time_interval
+            if nxt - self.common_step_counter <= num_steps:
+                return False
+        return True
+
+    def after_graph_steps(self, num_steps):
+        """host-side book-keeping of `num_steps` control steps that ran inside a graph replay"""
+        self.common_step_counter += num_steps
+        self._ref_bodies = None
+        self.extras.invalidate()
+        self.simulator.mark_step(-1)
+        self.extras["episode"] = EpisodeExtras(self)
 
     def set_eager_outputs(self, on=True):
         """Have the fused step STORE the optional outputs (rigid-body state, contact forces, reference bodies) instead of leaving them to be
@@ -378,6 +405,7 @@ class LeggedRobotMotionTracking:
             self._eager = None
         for k in ("rigid_body_state", "contact_forces", "ref_body_pos_extend", "ref_body_rot_extend"):
             setattr(self._io, k, self._eager[k].data_ptr() if on else None)
+        self._io_epoch += 1
 
     def set_obs_outputs(self, tensors):
         """Point the observation outputs of the next step(s) at caller-owned `[N, dim]` tensors (e.g. the rollout-buffer slab of
@@ -394,6 +422,7 @@ class LeggedRobotMotionTracking:
         """Keeps the tensors alive and points the kernel at them (None -> in-kernel RNG)."""
         self._overrides = dict(u_rfi=u_rfi, ovr_start_time=start_time, ovr_kp=kp, ovr_kd=kd, ovr_rfi_lim=rfi_lim, ovr_rao=rao, ovr_delay=delay,
                                ovr_dof_pos_bias=dof_pos_bias, ovr_gate_u=gate_u)
+        self._io_epoch += 1
         for k, v in self._overrides.items():
             setattr(self._io, k, None if v is None else v.data_ptr())
 
@@ -595,6 +624,7 @@ class LeggedRobotMotionTracking:
             io.frame_dof_vel, io.frame_contact = r["dof_vel"].data_ptr(), r["contact"].data_ptr()
             io.frame_cursor, io.num_frames = s.frame_cursor.data_ptr(), s.replay_len
             self._replay_version = s.replay_version
+            self._io_epoch += 1
         io.frame_index = s.take_host_frame()
         # _update_tasks_callback's re-draw of every env's episodic DR (legged_robot_base.py:390-395): decided on the host, done by the kernel
         # in this very step (after its torques, before its observations — where the reference does it)

@@ -148,6 +148,11 @@ class ReplaySimStub:
             self._host_frame = 0
             self.replay_version += 1
 
+    def use_device_cursor(self):
+        """from now on the fused step reads the frame index from the device-side cursor (which its reduction has been advancing all along):
+        what a captured graph of several steps needs — a frame index passed by value would be frozen into the graph"""
+        self._host_frame = -1
+
     def take_host_frame(self):
         """Frame index of the fused step about to be launched, by value (the step kernel advances the device cursor itself)."""
         k = self._host_frame

@@ -232,9 +232,11 @@ CASES = [("horse", "v1_g1_23dof_horse_stance.yaml"), ("walk", "v1_g1_23dof_walk.
 
 
 @pytest.mark.parametrize("tag,cfgname,overrides", [("walk_ctrlV", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "V"}),
-                                                   ("walk_ctrlT", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "T"})])
+                                                   ("walk_ctrlT", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "T"}),
+                                                   ("walk_feetori", "v1_g1_23dof_walk.yaml", {"rewards.reward_scales.feet_heading_alignment": -0.5, "rewards.reward_scales.feet_heading_alignment_contact": -0.3, "rewards.reward_scales.penalty_feet_ori": -0.2, "rewards.reward_scales.penalty_feet_ori_contact": -0.4})])
 def test_env_step_matches_reference_trace_of_a_switch(tag, cfgname, overrides):
-    """control types "V" and "T" (legged_robot_base.py:809-817; no shipped yaml uses them): the reference's own traces"""
+    """control types "V" and "T" (legged_robot_base.py:809-817) and the four foot-orientation reward terms (:1030-1079) — no shipped yaml uses
+    them: the reference's own traces with the switch on (oracle/ref_harness/gen_switch_golden.py)"""
     test_env_step_matches_reference_trace(tag, cfgname, overrides)
 
 
