@@ -260,7 +260,8 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
     algo.setup()
     T = algo.num_steps_per_env
     obs = env.reset_all()
-    frames = (K + max(W, 2)) * T + 2
+    E = 2                                                    # eager, per-launch-timed iterations after the timed region (the roofline meter)
+    frames = (K + max(W, 2) + E) * T + 2
     env.simulator.set_replay(*make_replay_on_device(env, frames, seed=99 + rank))
     algo._train_mode()
     from pbhc_amd import _lib
@@ -274,16 +275,15 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup, not measurement: the policy forward is captured into hipGraphs on the second rollout (the first runs eagerly so that
-    # GEMM solution selection sees every shape outside a capture) — make sure that has happened even when --warmup < 2
+    # setup, not measurement: the first rollout runs eagerly (GEMM solution selection sees every shape outside a capture), the second records
+    # the rollout's hipGraph — make sure both have happened even when --warmup < 2
     for _ in range(max(0, 2 - W)):
         obs = algo._rollout_step(obs)
         algo._training_step()
     for _ in range(W):
         obs = algo._rollout_step(obs)
         algo._training_step()
-    _lib.check(lib.pbhc_env_profile(env._env, 1))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (K + E))]
     sync()
     pdist.reset_counters()
     t0 = time.perf_counter()
@@ -295,6 +295,7 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
         ev[3 * i + 2].record()
     sync()
     dt = time.perf_counter() - t0
+    rollout_mode = "hipGraph" if getattr(algo, "_rollout_used_graph", False) else "eager"
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     coll = dict(pdist.COUNTERS)
     if dp:
@@ -302,10 +303,24 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
     dt = float(tmax)
     rollout_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K
     update_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / K
-    # --- roofline of the fused obs/reward step kernel: HIP events recorded by the library around k_env_step
+    # --- roofline of the fused obs/reward step kernel: a HIP event pair attached to each k_env_step dispatch.  A graph replay cannot carry
+    # per-launch events, so the meter runs right AFTER the timed region: E more iterations of the same workload with the rollout loop eager
+    # (env.set_profiling switches the step to the hipExt launch form, which `rollout_graph_safe` excludes from a capture) — the kernel, its
+    # inputs and its neighbours on the stream are the ones of the timed iterations; `eager` reports what those iterations took.
+    env.set_profiling(True)
+    te0 = time.perf_counter()
+    for i in range(K, K + E):
+        ev[3 * i].record()
+        obs = algo._rollout_step(obs)
+        ev[3 * i + 1].record()
+        algo._training_step()
+        ev[3 * i + 2].record()
+    sync()
+    eager_ms = (time.perf_counter() - te0) / E * 1e3
+    eager_rollout_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K, K + E)) / E
     buf = (C.c_float * 512)()
     cnt = C.c_int(0)
-    _lib.check(lib.pbhc_env_profile_read(env._env, buf, min(512, K * T), C.byref(cnt)))
+    _lib.check(lib.pbhc_env_profile_read(env._env, buf, min(512, E * T), C.byref(cnt)))
     kern_ms = sum(buf[i] for i in range(cnt.value)) / max(cnt.value, 1)      # the RAW event-pair reading: what roofline.achieved / frac use
     # what the dispatch-attached pair reads beyond a kernel's execution, from a kernel of known duration (a 20 us spin): published next to
     # the raw value, not subtracted from it (round 2 subtracted it and read 5-7 % below rocprofv3 of the same launches)
@@ -338,9 +353,13 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
             "config": {"workload": f"{N} envs/GPU, {WORKLOADS[workload]['desc']}" + (f", synthetic library of {clips} clips" if clips > 1 else "") +
                                    f", {T} steps/iter, 5 epochs x 4 minibatches; replay sim-stub tensors resident in HBM",
                        "envs_per_gpu": N, "global_envs": N * world, "num_steps_per_env": T, "parallelism": f"dp{world}"},
-            "rollout_ms": rollout_ms, "update_ms": update_ms,
+            "rollout_ms": rollout_ms, "update_ms": update_ms, "rollout_mode": rollout_mode,
+            "eager": {"ms_per_step": eager_ms, "rollout_ms": eager_rollout_ms, "steps": E,
+                      "note": "the same workload with the rollout loop launched step by step (PBHC_ROLLOUT_GRAPH=0 / while per-launch event pairs are on): "
+                              "the iterations the roofline meter below ran in, right after the timed region"},
             "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes() if (N == 4096 and workload == "v1_walk") else None, "kernel_ms": kern_ms, "kernel_ms_minus_event_overhead": max(kern_ms - ev_overhead_ms, 1e-6), "event_pair_overhead_ms": ev_overhead_ms, "launches_timed": cnt.value,
+                         "measured_in": f"{E} eager iterations right after the timed region (see `eager`)",
                          "kernel_specialised_to_config": bool(env.is_specialised),
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
                          "bytes_per_env_step_excl_cached_motion_rows": 4.0 * words},
@@ -380,6 +399,7 @@ def dp1_rehearsal(a, device, primary_ms):
         os.environ.pop("PBHC_DIST_FORCE", None)
     c = r["collectives"]
     return {"ms_per_step": r["ms_per_step"], "overhead_ms_per_iteration": r["ms_per_step"] - primary_ms, "rollout_ms": r["rollout_ms"], "update_ms": r["update_ms"],
+            "rollout_mode": r["rollout_mode"],
             "steps": 5, "warmup": 2, "backend": "nccl", "ranks": 1, "all_reduces_per_iter": c["all_reduces_per_iter"],
             "all_reduce_bytes_per_iter": c["all_reduce_bytes_per_iter"], "grad_allreduce_ms": c["grad_allreduce_ms"], "grad_bucket_bytes": c["grad_bucket_bytes"],
             "note": "one-rank RCCL group in the same process: the exchanges' launch / ordering cost without wire time (round 2: 65 all-reduces, +2.9 ms)"}

@@ -500,6 +500,9 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
                   float value_coef, float entropy_coef, int use_clipped_value_loss, float desired_kl, int adapt_lr, float* grad_mu, float* grad_value,
                   float* grad_std, float* scalars, float* lr, float* scratch, void* stream);
 int pbhc_ppo_loss_scratch_floats(int B);
+/* The same learning-rate rule on a KL mean already on the device (data-parallel update: the mean over all ranks, after the all-reduce):
+ * lr[i] <- rule(lr[i], *kl_mean) for i < n.  Reference: mh_ppo.py:455-466. */
+int pbhc_kl_lr_rule(float* lr, int n, const float* kl_mean, float desired_kl, void* stream);
 
 /* Backward of one MLP activation fused with the bias gradient of the layer below it (what autograd runs as elu_backward /
  * silu_backward + a column sum, agents/modules/modules.py:47-63 under torch.autograd): dz = dy * act'(saved), grad_bias = colsum(dz).

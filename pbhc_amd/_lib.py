@@ -90,7 +90,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
            "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
-           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize"]
+           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule"]
 
 
 class PbhcError(RuntimeError):
@@ -130,6 +130,7 @@ def _load():
     lib.pbhc_env_profile_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.pbhc_ppo_loss.argtypes = [vp] * 10 + [i, i, i, f, f, f, i, f, i] + [vp] * 6 + [vp]
     lib.pbhc_ppo_loss_scratch_floats.argtypes = [i]
+    lib.pbhc_kl_lr_rule.argtypes = [vp, i, vp, f, vp]
     lib.pbhc_act_bwd_bias.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
     lib.pbhc_act_bwd_partials.argtypes = [vp, vp, i, i, i, vp, vp, C.POINTER(C.c_int), vp]
     lib.pbhc_colsum_final.argtypes = [vp, i, vp]

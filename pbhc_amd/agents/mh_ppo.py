@@ -476,35 +476,62 @@ class MHPPO:
                 steps = sc[1]
                 std_p, sum_p, len_p, stat_p, gamma = std.data_ptr(), self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
                 br_h = br.cuda_stream
-                br.wait_stream(cur)
-                for t in range(T):
-                    sp = steps[t]
-                    if not batched:
-                        with torch.cuda.stream(br):
-                            st.values[t].copy_(critic_fwd(t))
-                    mu = actor_fwd(t)
-                    if split and t > 0:
-                        cur.wait_event(post_done)          # reduction + book-keeping kernel of step t-1 (13 us of work, issued ~60 us ago)
-                        env.finalize_joined()
-                    if not fuse_sample:
-                        _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
-                    env.set_obs_outputs(sp["obs_out"])
-                    nxt, rewards, dones, infos = env.step(sp["act"])
-                    if self._need_next:
-                        for k in keys:
-                            getattr(st, "next_" + k)[t].copy_(nxt[k])
-                    if split:
-                        # branch: [reduction of step t, queued by env.step] -> done / episode-statistics kernel of step t (per-step critic: values[t]
-                        # were produced earlier on this stream and the bootstrap is added here) -> critic of slab t+1 (next iteration)
-                        _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), None if batched else sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                          gamma, *sp["post"], sum_p, len_p, stat_p, sp["tout"], br_h), "pbhc_rollout_post2")
-                        post_done.record(br)
-                    else:
-                        cur.wait_stream(br)
-                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                         gamma, *sp["post"], sum_p, len_p, stat_p, stream), "pbhc_rollout_post")
-                        br.wait_stream(cur)
-                cur.wait_stream(br)
+                post_done = [post_done]                  # (a cell: the capture below swaps the event it used for a fresh one)
+
+                def run_loop(cur, actor_call):
+                    stream = cur.cuda_stream
+                    br.wait_stream(cur)
+                    for t in range(T):
+                        sp = steps[t]
+                        if not batched:
+                            with torch.cuda.stream(br):
+                                st.values[t].copy_(critic_fwd(t))
+                        mu = actor_call(t)
+                        if split and t > 0:
+                            cur.wait_event(post_done[0])          # reduction + book-keeping kernel of step t-1 (13 us of work, issued ~60 us ago)
+                            env.finalize_joined()
+                        if not fuse_sample:
+                            _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), std_p, None, N, A, R, self._sample_seed, counter, *sp["sample"], None, stream), "pbhc_policy_sample")
+                        env.set_obs_outputs(sp["obs_out"])
+                        nxt, rewards, dones, infos = env.step(sp["act"])
+                        if self._need_next:
+                            for k in keys:
+                                getattr(st, "next_" + k)[t].copy_(nxt[k])
+                        if split:
+                            # branch: [reduction of step t, queued by env.step] -> done / episode-statistics kernel of step t (per-step critic: values[t]
+                            # were produced earlier on this stream and the bootstrap is added here) -> critic of slab t+1 (next iteration)
+                            _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), None if batched else sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                              gamma, *sp["post"], sum_p, len_p, stat_p, sp["tout"], br_h), "pbhc_rollout_post2")
+                            post_done[0].record(br)
+                        else:
+                            cur.wait_stream(br)
+                            _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
+                                                             gamma, *sp["post"], sum_p, len_p, stat_p, stream), "pbhc_rollout_post")
+                            br.wait_stream(cur)
+                    cur.wait_stream(br)
+
+                # ONE hipGraph for the whole loop (PBHC_ROLLOUT_GRAPH=0: the eager loop above all): T x (policy stack + sampling, fused env step,
+                # its reduction and the done / episode-statistics kernel on the branch stream) with fork / join edges instead of stream events
+                # and 4 dispatch gaps per step — the steps read the replay frame from the device-side cursor, their addresses (rollout slabs)
+                # are fixed, and the env's host-side events (DR re-draw, motion resample) are checked for the whole window before
+                # (`rollout_graph_safe`); a rollout that contains one, or that is being timed launch by launch, runs eagerly.
+                graph_ok = (os.environ.get("PBHC_ROLLOUT_GRAPH", "1") != "0" and split and batched and fuse_sample and not self._need_next
+                            and self.__dict__.get("_rollouts_done", 0) >= 1 and not self.__dict__.get("_rollout_graph_failed", False)
+                            and hasattr(env, "rollout_graph_safe") and env.rollout_graph_safe(T))
+                ran = False
+                if graph_ok:
+                    env.simulator.use_device_cursor()
+                    key = (id(st), env._io_epoch, N, T)
+                    gc = self.__dict__.get("_rollout_graph")
+                    if gc is None or gc[0] != key:
+                        gc = self._capture_rollout(key, run_loop, actor_eager, env, post_done, T)
+                    if gc is not None:
+                        gc[1].replay()
+                        env.after_graph_steps(T)
+                        ran = True
+                self._rollout_used_graph = ran
+                if not ran:
+                    run_loop(cur, actor_fwd)
                 if split:
                     env.set_finalize_stream(None)
             finally:
@@ -518,11 +545,43 @@ class MHPPO:
                 st.values.copy_(vals[:T])
                 st.rewards.addcmul_(st.values, self._time_outs.to(torch.float32), value=float(self.gamma))
             st.step = T
+            self._rollouts_done = self.__dict__.get("_rollouts_done", 0) + 1
             if self._dp and self._stat_mode == "rollout":
                 env.sync_globals()                     # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()
             self._compute_returns(self._last_obs, last_values=vals[T] if batched else None)
         return self._last_obs
+
+    def _capture_rollout(self, key, run_loop, actor_eager, env, post_done, T):
+        """record the rollout loop into one hipGraph (nothing executes during the capture: the caller replays it).  On any failure the agent
+        stays on the eager loop for good."""
+        g = torch.cuda.CUDAGraph()
+        side = self.__dict__.setdefault("_graph_stream", torch.cuda.Stream(device=self.device))
+        counter0 = env.common_step_counter
+        try:
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                # thread_local: the RCCL watchdog thread polls its events while we capture; only this thread's calls are policed
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    run_loop(side, actor_eager)
+            torch.cuda.current_stream().wait_stream(side)
+        except Exception as e:                                   # noqa: BLE001 (whatever the capture objects to: report once, go on eagerly)
+            print(f"[pbhc] rollout graph capture failed ({type(e).__name__}: {e}); the rollout stays eager")
+            self._rollout_graph_failed = True
+            self._rollout_graph = None
+            g = None
+        finally:
+            # the env's and the loop's events were recorded INSIDE the capture: they are edges of the graph now, not events a later eager
+            # step may wait on; the host-side counters the captured env.step() calls advanced are advanced again after every replay
+            env.common_step_counter = counter0
+            env._step_done, env._fin_done, env._fin_pending = torch.cuda.Event(), torch.cuda.Event(), False
+            post_done[0] = torch.cuda.Event()
+            self._post_done = post_done[0]
+        if g is None:
+            return None
+        self._rollout_graph = (key, g)
+        return self._rollout_graph
 
     def _compute_returns(self, last_obs_dict, last_values=None):
         """mh_ppo.py:348-395 in one HIP pass over the [T,N,R] slab."""
@@ -620,8 +679,8 @@ class MHPPO:
             else:
                 torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
                 pdist.allreduce_mean_(self._gflat[:na + nc + 1])
-            if adapt:
-                pdist.kl_lr_rule_(self._lr, self._gflat[na + nc], self.desired_kl, reduced=True)
+            if adapt:                                    # the rule on the all-rank KL mean: one launch (pdist.kl_lr_rule_ is its host-tensor form)
+                _lib.check(lib.pbhc_kl_lr_rule(self._lr.data_ptr(), 2, self._gflat[na + nc:].data_ptr(), float(self.desired_kl), st), "pbhc_kl_lr_rule")
         else:
             if two:
                 br.wait_stream(cur)                      # the loss kernel's gradients are ready for the critic's backward on its stream

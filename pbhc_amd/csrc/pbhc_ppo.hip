@@ -661,6 +661,25 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream) {
   return PBHC_OK;
 }
 
+// The adaptive-KL learning-rate rule (mh_ppo.py:455-466) on a KL mean that is ready on the device — the data-parallel update applies it to
+// the mean over ALL ranks, which exists only after the gradient bucket's all-reduce; as eight tiny torch launches it was 40 us of every
+// optimiser step.  Same arithmetic as the rule inside k_ppo_reduce.
+__global__ void k_kl_lr_rule(float* __restrict__ lr, int n, const float* __restrict__ kl_mean_p, float desired_kl) {
+  if (threadIdx.x < n) {
+    const float kl_mean = kl_mean_p[0];
+    float l = lr[threadIdx.x];                                   // each rate from its own value (mh_ppo.py:457-461)
+    if (kl_mean > desired_kl * 2.0f) l = fmaxf(1e-5f, l / 1.5f);
+    else if (kl_mean < desired_kl / 2.0f && kl_mean > 0.0f) l = fminf(1e-2f, l * 1.5f);
+    lr[threadIdx.x] = l;
+  }
+}
+int pbhc_kl_lr_rule(float* lr, int n, const float* kl_mean, float desired_kl, void* stream) {
+  ARG_CHECK(lr && kl_mean && n >= 1 && n <= 64);
+  hipLaunchKernelGGL(k_kl_lr_rule, dim3(1), dim3(64), 0, (hipStream_t)stream, lr, n, kl_mean, desired_kl);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
 int pbhc_ppo_loss_scratch_floats(int B) { return ((B + LOSS_ROWS - 1) / LOSS_ROWS) * (LOSS_NP + 32); }
 
 static void adam_fill(AdamSegs& S, int k, float* param, float* grad, float* m, float* v, int n, const float* lr, float* step, double* scratch, float* norm_out) {

@@ -617,10 +617,11 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
-def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True):
+def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True, rollout_graph=False, rollouts=3):
     """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state"""
     import os
 
+    os.environ["PBHC_ROLLOUT_GRAPH"] = "1" if rollout_graph else "0"
     os.environ["PBHC_ROLLOUT_SPLIT"] = "1" if split else "0"
     os.environ["PBHC_CRITIC_BATCHED"] = "1" if batched else "0"
     os.environ["PBHC_FUSED_SAMPLE"] = "1" if fused_sample else "0"
@@ -640,12 +641,19 @@ def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True):
             algo.setup()
         algo._train_mode()
         obs = env.reset_all()
-        for _ in range(3):
+        if rollout_graph or rollouts > 3:                      # a replay window (the graph's steps read the device-side frame cursor)
+            import bench
+
+            env.simulator.set_replay(*bench.make_replay_on_device(env, rollouts * algo.num_steps_per_env + 2, seed=5))
+        for _ in range(rollouts):
             algo.storage.clear()
             obs = algo._rollout_step(obs)
         torch.cuda.synchronize()
         st = algo.storage
         out = {k: getattr(st, k).clone() for k in st.stored_keys}
+        out["_used_graph"] = torch.tensor([bool(getattr(algo, "_rollout_used_graph", False))])
+        out["common_step_counter"] = torch.tensor([env.common_step_counter])
+        out["frame_cursor"] = env.simulator.frame_cursor.clone().cpu()
         out["globals"] = env.globals.clone()
         out["episode_sums"] = env._episode_sums.clone()
         out["ep_stats"] = algo._ep_stats.clone()
@@ -653,6 +661,7 @@ def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True):
             out["_time_outs_seen"] = algo._time_outs.any().reshape(1)
         return out
     finally:
+        os.environ.pop("PBHC_ROLLOUT_GRAPH", None)
         os.environ.pop("PBHC_ROLLOUT_SPLIT", None)
         os.environ.pop("PBHC_CRITIC_BATCHED", None)
         os.environ.pop("PBHC_FUSED_SAMPLE", None)
@@ -665,6 +674,18 @@ def test_rollout_branch_stream_equals_one_stream(agent):
     statistics are bit-identical to the one-stream order (mh_ppo.py:270-342, ppo_mimic.py:371-438)."""
     a = _rollouts_with_split(True, agent)
     b = _rollouts_with_split(False, agent)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_rollout_as_one_graph_equals_the_eager_loop():
+    """MHPPO's default rollout replays ONE hipGraph for the 24 control steps (policy stack + sampling, fused env step, its reduction, the
+    done / episode-statistics kernel; frame index from the device-side cursor): a schedule, not arithmetic — after five rollouts (eager,
+    capture + replay, three replays) every buffer, the env's globals / episode sums, the episode statistics, the step counter and the replay
+    cursor are bit-identical to the step-by-step loop."""
+    a = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=True, rollouts=5)
+    b = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=False, rollouts=5)
+    assert bool(a.pop("_used_graph")) and not bool(b.pop("_used_graph"))
     for k in a:
         assert torch.equal(a[k], b[k]), k
 

@@ -31,7 +31,7 @@ if os.environ.get("PBHC_PROBE_EAGER_OUTPUTS", "0") == "1":
 act = torch.zeros(N, env.num_dof, device="cuda:0")
 for _ in range(20):
     env.step({"actions": act})
-_lib.check(lib.pbhc_env_profile(env._env, 1))
+env.set_profiling(True)
 for _ in range(100):
     env.step({"actions": act})
 if os.environ.get("PBHC_PROBE_RESET_WG0", "0") == "1":       # the stamped workgroup's env 0 times out in the last launch: phase stamps of the reset path
