@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 7
+#define PBHC_ABI_VERSION 8
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -494,11 +494,12 @@ int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, co
  * (mh_ppo.py:455-466) to lr[0] (actor) and lr[1] (critic) on the device; bit 1: the KL of ppo_mimic.py:621-628
  * (log(sigma / (old_sigma + 1e-5)) instead of log(sigma / old_sigma + 1e-5)).  `std` is the sigma vector the distribution used
  * (mh_ppo: the parameter; ppo_mimic: clamp(std, min_sigma, max_sigma), the caller masks grad_std accordingly).
- * scratch: pbhc_ppo_loss_scratch_floats(B) floats. */
+ * scalars_acc (may be NULL): float[4], scalars_acc[i] += scalars[i] — the running sums behind the iteration's mean losses
+ * (mh_ppo.py:412-417 `mean_value_loss += ...`) without a launch of their own.  scratch: pbhc_ppo_loss_scratch_floats(B) floats. */
 int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
                   const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,
                   float value_coef, float entropy_coef, int use_clipped_value_loss, float desired_kl, int adapt_lr, float* grad_mu, float* grad_value,
-                  float* grad_std, float* scalars, float* lr, float* scratch, void* stream);
+                  float* grad_std, float* scalars, float* scalars_acc, float* lr, float* scratch, void* stream);
 int pbhc_ppo_loss_scratch_floats(int B);
 /* The same learning-rate rule on a KL mean already on the device (data-parallel update: the mean over all ranks, after the all-reduce):
  * lr[i] <- rule(lr[i], *kl_mean) for i < n.  Reference: mh_ppo.py:455-466. */
@@ -538,6 +539,12 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
  *   pre[M,N] (may be NULL) = x . w^T + bias            the pre-activation, which SiLU's derivative needs
  * x, w row-major, contiguous (rows need 4-byte alignment only).  f32 in, f32 accumulate (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
 int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, void* stream);
+/* The stack's last hidden layer AND its narrow output layer in one launch (the tail `Linear(K,128) - act - Linear(128,NO)` of modules.py:47-63's
+ * nn.Sequential: 23 action means / 20 value heads): y, pre as above with N = 128, and out[M, NO] = y . w_out[NO,128]^T + b_out[NO] (b_out may be
+ * NULL) computed from the tile's activated rows while they are in LDS (32-row tiles hold whole rows) — replaces the library addmm of the
+ * output layer (14 / 9 us of launch for 0.14 GFLOP at 24 576 rows).  NO <= 32, K >= 4; out rows contiguous. */
+int pbhc_linear_act_fwd_out(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, const float* w_out,
+                            const float* b_out, int NO, float* out, void* stream);
 /* The same with row strides and a batch: batch b computes y[b] = act(x[b] . w^T + bias) with x[b] = x + b * x_batch_stride (rows lda floats
  * apart, lda >= K), y[b] = y + b * y_batch_stride (rows ldc floats apart, ldc >= N), one weight matrix for all — e.g. the L output positions of
  * nn.Conv1d(C -> O, kernel k, stride s) on time-major activations [B, T, C] (encoder_modules.py:60-107): window l is the [B, k*C] matrix at
@@ -600,9 +607,11 @@ void pbhc_gemm_debug_force_shape(int shape);
 int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n, const float* lr, float* step, float max_norm, float beta1,
                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
 /* Two consecutive segments (actor [0,n0), critic [n0,n0+n1): MHPPO's two clip_grad_norm_ + two Adam steps, mh_ppo.py:519-524) in ONE launch
- * pair: lr, step, norm_out are 2-element device arrays, scratch 2 x 512 doubles; each segment is clipped by its own norm. */
+ * pair: lr, step, norm_out are 2-element device arrays, scratch 2 x 512 doubles; each segment is clipped by its own norm.
+ * zero_grad != 0: the gradient buffer is left ZEROED instead of holding the clipped gradients (the next optimiser step's
+ * `optimizer.zero_grad()`, mh_ppo.py:513-514, done by the pass that read the gradients last: no fill launch of its own). */
 int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n0, int n1, const float* lr, float* step, float max_norm, float beta1,
-                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream);
+                    float beta2, float eps, float weight_decay, int zero_grad, double* scratch, float* norm_out, void* stream);
 
 /* Test-only: the device functions of csrc/pbhc_math.h (the quaternion / rotation algebra every kernel inlines; SURVEY 8 row a1:
  * isaac_utils/rotations.py:28-669, utils/torch_utils.py:51-79,239-296) applied elementwise, so that they can be pinned directly against

@@ -88,7 +88,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
-           "pbhc_linear_act_fwd", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
+           "pbhc_linear_act_fwd", "pbhc_linear_act_fwd_out", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
            "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule"]
 
@@ -128,7 +128,7 @@ def _load():
     lib.pbhc_env_profile.argtypes = [vp, i]
     lib.pbhc_env_profile_read.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(C.c_int)]
     lib.pbhc_env_profile_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
-    lib.pbhc_ppo_loss.argtypes = [vp] * 10 + [i, i, i, f, f, f, i, f, i] + [vp] * 6 + [vp]
+    lib.pbhc_ppo_loss.argtypes = [vp] * 10 + [i, i, i, f, f, f, i, f, i] + [vp] * 7 + [vp]
     lib.pbhc_ppo_loss_scratch_floats.argtypes = [i]
     lib.pbhc_kl_lr_rule.argtypes = [vp, i, vp, f, vp]
     lib.pbhc_act_bwd_bias.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp]
@@ -136,6 +136,7 @@ def _load():
     lib.pbhc_colsum_final.argtypes = [vp, i, vp]
     lib.pbhc_linear_out_bwd.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, C.POINTER(C.c_int), vp]
     lib.pbhc_linear_act_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    lib.pbhc_linear_act_fwd_out.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp, i, vp, vp]
     lib.pbhc_linear_dgrad_act.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int), i, i, i, i, vp]
     lib.pbhc_gemm_debug_force_shape.argtypes = [i]
     lib.pbhc_linear_wgrad_parts.argtypes = [i, i, i]
@@ -150,7 +151,7 @@ def _load():
     lib.pbhc_mlp_packed_floats.restype = C.c_size_t
     lib.pbhc_gemm_debug_force_shape.restype = None
     lib.pbhc_adam_clip.argtypes = [vp, vp, vp, vp, i, vp, vp, f, f, f, f, f, vp, vp, vp]
-    lib.pbhc_adam_clip2.argtypes = [vp, vp, vp, vp, i, i, vp, vp, f, f, f, f, f, vp, vp, vp]
+    lib.pbhc_adam_clip2.argtypes = [vp, vp, vp, vp, i, i, vp, vp, f, f, f, f, f, i, vp, vp, vp]
     lib.pbhc_policy_sample.argtypes = [vp, vp, vp, i, i, i, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.pbhc_rollout_post.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp]
     lib.pbhc_rollout_post2.argtypes = [vp, vp, vp, vp, i, i, f, vp, vp, vp, vp, vp, vp, vp]

@@ -104,6 +104,40 @@ def _wgrad_library(d, x, out, defer=None):
     return torch.sum(part, 0, out=out)
 
 
+# ---- the backward's finishing launch, shared ----------------------------------------------------------------------------------------------
+# Every fused backward ends in ONE `pbhc_colsum_final` (bias gradients, the output layer's weight gradient, split-K partials): a latency-bound
+# launch of ~16 us.  An owner that runs several stacks' backwards back to back on one stream (MHPPO: critic, then actor) brackets them with
+# begin_deferred_finish() / finish_deferred(): stacks whose gradients are STORED (grad_direct) then hand their jobs — and the scratch tensors
+# the jobs read — to a pending list, and one launch per PBHC_MAX_COLSUM_JOBS jobs finishes them all.  Stacks that return gradients to autograd
+# finish at once as before (autograd may consume their outputs right after backward returns).
+_DEFER = {"on": False, "jobs": [], "keep": []}
+
+
+def begin_deferred_finish():
+    _DEFER["on"] = True
+
+
+def _launch_jobs(job_list, st):
+    MAXJ = _lib.K["PBHC_MAX_COLSUM_JOBS"]
+    lib = _lib.lib()
+    for k in range(0, len(job_list), MAXJ):
+        chunk = job_list[k:k + MAXJ]
+        jobs = (_lib._S["PbhcColsumJob"] * MAXJ)()
+        for j, (part, out, nrb, n) in zip(jobs, chunk):
+            j.part, j.out, j.num_row_blocks, j.n = part, out, nrb, n
+        _lib.check(lib.pbhc_colsum_final(jobs, len(chunk), st), "pbhc_colsum_final")
+
+
+def finish_deferred():
+    """launch what the backwards since begin_deferred_finish() left pending (current stream = the stream those backwards ran on)"""
+    _DEFER["on"] = False
+    job_list, keep = _DEFER["jobs"], _DEFER["keep"]
+    _DEFER["jobs"], _DEFER["keep"] = [], []
+    if job_list:
+        _launch_jobs(job_list, _lib.current_stream())
+    del keep
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, seq, *params):
@@ -114,12 +148,27 @@ class _FusedMLP(torch.autograd.Function):
         fused = FUSED_GEMM and act in (1, 2, 3) and h.is_cuda and h.dtype == torch.float32
         if fused:
             lib, st = _lib.lib(), _lib.current_stream()
+        out = None
         for i, l in enumerate(lin):
             saved_in.append(h)
+            if out is not None:                        # the output layer already ran in the epilogue of the layer below
+                continue
             if fused and i < len(lin) - 1 and l.weight.is_contiguous():
                 B = h.shape[0]
                 z = torch.empty(B, l.out_features, device=h.device)
                 pre = torch.empty_like(z) if act == 2 else None          # SiLU' needs the pre-activation; ELU' / ReLU' come from the output
+                lo = lin[-1]
+                if (FWD_OUT and i == len(lin) - 2 and l.out_features == 128 and lo.out_features <= 32 and l.in_features >= 4 and lo.weight.is_contiguous()
+                        and 8192 <= B <= 32 * _lib.K["PBHC_ACT_MAX_BLOCKS"]):
+                    # 32-row tiles hold whole 128-wide rows: the narrow output layer is applied to them while they are in LDS
+                    out = torch.empty(B, lo.out_features, device=h.device)
+                    _lib.check(lib.pbhc_linear_act_fwd_out(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(),
+                                                           pre.data_ptr() if pre is not None else None, B, 128, l.in_features, act, lo.weight.data_ptr(),
+                                                           lo.bias.data_ptr() if lo.bias is not None else None, lo.out_features, out.data_ptr(), st),
+                               "pbhc_linear_act_fwd_out")
+                    h = z
+                    saved_act.append(pre if pre is not None else h)
+                    continue
                 _lib.check(lib.pbhc_linear_act_fwd(h.data_ptr(), l.weight.data_ptr(), l.bias.data_ptr() if l.bias is not None else None, z.data_ptr(),
                                                    pre.data_ptr() if pre is not None else None, B, l.out_features, l.in_features, act, st), "pbhc_linear_act_fwd")
                 h = z
@@ -154,15 +203,12 @@ class _FusedMLP(torch.autograd.Function):
         ins, acts = saved[:L], saved[L:]
         d = dout.contiguous()
         B = d.shape[0]
-        if L > _lib.K["PBHC_MAX_COLSUM_JOBS"]:
-            raise _lib.PbhcError("fused MLP backward: too many layers")
         widths = [l.out_features for l in lin]
         MAXB = _lib.K["PBHC_ACT_MAX_BLOCKS"]
         scratch = torch.empty(MAXB * sum(widths), device=d.device)       # per-layer row-block column sums, finished by ONE launch below
-        MAXJ = _lib.K["PBHC_MAX_COLSUM_JOBS"]
-        jobs = (_lib._S["PbhcColsumJob"] * MAXJ)()                  # one per layer's bias gradient (+ the output layer's weight gradient, + the
-        njobs = L                                                   # split-K partials of the hidden layers' weight gradients)
-        deferred = []
+        jobs = []                                                   # (part, out, row blocks, n): one per layer's bias gradient, + the output layer's
+        deferred = []                                               # weight gradient, + the split-K partials of the hidden layers' weight gradients
+        keep = [scratch]
         nb = C.c_int(0)
         ret_w = []
         off = 0
@@ -190,7 +236,7 @@ class _FusedMLP(torch.autograd.Function):
             part = scratch[offs[i]:offs[i] + MAXB * n]
             k_in = l.in_features
             if (i == L - 1 and i > 0 and ctx.fused and OUT_BWD and ctx.act in (1, 3) and 8 < n <= 32 and k_in in (64, 128, 192, 256) and l.weight.is_contiguous()
-                    and ins[i].is_contiguous() and L + 1 <= _lib.K["PBHC_MAX_COLSUM_JOBS"]):
+                    and ins[i].is_contiguous()):
                 # the narrow output layer: weight / bias / input gradient and the activation backward of the layer below in ONE pass over the rows
                 # (ELU / ReLU stacks with 9..32 outputs: measured slower than the four launches on the general-tracking agent's SiLU stacks,
                 # whose derivative needs a second row stream and an exp per element — 58 / 45 us for 29 / 1 outputs)
@@ -202,11 +248,9 @@ class _FusedMLP(torch.autograd.Function):
                 _lib.check(lib.pbhc_linear_out_bwd(d.data_ptr(), ins[i].data_ptr(), None if saved.data_ptr() == ins[i].data_ptr() else saved.data_ptr(),
                                                    l.weight.data_ptr(), B, n, k_in, ctx.act, dn.data_ptr(), part_dw.data_ptr(), part.data_ptr(),
                                                    scratch[offs[i - 1]:].data_ptr(), C.byref(nb), st), "pbhc_linear_out_bwd")
-                j = jobs[L - 1 - i]
-                j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
-                j = jobs[L]
-                j.part, j.out, j.num_row_blocks, j.n = part_dw.data_ptr(), gw.data_ptr(), nb.value, n * k_in
-                njobs = L + 1
+                jobs.append((part.data_ptr(), gb.data_ptr(), nb.value, n))
+                jobs.append((part_dw.data_ptr(), gw.data_ptr(), nb.value, n * k_in))
+                keep += [part_dw, gw, gb]
                 ret_w.append((None, None) if direct else (gw, gb))
                 d = dn
                 have_partials = True
@@ -214,9 +258,9 @@ class _FusedMLP(torch.autograd.Function):
             if not have_partials:
                 _lib.check(lib.pbhc_act_bwd_partials(d.data_ptr(), acts[i].data_ptr() if i < L - 1 else None, B, n, ctx.act if i < L - 1 else 0, d.data_ptr(),
                                                      part.data_ptr(), C.byref(nb), st), "pbhc_act_bwd_partials")
-            j = jobs[L - 1 - i]
-            j.part, j.out, j.num_row_blocks, j.n = part.data_ptr(), gb.data_ptr(), nb.value, n
-            room = deferred if (njobs + len(deferred) + 2 <= MAXJ) else None      # (+ the output layer's own extra job)
+            jobs.append((part.data_ptr(), gb.data_ptr(), nb.value, n))
+            keep.append(gb)
+            room = deferred
             if direct:
                 _wgrad(d, ins[i], l.weight.grad, room)
                 ret_w.append((None, None))
@@ -234,10 +278,13 @@ class _FusedMLP(torch.autograd.Function):
             elif i > 0 or ctx.needs_input_grad[0]:
                 d = d @ l.weight
         for part_w, out_w in deferred:                              # [P, n, k] partials -> the weight gradient: the same fixed-order column sum
-            j = jobs[njobs]
-            j.part, j.out, j.num_row_blocks, j.n = part_w.data_ptr(), out_w.data_ptr(), part_w.shape[0], out_w.numel()
-            njobs += 1
-        _lib.check(lib.pbhc_colsum_final(jobs, njobs, st), "pbhc_colsum_final")
+            jobs.append((part_w.data_ptr(), out_w.data_ptr(), part_w.shape[0], out_w.numel()))
+            keep += [part_w, out_w]
+        if _DEFER["on"] and may_direct and all(gw is None for gw, _ in ret_w):
+            _DEFER["jobs"] += jobs                                  # every gradient is stored in place: the owner's finish_deferred() launches
+            _DEFER["keep"] += keep
+        else:
+            _launch_jobs(jobs, st)
         if ctx.live is not None:
             seq._fused_live.discard(ctx.live)
             ctx.live = None
@@ -251,6 +298,7 @@ class _FusedMLP(torch.autograd.Function):
 
 
 OUT_BWD = os.environ.get("PBHC_FUSED_OUT_BWD", "1") != "0"
+FWD_OUT = os.environ.get("PBHC_FUSED_FWD_OUT", "1") != "0"
 FUSED_STACK = os.environ.get("PBHC_FUSED_STACK", "1") != "0"
 _STACK_MAX_ROWS = int(os.environ.get("PBHC_FUSED_STACK_MAX_ROWS", "16384"))
 

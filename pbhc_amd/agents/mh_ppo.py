@@ -303,7 +303,9 @@ class MHPPO:
         """zero the flat gradient buffer and tell the declared stacks (their next backward may store instead of accumulate)"""
         from . import fused_mlp
 
-        self._gflat.zero_()
+        if not getattr(self, "_gflat_clean", False):      # (clean: the last Adam pass left it zeroed and nothing has written it since)
+            self._gflat.zero_()
+        self._gflat_clean = False
         for q in self._direct_stacks:
             fused_mlp.grads_zeroed(q)
 
@@ -660,7 +662,7 @@ class MHPPO:
                                      b["values"].data_ptr(), B, self.num_act, self.num_rew_fn, float(self.clip_param), float(self.value_loss_coef),
                                      float(self.entropy_coef), int(self.use_clipped_value_loss), float(self.desired_kl or 0.0), on_device_lr,
                                      self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._gflat[so:so + sn].data_ptr(), self._loss_scalars.data_ptr(),
-                                     self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
+                                     loss["_acc"].data_ptr() if "_acc" in loss else None, self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
         na, nc = self._n_actor, self._n_critic
         if self._dp:
             # ONE all-reduce per optimiser step (north_star: "a single RCCL all-reduce of policy gradients per PPO update"): actor + critic
@@ -677,25 +679,36 @@ class MHPPO:
                 h_a.wait(); h_c.wait()
                 self._gflat.div_(self.world_size)
             else:
-                torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+                self._backward_both(mu, value)
                 pdist.allreduce_mean_(self._gflat[:na + nc + 1])
             if adapt:                                    # the rule on the all-rank KL mean: one launch (pdist.kl_lr_rule_ is its host-tensor form)
                 _lib.check(lib.pbhc_kl_lr_rule(self._lr.data_ptr(), 2, self._gflat[na + nc:].data_ptr(), float(self.desired_kl), st), "pbhc_kl_lr_rule")
         else:
             if two:
                 br.wait_stream(cur)                      # the loss kernel's gradients are ready for the critic's backward on its stream
-            torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
-            if two:
+                torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
                 cur.wait_stream(br)
-        # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm)
+            else:
+                self._backward_both(mu, value)
+        # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm); the pass
+        # leaves the gradient buffer zeroed — the next step's zero_grad()
         _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
                                        self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
-                                       self.adam_eps, 0.0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
-        if "_acc" in loss:
-            loss["_acc"].add_(self._loss_scalars)
-        else:
+                                       self.adam_eps, 0.0, 1, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
+        self._gflat_clean = True
+        if "_acc" not in loss:                            # ("_acc": summed by the loss kernel's finishing block)
             loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         return loss
+
+    def _backward_both(self, mu, value):
+        """both networks' backward on this stream, their finishing column-sum launches merged into one (fused_mlp.finish_deferred)"""
+        from . import fused_mlp
+
+        fused_mlp.begin_deferred_finish()
+        try:
+            torch.autograd.backward([mu, value], [self._grad_mu, self._grad_value])
+        finally:
+            fused_mlp.finish_deferred()
 
     def _update_ppo_eager(self, b, loss):
         """Eager PyTorch form of the update (used only for the optional L2C2 regulariser, mh_ppo.py:488-507)."""
@@ -743,7 +756,7 @@ class MHPPO:
         # both networks' clip_grad_norm_ + Adam in one launch pair (two segments of the flat buffers, each clipped by its own norm)
         _lib.check(lib.pbhc_adam_clip2(self._pflat.data_ptr(), self._gflat.data_ptr(), self._mflat.data_ptr(), self._vflat.data_ptr(), na, nc,
                                        self._lr.data_ptr(), self._adam_step.data_ptr(), float(self.max_grad_norm), self.betas[0], self.betas[1],
-                                       self.adam_eps, 0.0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
+                                       self.adam_eps, 0.0, 0, self._adam_scratch.data_ptr(), self._grad_norms.data_ptr(), st), "pbhc_adam_clip2")
         with torch.no_grad():
             loss["Value"] += value_loss.detach(); loss["Surrogate"] += surrogate.detach(); loss["Entropy"] += entropy_loss.detach()
             loss["L2C2_Value"] += l2c2_v.detach(); loss["L2C2_Policy"] += l2c2_p.detach()

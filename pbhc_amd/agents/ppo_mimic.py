@@ -558,7 +558,7 @@ class PPO:
                                      b["values"].data_ptr(), B, self.num_act, self.num_rew_fn, float(self.clip_param), float(self.value_loss_coef),
                                      float(self.entropy_coef), int(self.use_clipped_value_loss), float(self.desired_kl or 0.0), flags,
                                      self._grad_mu.data_ptr(), self._grad_value.data_ptr(), self._g_sigma.data_ptr(), self._loss_scalars.data_ptr(),
-                                     self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
+                                     loss["_acc"].data_ptr() if "_acc" in loss else None, self._lr.data_ptr(), self._loss_scratch.data_ptr(), st), "pbhc_ppo_loss")
         heads, grads = [mu, value], [self._grad_mu, self._grad_value]
         if coef != 0.0:
             heads.append(priv_reg * coef)
@@ -574,7 +574,7 @@ class PPO:
             pdist.allreduce_mean_(self._gflat[: self._n_main])
         self._adam(0, 0, self._n_main, self._lr[0:1])
         if "_acc" in loss:
-            loss["_acc"].add_(self._loss_scalars)
+            pass                                           # (summed by the loss kernel's finishing block)
         else:
             loss["Value"] += self._loss_scalars[1]; loss["Surrogate"] += self._loss_scalars[0]; loss["Entropy"] += self._loss_scalars[2]
         loss["priv_reg_loss"] += priv_reg.detach()

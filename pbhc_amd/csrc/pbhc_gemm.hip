@@ -262,6 +262,10 @@ __device__ __forceinline__ void lds_barrier_raw() {
 
 template <int V> struct IC { static constexpr int value = V; };
 
+// The narrow output layer of a stack (23 actions / 20 value heads behind a 128-wide hidden layer) riding in the epilogue of that hidden
+// layer's forward GEMM: out[M, no] = y[M, 128] . w[no, 128]^T + b[no] with y the activated tile rows (no <= 32; out == nullptr: nothing).
+struct GemmOutLayer { const float* w; const float* b; float* out; int no; };
+
 // The fp32 MFMA moves 34 registers per lane in its 64 cycles (32x32x2: 16 accumulators in, 16 out, one A, one B), so it runs at the VGPR
 // file's pace and every other VALU instruction a co-resident wave issues displaces it: measured, a K stage with ~57 address / bookkeeping
 // VALU instructions per 32 MFMAs ran the matrix pipe at 67 %.  Hence the shape of this loop: per-lane addresses are stage-invariant 32-bit
@@ -270,9 +274,11 @@ template <int V> struct IC { static constexpr int value = V; };
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                       const float* __restrict__ S, float* __restrict__ Cout, float* __restrict__ Pre, float* __restrict__ part,
-                                                      int M, int N, int K, int act, int tiles_n, int dbg, int lda, int ldc, long long a_batch, long long c_batch) {
+                                                      int M, int N, int K, int act, int tiles_n, int dbg, int lda, int ldc, long long a_batch, long long c_batch,
+                                                      GemmOutLayer fo) {
   // MODE 0 only: row strides of A / of the outputs (floats; lda >= K, ldc >= N) and a batch over blockIdx.y with element strides a_batch / c_batch
   // — the L output positions of a Conv1d window GEMM in one launch (agents/agent_modules.py).  MODE 1 is launched with lda = K, ldc = N, one batch.
+  // fo (32 x 128 forward tiles with N = 128 only): the stack's narrow OUTPUT layer applied to the tile's activated rows in the epilogue.
   A += (size_t)blockIdx.y * a_batch;
   Cout += (size_t)blockIdx.y * c_batch;
   if (Pre) Pre += (size_t)blockIdx.y * c_batch;
@@ -450,7 +456,28 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
   // of lane (r, kk) is row 8 (e / 4) + 4 kk + (e % 4), column r); bias / activation / activation derivative are applied on the way out.
   if ((dbg & 16) && acc[0][0][0] != 12345.678f) return;
   constexpr int CS = BN + 4;                               // row stride of the image (floats): 16-byte rows, ds_write_b32 by 32 consecutive columns
+  constexpr bool CAN_FUSE_OUT = MODE == 0 && BM == 32 && BN == 128;
+  const bool fuse_out = CAN_FUSE_OUT && fo.out != nullptr;
+  f32x4 wo[3];                                             // the output layer's weights on their way to LDS: 32 x 128 floats = 3 x 16 B per thread (+ a rest)
+  if (CAN_FUSE_OUT && fuse_out) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int ch = tid + GEMM_T * q;                     // 16-byte chunk: row n = ch / 32, floats 4 (ch % 32) ...
+      const int n = ch >> 5;
+      wo[q] = n < fo.no ? reinterpret_cast<const F4U*>(fo.w + (size_t)n * 128 + 4 * (ch & 31))->v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   lds_barrier_raw();                                       // every wave is out of the K loop (its last stage waited vmcnt(0)): the ring is free
+  if (CAN_FUSE_OUT && fuse_out) {                          // W_out image [32][CS] behind the tile image (rows n >= no are zeros)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = tid + GEMM_T * q;
+      const int n = ch >> 5;
+      f32x4 v = q < 3 ? wo[q < 3 ? q : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q == 3 && n < fo.no) v = reinterpret_cast<const F4U*>(fo.w + (size_t)n * 128 + 4 * (ch & 31))->v;
+      *reinterpret_cast<f32x4*>(&lds[BM * CS + n * CS + 4 * (ch & 31)]) = v;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -506,6 +533,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = gemm_act(act, v[q]);
+        if (CAN_FUSE_OUT && fuse_out) *reinterpret_cast<f32x4*>(&lds[(p * RP + rr) * CS + c4]) = v;   // the activated row stays for the output layer
       } else if (act) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(act, sv[p][q]);
@@ -527,6 +555,41 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
       __builtin_amdgcn_s_waitcnt(0);
       Cout[0] = (float)(clock64() - dbg_c0);
       Cout[1] = (float)(wall_clock64() - dbg_w0);
+    }
+    if constexpr (CAN_FUSE_OUT) {
+      if (fuse_out) {
+        // out[32, 32] = y[32, 128] . W_out^T: wave w takes k in [32 w, 32 w + 32) (16 MFMAs, operand fragments as in the K loop: lane (r, kk) holds
+        // k = 8 k8 + 4 kk + s), the four partial tiles meet in LDS — in the tile image's place, [4][32][33] floats are exactly its 32 x 132 —
+        // and are summed in the fixed order w = 0..3 (+ bias).  Rows / columns beyond M / no are computed on zeros and not stored.
+        lds_barrier_raw();                                 // activated image + W_out image complete
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+          const f32x4 ya = *reinterpret_cast<const f32x4*>(&lds[r * CS + 32 * wave + 8 * k8 + 4 * kk]);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(&lds[BM * CS + r * CS + 32 * wave + 8 * k8 + 4 * kk]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[s], wb[s], o, 0, 0, 0);
+        }
+        lds_barrier_raw();                                 // every wave has read its fragments: the image may be overwritten
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds[wave * (32 * 33) + (8 * (e >> 2) + 4 * kk + (e & 3)) * 33 + r] = o[e];
+        lds_barrier_raw();
+        const int m = tid >> 3, q0 = tid & 7;
+        if (row0 + m < M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = q0 + 8 * j;
+            if (n < fo.no) {
+              float t = lds[m * 33 + n];
+#pragma unroll
+              for (int w = 1; w < 4; ++w) t += lds[w * (32 * 33) + m * 33 + n];
+              fo.out[(size_t)(row0 + m) * fo.no + n] = t + (fo.b ? fo.b[n] : 0.0f);
+            }
+          }
+        }
+      }
     }
     if (MODE == 1 && part) {
       // column sums over the tile's rows: the RP threads of a column group through LDS, fixed order
@@ -730,9 +793,10 @@ static int tile_bm(int shape) { return shape == 0 ? 128 : shape == 1 ? 96 : shap
 
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NS>
 static hipError_t gemm2_launch(const float* A, const float* B, const float* bias, const float* S, float* C, float* pre, float* part, int M, int N, int K, int act,
-                               hipStream_t st, int lda = 0, int ldc = 0, long long a_batch = 0, long long c_batch = 0, int batches = 1) {
+                               hipStream_t st, int lda = 0, int ldc = 0, long long a_batch = 0, long long c_batch = 0, int batches = 1,
+                               GemmOutLayer fo = GemmOutLayer{nullptr, nullptr, nullptr, 0}) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  constexpr int RING_BYTES = NS * (BM + BN) * BK * 4, IMAGE_BYTES = BM * (BN + 4) * 4;   // K stages; the epilogue's [BM][BN + 4] image
+  constexpr int RING_BYTES = NS * (BM + BN) * BK * 4, IMAGE_BYTES = (BM + (MODE == 0 && BM == 32 && BN == 128 ? 32 : 0)) * (BN + 4) * 4;   // K stages; the epilogue's [BM][BN + 4] image (+ the fused output layer's weights)
   constexpr int LDS_BYTES = RING_BYTES > IMAGE_BYTES ? RING_BYTES : IMAGE_BYTES;
   static bool attr_set = LDS_BYTES <= 65536;               // (the shapes pick_shape() chooses stay below 64 KB: nothing to set, safe under stream capture)
   if (!attr_set) {
@@ -742,7 +806,7 @@ static hipError_t gemm2_launch(const float* A, const float* B, const float* bias
   }
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   hipLaunchKernelGGL((k_gemm2<MODE, WM, WN, TM, TN, BK, NS>), dim3(tm * tn, batches), dim3(GEMM_T), LDS_BYTES, st, A, B, bias, S, C, pre, part, M, N, K, act, tn, g_dbg,
-                     lda ? lda : K, ldc ? ldc : N, a_batch, c_batch);
+                     lda ? lda : K, ldc ? ldc : N, a_batch, c_batch, fo);
   return hipGetLastError();
 }
 
@@ -804,6 +868,16 @@ int pbhc_linear_act_fwd(const float* x, const float* w, const float* bias, float
   GEMM_ARG(x && w && y && M >= 1 && N >= 1 && K >= 1 && act >= 0 && act <= 3);
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0);
   GEMM_HIP(gemm_dispatch<0>(pick_shape(M, N, K, g_force_shape, true), x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream));
+  return PBHC_OK;
+}
+
+int pbhc_linear_act_fwd_out(const float* x, const float* w, const float* bias, float* y, float* pre, int M, int N, int K, int act, const float* w_out,
+                            const float* b_out, int NO, float* out, void* stream) {
+  GEMM_ARG(x && w && y && w_out && out && M >= 1 && N == 128 && K >= 4 && NO >= 1 && NO <= 32 && act >= 0 && act <= 3);
+  GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0 && ((uintptr_t)w_out & 3) == 0);
+  GEMM_ARG((size_t)M * K < (1u << 30) && (size_t)N * K < (1u << 30));
+  GEMM_HIP((gemm2_launch<0, 1, 4, 1, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream, 0, 0, 0, 0, 1,
+                                               GemmOutLayer{w_out, b_out, out, NO})));
   return PBHC_OK;
 }
 

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
 #define RED_CH (RED_T / 32)
 __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ partial, const float* __restrict__ gstd_part, const float* __restrict__ stdp,
                                                       int nblocks, int B, int A, float entropy_coef, float desired_kl, int adapt_lr,
-                                                      float* __restrict__ grad_std, float* __restrict__ scalars, float* __restrict__ lr) {
+                                                      float* __restrict__ grad_std, float* __restrict__ scalars, float* __restrict__ lr,
+                                                      float* __restrict__ scalars_acc) {
   __shared__ double sh_g[RED_CH][33];
   __shared__ double sh_s[RED_CH][4];
   __shared__ float sh_e[32];
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ 
     double t = 0.0;
     for (int ch = 0; ch < RED_CH; ++ch) t += sh_s[ch][k];
     const float mean = (float)(t / (double)B);
-    if (k == 0) scalars[0] = mean;                          // surrogate loss
-    if (k == 1) scalars[1] = mean;                          // value loss
-    if (k == 2) scalars[3] = mean;                          // kl
+    const int slot = k == 2 ? 3 : k;                        // surrogate loss, value loss, (entropy), kl
+    scalars[slot] = mean;
+    if (scalars_acc) scalars_acc[slot] += mean;
     sh_m[k] = mean;
   }
   __syncthreads();
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ 
     float ent = 0.0f;
     for (int a = 0; a < A; ++a) ent += sh_e[a];
     scalars[2] = ent;
+    if (scalars_acc) scalars_acc[2] += ent;
   }
   if (threadIdx.x < 2 && adapt_lr) {
     const float kl_mean = sh_m[2];
@@ -256,11 +258,48 @@ __global__ __launch_bounds__(ACT_T) void k_colsum_final(const float* __restrict_
   colsum_final_block(part, nblocks, n, out, blockIdx.x);
 }
 struct ColsumJobs { PbhcColsumJob job[PBHC_MAX_COLSUM_JOBS]; int first_block[PBHC_MAX_COLSUM_JOBS]; };
+// Two job shapes.  TALL: many partial rows, few columns (bias gradients, the output layer's weight gradient: <= 1024 rows x <= 3k columns) —
+// 32 columns x 8 row slices per block.  WIDE: few partial images, many columns (the split-K partials of a hidden layer's weight gradient:
+// 2..32 images of up to 768 x 630) — a thread owns four consecutive columns, 1024 per block, and walks the images in order with all loads of
+// a run of eight in flight.
+__host__ __device__ __forceinline__ bool colsum_wide(int num_row_blocks, int n) { return num_row_blocks <= 64 && n >= 4096 && (n & 3) == 0; }
+__host__ __device__ __forceinline__ int colsum_blocks(int num_row_blocks, int n) { return colsum_wide(num_row_blocks, n) ? (n + 1023) / 1024 : (n + 31) / 32; }
+__device__ __forceinline__ void colsum_wide_block(const float* __restrict__ part, int P, int n, float* __restrict__ out, int block) {
+  const int c = block * 1024 + 4 * (int)threadIdx.x;
+  if (c >= n) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 8 <= P; b += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (size_t)(b + u) * n + c);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+  }
+  for (; b < P; ++b) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)b * n + c);
+    s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+  }
+  if (((uintptr_t)out & 15) == 0) {
+    *reinterpret_cast<float4*>(out + c) = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+  } else {                                                         // a .grad view at an odd offset of the flat gradient buffer
+    out[c] = (float)s0; out[c + 1] = (float)s1; out[c + 2] = (float)s2; out[c + 3] = (float)s3;
+  }
+}
 // the second stage of several layers in one launch (the bias gradients of a whole MLP backward)
 __global__ __launch_bounds__(ACT_T) void k_colsum_final_multi(ColsumJobs J, int num_jobs) {
   int j = 0;
   while (j + 1 < num_jobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
-  colsum_final_block(J.job[j].part, J.job[j].num_row_blocks, J.job[j].n, J.job[j].out, (int)blockIdx.x - J.first_block[j]);
+  const PbhcColsumJob job = J.job[j];
+  const int block = (int)blockIdx.x - J.first_block[j];
+  if (colsum_wide(job.num_row_blocks, job.n) && ((uintptr_t)job.part & 15) == 0) {
+    colsum_wide_block(job.part, job.num_row_blocks, job.n, job.out, block);
+  } else if (colsum_wide(job.num_row_blocks, job.n)) {             // (unaligned partial images: the tall form over this block's 1024 columns)
+    for (int sub = 0; sub < 32; ++sub)
+      if ((block * 32 + sub) * 32 < job.n) { colsum_final_block(job.part, job.num_row_blocks, job.n, job.out, block * 32 + sub); __syncthreads(); }
+  } else {
+    colsum_final_block(job.part, job.num_row_blocks, job.n, job.out, block);
+  }
 }
 __device__ __forceinline__ void colsum_final_block(const float* __restrict__ part, int nblocks, int n, float* __restrict__ out, int block) {
   // 32 columns x 8 row slices per block (a slice reads rows slice, slice + 8, ...: eight independent loads in flight per thread), then the
@@ -334,7 +373,7 @@ __global__ __launch_bounds__(ADAM_T) void k_sqnorm_partial(AdamSegs S) {
 // torch.optim.Adam (no amsgrad, no weight decay), after nn.utils.clip_grad_norm_(max_norm):
 //   clip = min(1, max_norm / (||g|| + 1e-6));  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__global__ __launch_bounds__(ADAM_T) void k_adam_clip(AdamSegs S, float max_norm, float b1, float b2, float eps, float weight_decay) {
+__global__ __launch_bounds__(ADAM_T) void k_adam_clip(AdamSegs S, float max_norm, float b1, float b2, float eps, float weight_decay, int zero_grad) {
   __shared__ float s_clip, s_bc1, s_bc2s, s_lr;
   __shared__ double sh[ADAM_T];
   const int seg = (S.num > 1 && (int)blockIdx.x >= S.first_adam_block[1]) ? 1 : 0;
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(ADAM_T) void k_adam_clip(AdamSegs S, float max_norm
   const float decay = 1.0f - s_lr * weight_decay;              // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) before the Adam update
   auto one = [&](float& pi, float& gi_, float& mi_, float& vi_) {
     const float gi = gi_ * clipc;
-    gi_ = gi;                                         // clip_grad_norm_ scales .grad in place
+    gi_ = zero_grad ? 0.0f : gi;                      // clip_grad_norm_ scales .grad in place; or the next step's zero_grad() right here
     const float mi = mi_ + (gi - mi_) * (1.0f - b1);
     const float vi = vi_ * b2 + (1.0f - b2) * gi * gi;
     mi_ = mi; vi_ = vi;
@@ -528,7 +567,26 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
       }
     }
   }
-  if (live) {
+  if constexpr (KT == 128) {
+    // the two row lanes of a column meet in LDS (fixed order: lane 0 + lane 1): ONE partial row per workgroup — half the partial traffic
+    // (24 576 rows, 23 x 128 weights: 6 MB written here and read by pbhc_colsum_final instead of 12)
+    __shared__ float sred[(AP + 2) * 128];
+    if (rl == 1) {
+#pragma unroll
+      for (int a = 0; a < AP; ++a) sred[a * 128 + c] = acc[a];
+      sred[AP * 128 + c] = cs;
+      sred[(AP + 1) * 128 + c] = dbacc;
+    }
+    __syncthreads();
+    if (rl == 0) {
+      const size_t pb = blockIdx.x;
+#pragma unroll
+      for (int a = 0; a < AP; ++a)
+        if (a < A) part_dw[pb * (size_t)(A * K) + (size_t)a * K + c] = acc[a] + sred[a * 128 + c];
+      part_cs[pb * K + c] = cs + sred[AP * 128 + c];
+      if (c < A) part_db[pb * A + c] = dbacc + sred[(AP + 1) * 128 + c];
+    }
+  } else if (live) {
     const size_t pb = (size_t)blockIdx.x * RPI + rl;                          // this thread group's partial row
 #pragma unroll
     for (int a = 0; a < AP; ++a)
@@ -577,7 +635,7 @@ int pbhc_rollout_post(const float* rew, const float* values, const int64_t* rese
 int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* old_mu,
                   const float* old_sigma, const float* adv, const float* returns, const float* old_values, int B, int A, int R, float clip,
                   float value_coef, float entropy_coef, int use_clipped_value_loss, float desired_kl, int adapt_lr, float* grad_mu, float* grad_value,
-                  float* grad_std, float* scalars, float* lr, float* scratch, void* stream) {
+                  float* grad_std, float* scalars, float* scalars_acc, float* lr, float* scratch, void* stream) {
   ARG_CHECK(mu && std && value && actions && old_logp && old_mu && old_sigma && adv && returns && old_values);
   ARG_CHECK(grad_mu && grad_value && grad_std && scalars && lr && scratch);
   ARG_CHECK(B >= 1 && A >= 1 && A <= 32 && R >= 1 && R <= 32);
@@ -588,7 +646,7 @@ int pbhc_ppo_loss(const float* mu, const float* std, const float* value, const f
   float* gstd_part = scratch + (size_t)nb * LOSS_NP;   // [nb][32]
   hipLaunchKernelGGL(k_ppo_loss, dim3(nb), dim3(256), 0, st, mu, std, value, actions, old_logp, old_mu, old_sigma, adv, returns, old_values, B, A, R,
                      clip, value_coef, use_clipped_value_loss, (adapt_lr >> 1) & 1, grad_mu, grad_value, partial, gstd_part);
-  hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr & 1, grad_std, scalars, lr);
+  hipLaunchKernelGGL(k_ppo_reduce, dim3(1), dim3(RED_T), 0, st, partial, gstd_part, std, nb, B, A, entropy_coef, desired_kl, adapt_lr & 1, grad_std, scalars, lr, scalars_acc);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
@@ -632,7 +690,7 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
   int rpb = (M + grid - 1) / grid;
   rpb = (rpb + OUTB_HR - 1) / OUTB_HR * OUTB_HR;
   grid = (M + rpb - 1) / rpb;
-  *num_row_blocks = grid * RPI;
+  *num_row_blocks = K == 128 ? grid : grid * RPI;          // (K = 128: the two row lanes are summed inside the workgroup)
   hipStream_t st = (hipStream_t)stream;
   if (K == 128) out_bwd_launch<128>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
   else if (K == 256) out_bwd_launch<256>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
@@ -649,13 +707,13 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream) {
     if (j < num_jobs) {
       ARG_CHECK(jobs[j].part && jobs[j].out && jobs[j].num_row_blocks >= 1 && jobs[j].n >= 1);
       J.job[j] = jobs[j];
-      blocks += (jobs[j].n + 31) / 32;
+      blocks += colsum_blocks(jobs[j].num_row_blocks, jobs[j].n);
     } else {
       J.job[j] = PbhcColsumJob{nullptr, nullptr, 0, 0};
     }
   }
   int acc = 0;
-  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) { J.first_block[j] = acc; acc += (J.job[j].n + 31) / 32; }
+  for (int j = 0; j < PBHC_MAX_COLSUM_JOBS; ++j) { J.first_block[j] = acc; acc += colsum_blocks(J.job[j].num_row_blocks, J.job[j].n); }
   hipLaunchKernelGGL(k_colsum_final_multi, dim3(blocks), dim3(ACT_T), 0, (hipStream_t)stream, J, num_jobs);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
@@ -702,13 +760,13 @@ int pbhc_adam_clip(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
   adam_fill(S, 0, param, grad, exp_avg, exp_avg_sq, n, lr, step, scratch, norm_out);
   S.first_norm_block[2] = S.first_norm_block[1]; S.first_adam_block[2] = S.first_adam_block[1];
   hipLaunchKernelGGL(k_sqnorm_partial, dim3(S.first_norm_block[1]), dim3(ADAM_T), 0, st, S);
-  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[1]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay);
+  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[1]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay, 0);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }
 
 int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int n0, int n1, const float* lr, float* step, float max_norm, float beta1,
-                    float beta2, float eps, float weight_decay, double* scratch, float* norm_out, void* stream) {
+                    float beta2, float eps, float weight_decay, int zero_grad, double* scratch, float* norm_out, void* stream) {
   ARG_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step && scratch && n0 >= 1 && n1 >= 1);
   hipStream_t st = (hipStream_t)stream;
   AdamSegs S = {};
@@ -716,7 +774,7 @@ int pbhc_adam_clip2(float* param, float* grad, float* exp_avg, float* exp_avg_sq
   adam_fill(S, 0, param, grad, exp_avg, exp_avg_sq, n0, lr, step, scratch, norm_out);
   adam_fill(S, 1, param + n0, grad + n0, exp_avg + n0, exp_avg_sq + n0, n1, lr + 1, step + 1, scratch + 512, norm_out ? norm_out + 1 : nullptr);
   hipLaunchKernelGGL(k_sqnorm_partial, dim3(S.first_norm_block[2]), dim3(ADAM_T), 0, st, S);
-  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[2]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay);
+  hipLaunchKernelGGL(k_adam_clip, dim3(S.first_adam_block[2]), dim3(ADAM_T), 0, st, S, max_norm, beta1, beta2, eps, weight_decay, zero_grad);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }

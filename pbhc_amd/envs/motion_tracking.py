@@ -533,9 +533,9 @@ class LeggedRobotMotionTracking:
         return obs_dict
 
     def _reset_all_state(self, keep_reset_buf=False):
-        self.wait_finalize()
         """reset_envs_idx(arange(N)) (legged_robot_base.py:491-517).  keep_reset_buf: the periodic resample inside step() — the reference's
         resample_motion() resets every env WITHOUT touching reset_buf, the dones of that step stay those of its own _check_termination."""
+        self.wait_finalize()
         N, dev = self.num_envs, self.device
         ids = torch.arange(N, device=dev)
         g = self.globals

@@ -273,3 +273,70 @@ def test_linear_out_bwd_matches_fp64(shape, act):
     assert (dw.double() - dy.double().t() @ h.double()).abs().max().item() < TOL * scale
     assert (db.double() - dy.double().sum(0)).abs().max().item() < TOL * scale
     assert (cs.double() - ref_dh.sum(0)).abs().max().item() < TOL * scale
+
+
+# (M, K = in_features of the 128-wide hidden layer, NO = outputs of the narrow layer behind it): the update's two tails, ragged rows, a K tail,
+# every output-count class (a whole 32, one, more than 24)
+FWD_OUT_SHAPES = [(24576, 256, 23), (24576, 512, 20), (100, 64, 23), (33, 37, 1), (4096, 256, 32), (1, 4, 29), (8192, 630, 7)]
+
+
+@pytest.mark.parametrize("shape", FWD_OUT_SHAPES)
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_linear_act_fwd_out_matches_fp64(shape, act):
+    """the last hidden layer + the narrow output layer in one launch (`pbhc_linear_act_fwd_out`): hidden activations, pre-activations and
+    the output layer's result against fp64, with and without biases"""
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    M, K, NO = shape
+    g = torch.Generator(device="cuda").manual_seed(31 * act + M + K + NO)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(128, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(128, device="cuda", generator=g)
+    wo = torch.randn(NO, 128, device="cuda", generator=g) / 128 ** 0.5
+    bo = torch.randn(NO, device="cuda", generator=g)
+    for with_bias in (True, False):
+        y = torch.full((M, 128), float("nan"), device="cuda")
+        pre = torch.full((M, 128), float("nan"), device="cuda")
+        out = torch.full((M, NO), float("nan"), device="cuda")
+        _lib.check(lib.pbhc_linear_act_fwd_out(x.data_ptr(), w.data_ptr(), b.data_ptr() if with_bias else None, y.data_ptr(), pre.data_ptr(), M, 128, K, act,
+                                               wo.data_ptr(), bo.data_ptr() if with_bias else None, NO, out.data_ptr(), _lib.current_stream()), "fwd_out")
+        z = x.double() @ w.double().t() + (b.double() if with_bias else 0.0)
+        h = _act_ref(act, z)
+        o = h @ wo.double().t() + (bo.double() if with_bias else 0.0)
+        assert (pre.double() - z).abs().max().item() < TOL
+        assert (y.double() - h).abs().max().item() < TOL
+        assert (out.double() - o).abs().max().item() < TOL
+    # the hidden layer is the same launch as pbhc_linear_act_fwd's 32 x 128 tiles: bit-identical activations
+    lib.pbhc_gemm_debug_force_shape(4)
+    y2 = torch.empty(M, 128, device="cuda")
+    _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), None, y2.data_ptr(), None, M, 128, K, act, _lib.current_stream()), "fwd")
+    lib.pbhc_gemm_debug_force_shape(-1)
+    if K >= 4:
+        assert torch.equal(y2, y)
+    assert lib.pbhc_linear_act_fwd_out(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, M, 64, K, act, wo.data_ptr(), None, NO, out.data_ptr(), None) == _lib.K["PBHC_EINVAL"]
+    assert lib.pbhc_linear_act_fwd_out(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, M, 128, K, act, wo.data_ptr(), None, 33, out.data_ptr(), None) == _lib.K["PBHC_EINVAL"]
+
+
+def test_colsum_final_job_shapes():
+    """`pbhc_colsum_final` with jobs of both shapes in one launch — tall (many partial rows, few columns: bias gradients) and wide (a few
+    partial images of a weight gradient: the split-K sums) — incl. a wide job whose output is not 16-byte aligned and one with a ragged
+    last block; every result equals the fp64 column sum rounded to fp32."""
+    from pbhc_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    specs = [(512, 128, 0), (1024, 23 * 128, 0), (2, 768 * 630, 0), (32, 256 * 512, 0), (4, 512 * 380, 1), (16, 4096 + 4, 0), (64, 4096, 3), (8, 8192, 2), (65, 8192, 0), (7, 5, 0)]
+    jobs = (_lib._S["PbhcColsumJob"] * _lib.K["PBHC_MAX_COLSUM_JOBS"])()
+    parts, outs = [], []
+    for j, (P, n, shift) in enumerate(specs):
+        part = torch.randn(P * n + 1, device="cuda", generator=g)[(1 if j == 7 else 0):][:P * n].view(P, n)      # (job 7: an unaligned partial buffer)
+        buf = torch.full((n + 8,), float("nan"), device="cuda")
+        out = buf[shift:shift + n]
+        jobs[j].part, jobs[j].out, jobs[j].num_row_blocks, jobs[j].n = part.data_ptr(), out.data_ptr(), P, n
+        parts.append(part); outs.append((buf, out, shift))
+    _lib.check(lib.pbhc_colsum_final(jobs, len(specs), _lib.current_stream()), "pbhc_colsum_final")
+    torch.cuda.synchronize()
+    for part, (buf, out, shift) in zip(parts, outs):
+        assert torch.equal(out, part.double().sum(0).float())
+        assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + out.numel():]).all()      # nothing written outside
