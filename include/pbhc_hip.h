@@ -531,6 +531,9 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
  *                                                    colsum(dh); finish each with a pbhc_colsum_final job (n = A*K, A, K). */
 int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,
                         float* part_db, float* part_cs, int* num_row_blocks, void* stream);
+/* test / measurement aid: 0 = the streaming VALU form of pbhc_linear_out_bwd for every shape (default 1: K = 128 with the derivative taken from
+ * the output runs on the matrix cores) */
+void pbhc_debug_out_bwd_variant(int mfma);
 
 
 /* One Linear of a training-time Linear / activation stack on the fp32 matrix cores with its activation folded into the GEMM epilogue

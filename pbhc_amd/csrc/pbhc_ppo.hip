@@ -596,6 +596,93 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
   }
 }
 
+// The same pass for K = 128 inputs and a derivative taken from the layer's OUTPUT (ELU / ReLU stacks: the 23-action and 20-value-head tails of
+// the update) on the matrix cores.  A workgroup takes 32-row tiles; wave w owns input columns [32 w, 32 w + 32).  Per tile, per wave, two
+// 32 x 32 products of depth 32 (`v_mfma_f32_32x32x2_f32`, 16 instructions each):
+//   dh[row, col]  = sum_n  dy[row, n] W[n, col]        A = the dy tile (LDS image [32][36], zero-padded to 32 outputs), B = W in registers
+//   dW[n, col]   += sum_row dy[row, n] h[row, col]     A = the same image read transposed, B = the tile of h in registers
+// and the second product's B fragment is, register for register, the accumulator layout of the first (element e of lane (r, kk) <-> row
+// 8 (e / 4) + 4 kk + e % 4, column r): ONE set of 16 loads of h per lane serves as the matrix operand and as act'(h) for the elementwise
+// factor.  Nothing but the dy tile goes through LDS.  One partial row per workgroup (dW, db, column sums of dh), finished by pbhc_colsum_final.
+typedef float outb_f32x16 __attribute__((ext_vector_type(16)));
+typedef float outb_f32x4 __attribute__((ext_vector_type(4)));
+#define OUTM_DS 36                   // row stride of the dy image (floats)
+__global__ __launch_bounds__(256) void k_out_bwd_mfma(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ w, int M, int A, int act,
+                                                      int ntiles, float* __restrict__ dh, float* __restrict__ part_dw, float* __restrict__ part_db,
+                                                      float* __restrict__ part_cs) {
+  __shared__ __attribute__((aligned(16))) float dyimg[32 * OUTM_DS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, kk = lane >> 5;
+  const int col = 32 * wave + r;
+  for (int i = tid; i < 32 * OUTM_DS; i += 256) dyimg[i] = 0.0f;          // the padding (outputs A..35) stays zero
+  float wb[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = 8 * (e >> 2) + 4 * kk + (e & 3);
+    wb[e] = n < A ? w[(size_t)n * 128 + col] : 0.0f;
+  }
+  outb_f32x16 accw;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accw[e] = 0.0f;
+  float cs = 0.0f, dbacc = 0.0f;
+  const int tile_elems = 32 * A;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row0 = t * 32;
+    float hv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row0 + 8 * (e >> 2) + 4 * kk + (e & 3);
+      hv[e] = row < M ? h[(size_t)row * 128 + col] : 0.0f;
+    }
+    __syncthreads();                                                     // the previous tile's image has been read (first tile: the zero fill is complete)
+    {
+      const float* src = dy + (size_t)row0 * A;
+      const int lim = min(tile_elems, (M - row0) * A);
+      for (int i = tid; i < tile_elems; i += 256) {
+        const int rr = i / A, n = i - rr * A;
+        dyimg[rr * OUTM_DS + n] = i < lim ? src[i] : 0.0f;
+      }
+    }
+    __syncthreads();
+    outb_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+      const outb_f32x4 a = *reinterpret_cast<const outb_f32x4*>(&dyimg[r * OUTM_DS + 8 * k8 + 4 * kk]);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_], wb[4 * k8 + s_], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float a2 = dyimg[(8 * (e >> 2) + 4 * kk + (e & 3)) * OUTM_DS + r];
+      accw = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, hv[e], accw, 0, 0, 0);
+    }
+    if (wave == 0 && kk == 0) {                                          // db: column sums of the dy tile (rows beyond M are zeros)
+      float t_ = 0.0f;
+#pragma unroll 8
+      for (int rr = 0; rr < 32; ++rr) t_ += dyimg[rr * OUTM_DS + r];
+      dbacc += t_;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row0 + 8 * (e >> 2) + 4 * kk + (e & 3);
+      const float hh = hv[e];
+      const float gr = act == 1 ? (hh > 0.0f ? 1.0f : hh + 1.0f) : act == 3 ? (hh > 0.0f ? 1.0f : 0.0f) : 1.0f;
+      const float g = acc[e] * gr;
+      if (row < M) { dh[(size_t)row * 128 + col] = g; cs += g; }
+    }
+  }
+  const size_t pb = blockIdx.x;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = 8 * (e >> 2) + 4 * kk + (e & 3);
+    if (n < A) part_dw[pb * (size_t)(A * 128) + (size_t)n * 128 + col] = accw[e];
+  }
+  cs += __shfl_xor(cs, 32, 64);
+  if (kk == 0) part_cs[pb * 128 + col] = cs;
+  if (wave == 0 && kk == 0 && r < A) part_db[pb * A + r] = dbacc;
+}
+
 template <int KT>
 static void out_bwd_launch(int grid, hipStream_t st, const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, int rpb,
                            float* dh, float* part_dw, float* part_db, float* part_cs) {
@@ -679,10 +766,22 @@ int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int
   return PBHC_OK;
 }
 
+static int g_out_bwd_mfma = 1;
+void pbhc_debug_out_bwd_variant(int mfma) { g_out_bwd_mfma = mfma; }       // test / measurement aid: 0 = the streaming VALU form for every shape
+
 int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,
                         float* part_db, float* part_cs, int* num_row_blocks, void* stream) {
   ARG_CHECK(dy && h && w && dh && part_dw && part_db && part_cs && num_row_blocks && M >= 1 && A >= 1 && A <= 32 && act >= 0 && act <= 3);
   ARG_CHECK(K == 64 || K == 128 || K == 192 || K == 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 128 && !saved && act != 2 && g_out_bwd_mfma) {
+    const int ntiles = (M + 31) / 32;
+    const int grid = ntiles < PBHC_ACT_MAX_BLOCKS ? ntiles : PBHC_ACT_MAX_BLOCKS;
+    *num_row_blocks = grid;
+    hipLaunchKernelGGL(k_out_bwd_mfma, dim3(grid), dim3(256), 0, st, dy, h, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+    HIP_CHECK(hipGetLastError());
+    return PBHC_OK;
+  }
   const int RPI = OUTB_T / K;
   int grid = (M + OUTB_HR - 1) / OUTB_HR;
   const int cap = PBHC_ACT_MAX_BLOCKS / RPI < 512 ? PBHC_ACT_MAX_BLOCKS / RPI : 512;     // two workgroups per CU; partial rows = grid x RPI <= the scratch cap
@@ -691,7 +790,6 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
   rpb = (rpb + OUTB_HR - 1) / OUTB_HR * OUTB_HR;
   grid = (M + rpb - 1) / rpb;
   *num_row_blocks = K == 128 ? grid : grid * RPI;          // (K = 128: the two row lanes are summed inside the workgroup)
-  hipStream_t st = (hipStream_t)stream;
   if (K == 128) out_bwd_launch<128>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
   else if (K == 256) out_bwd_launch<256>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);
   else out_bwd_launch<0>(grid, st, dy, h, saved, w, M, A, K, act, rpb, dh, part_dw, part_db, part_cs);

@@ -239,9 +239,10 @@ def test_module_inference_forward_uses_the_stack_kernel_and_matches_layers():
     assert not torch.equal(a, b)                                 # (different summation order: the two paths really are different kernels)
 
 
-@pytest.mark.parametrize("shape", [(24576, 23, 128), (24576, 21, 128), (1000, 23, 128), (37, 1, 64), (4096, 32, 256), (513, 12, 192)])
+@pytest.mark.parametrize("shape", [(24576, 23, 128), (24576, 21, 128), (1000, 23, 128), (37, 1, 64), (4096, 32, 256), (513, 12, 192), (70001, 20, 128), (5, 9, 128)])
 @pytest.mark.parametrize("act", [1, 2, 3])
-def test_linear_out_bwd_matches_fp64(shape, act):
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_linear_out_bwd_matches_fp64(shape, act, mfma):
     """`pbhc_linear_out_bwd`: the narrow output layer's weight / bias / input gradient + the activation backward of the layer below in one pass
     (what autograd runs as mm, a column sum, mm and elu_backward / silu_backward on agents/modules/modules.py:47-63)."""
     from pbhc_amd import _lib
@@ -258,8 +259,12 @@ def test_linear_out_bwd_matches_fp64(shape, act):
     dh = torch.empty(M, K, device="cuda")
     pdw, pdb, pcs = torch.empty(MAXB * A * K, device="cuda"), torch.empty(MAXB * A, device="cuda"), torch.empty(MAXB * K, device="cuda")
     nb = C.c_int(0)
-    _lib.check(lib.pbhc_linear_out_bwd(dy.data_ptr(), h.data_ptr(), None if saved is None else saved.data_ptr(), w.data_ptr(), M, A, K, act, dh.data_ptr(),
-                                       pdw.data_ptr(), pdb.data_ptr(), pcs.data_ptr(), C.byref(nb), _lib.current_stream()), "pbhc_linear_out_bwd")
+    lib.pbhc_debug_out_bwd_variant(mfma)        # 1 (default): K = 128 ELU / ReLU on the matrix cores; 0: the streaming form for every shape
+    try:
+        _lib.check(lib.pbhc_linear_out_bwd(dy.data_ptr(), h.data_ptr(), None if saved is None else saved.data_ptr(), w.data_ptr(), M, A, K, act, dh.data_ptr(),
+                                           pdw.data_ptr(), pdb.data_ptr(), pcs.data_ptr(), C.byref(nb), _lib.current_stream()), "pbhc_linear_out_bwd")
+    finally:
+        lib.pbhc_debug_out_bwd_variant(1)
     assert 1 <= nb.value <= MAXB
     jobs = (_lib._S["PbhcColsumJob"] * 3)()
     dw, db, cs = torch.empty(A, K, device="cuda"), torch.empty(A, device="cuda"), torch.empty(K, device="cuda")
