@@ -603,6 +603,18 @@ int pbhc_linear_wgrad(const float* dy, const float* x, float* dw, float* scratch
  * off); bits 16-23: staging version (0: automatic, 1: register-staged version 1, 2: LDS-DMA with BK 16 x 3 stages). */
 void pbhc_gemm_debug_force_shape(int shape);
 
+/* The minibatch shuffle of one update (RolloutStorage.mini_batch_generator, agents/modules/data_utils.py:134-152: `tensor.flatten(0, 1)[indices]`
+ * per stored key) for several keys in ONE launch: dst_j[i, :] = src_j[index[i], :] for every job j and row i < nrows.  src rows are src_pitch floats
+ * apart (the rollout slabs are 128-byte-padded), dst is contiguous [nrows, width]; f32 only; index values in [0, source rows). */
+#define PBHC_MAX_GATHER_JOBS 12
+typedef struct PbhcGatherJob {
+  const float* src;
+  float* dst;
+  int32_t width;
+  int32_t src_pitch;
+} PbhcGatherJob;
+int pbhc_gather_rows(const PbhcGatherJob* jobs, int num_jobs, const int64_t* index, int nrows, void* stream);
+
 /* nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() (mh_ppo.py:519-524; weight_decay > 0: torch.optim.AdamW, decoupled,
  * ppo_mimic.py:184-190,682-686) over ONE flat fp32 segment of n
  * parameters (param/grad/exp_avg/exp_avg_sq flat views; lr and step are device scalars, step is incremented).

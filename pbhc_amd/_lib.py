@@ -88,7 +88,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
-           "pbhc_linear_act_fwd", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
+           "pbhc_linear_act_fwd", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_gather_rows", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
            "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule"]
 
@@ -140,6 +140,7 @@ def _load():
     lib.pbhc_linear_dgrad_act.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int), i, i, i, i, vp]
     lib.pbhc_gemm_debug_force_shape.argtypes = [i]
     lib.pbhc_debug_out_bwd_variant.argtypes = [i]
+    lib.pbhc_gather_rows.argtypes = [vp, i, vp, i, vp]
     lib.pbhc_debug_out_bwd_variant.restype = None
     lib.pbhc_linear_wgrad_parts.argtypes = [i, i, i]
     lib.pbhc_linear_act_fwd_strided.argtypes = [vp, i, C.c_longlong, vp, vp, vp, vp, i, C.c_longlong, i, i, i, i, i, vp]

@@ -608,11 +608,13 @@ class MHPPO:
     UPDATE_KEYS = ["actor_obs", "critic_obs", "actions", "values", "advantages", "returns", "actions_log_prob", "action_mean", "action_sigma"]
 
     def _training_step(self, indices=None):
-        loss = {k: torch.zeros((), device=self.device) for k in ["Value", "Surrogate", "Entropy", "L2C2_Value", "L2C2_Policy"]}
+        names = ["Value", "Surrogate", "Entropy", "L2C2_Value", "L2C2_Policy"]
+        meters = torch.zeros(len(names) + 4, device=self.device)          # one fill: the five meters and, behind them, the loss kernel's running sums
+        loss = {k: meters[i] for i, k in enumerate(names)}
         keys = list(self.UPDATE_KEYS)
         if self._need_next:
             keys += ["next_actor_obs", "next_critic_obs"]
-        loss["_acc"] = torch.zeros(4, device=self.device)      # running sums of the loss kernel's scalars: one add per optimiser step, not one per meter
+        loss["_acc"] = meters[len(names):]                     # {surrogate, value, entropy, kl} summed by the loss kernel itself, one slot per scalar
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=keys, indices=indices):
             self._update_ppo(batch, loss)
         acc = loss.pop("_acc")
@@ -621,7 +623,8 @@ class MHPPO:
         self.storage.clear()
         self.actor_learning_rate = self._lr_a        # tensors; read back lazily by the logger
         self.critic_learning_rate = self._lr_c
-        return {k: v / n for k, v in loss.items()}
+        means = meters[:len(names)] / n
+        return {k: means[i] for i, k in enumerate(names)}
 
     def _allreduce_grads(self):
         """ONE RCCL all-reduce of the flat actor+critic gradient buffer (≈5 MB fp32), then average."""

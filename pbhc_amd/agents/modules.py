@@ -177,6 +177,34 @@ class RolloutStorage(nn.Module):
         assert hasattr(self, key), key
         return getattr(self, key)
 
+    def _gather(self, keys, indices):
+        """{key: buffer.flatten(0, 1)[indices]} — every f32 key whose [T, N, C] buffer is a uniformly pitched run of rows (contiguous, or the
+        128-byte-padded slabs) in ONE launch of `pbhc_gather_rows`; anything else (other dtypes, CPU) by torch indexing."""
+        import ctypes as C
+
+        out, jobs = {}, []
+        rows = self.num_envs * self.num_transitions_per_env
+        fast = indices.is_cuda and indices.dtype == torch.int64 and indices.is_contiguous() and indices.dim() == 1
+        for k in keys:
+            t = getattr(self, k)
+            w = int(t[0, 0].numel())
+            ok = (fast and t.dtype == torch.float32 and t.dim() >= 2 and w >= 1 and (t.dim() == 2 or (t.stride(-1) == 1 and t.dim() == 3))
+                  and t.stride(0) == t.shape[1] * t.stride(1) and (t.dim() == 2 or t.stride(1) >= w))
+            if not ok:
+                out[k] = t.flatten(0, 1)[indices].contiguous()
+                continue
+            dst = torch.empty((indices.numel(),) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            out[k] = dst
+            jobs.append((t.data_ptr(), dst.data_ptr(), w, int(t.stride(1))))
+        MAXJ = _lib.K["PBHC_MAX_GATHER_JOBS"]
+        for a in range(0, len(jobs), MAXJ):
+            chunk = jobs[a:a + MAXJ]
+            arr = (_lib._S["PbhcGatherJob"] * len(chunk))()
+            for j, (src, dst, w, pitch) in zip(arr, chunk):
+                j.src, j.dst, j.width, j.src_pitch = src, dst, w, pitch
+            _lib.check(_lib.lib().pbhc_gather_rows(arr, len(chunk), indices.data_ptr(), indices.numel(), _lib.current_stream()), "pbhc_gather_rows")
+        return out
+
     def clear(self):
         self.step = 0
 
@@ -188,7 +216,7 @@ class RolloutStorage(nn.Module):
         if indices is None:
             indices = torch.randperm(batch_size, device=self.device)
         keys = self.stored_keys if keys is None else keys
-        shuffled = {k: getattr(self, k).flatten(0, 1)[indices].contiguous() for k in keys}
+        shuffled = self._gather(keys, indices)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 yield {k: v[i * mb:(i + 1) * mb] for k, v in shuffled.items()}

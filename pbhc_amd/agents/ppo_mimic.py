@@ -505,8 +505,10 @@ class PPO:
                    "action_mean", "action_sigma"]
 
     def _training_step(self, indices=None):
-        loss = {k: torch.zeros((), device=self.device) for k in ["Value", "Entropy", "Surrogate", "priv_reg_loss"]}
-        loss["_acc"] = torch.zeros(4, device=self.device)      # running sums of the loss kernel's scalars: one add per optimiser step
+        names = ["Value", "Entropy", "Surrogate", "priv_reg_loss", "Actor_Load_Balancing_Loss", "Critic_Load_Balancing_Loss"]
+        meters = torch.zeros(len(names) + 4, device=self.device)          # one fill: the meters and, behind them, the loss kernel's running sums
+        loss = {k: meters[i] for i, k in enumerate(names[:4])}
+        loss["_acc"] = meters[len(names):]                     # {surrogate, value, entropy, kl} summed by the loss kernel itself
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=self.UPDATE_KEYS, indices=indices):
             self._update_ppo(batch, loss)
         acc = loss.pop("_acc")
@@ -515,10 +517,8 @@ class PPO:
         self.storage.clear()
         self.update_counter()
         self.learning_rate = self._lr[0:1]
-        out = {k: v / n for k, v in loss.items()}
-        out["Actor_Load_Balancing_Loss"] = torch.zeros((), device=self.device)
-        out["Critic_Load_Balancing_Loss"] = torch.zeros((), device=self.device)
-        return out
+        means = meters[:len(names)] / n                        # (the two load-balancing meters stay zero: no mixture-of-experts stacks here)
+        return {k: means[i] for i, k in enumerate(names)}
 
     def _training_step_dagger(self, indices=None):
         loss = {"hist_latent_loss": torch.zeros((), device=self.device)}

@@ -375,19 +375,28 @@ __global__ __launch_bounds__(GAE_TPB) void k_adv_sum(const float* __restrict__ r
   }
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
 }
-__global__ void k_adv_stats(double* __restrict__ part, int nblocks, double TN) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// mean / unbiased std of the advantages from the block partials, then the normalisation — in ONE launch: every block re-sums the (few hundred)
+// partial pairs itself, all in the same fixed order (thread i takes partials i, i + 256, ...; then a tree), so every block normalises with the
+// same two numbers; block 0 also leaves them behind the partials (part[2 nblocks], part[2 nblocks + 1]: the data-parallel path re-normalises
+// with the all-rank moments).  (Was a one-thread serial sum, 34 us, and a launch of its own.)
+__global__ __launch_bounds__(GAE_TPB) void k_adv_norm(float* __restrict__ adv, size_t TN, double* __restrict__ part, int nblocks) {
+  __shared__ double s1[GAE_TPB], s2[GAE_TPB];
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblocks; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
-  double mean = a / TN;
-  double var = (b - TN * mean * mean) / (TN - 1.0);       // torch.std: unbiased
-  part[2 * nblocks] = mean;
-  part[2 * nblocks + 1] = sqrt(var > 0.0 ? var : 0.0);
-}
-__global__ void k_adv_norm(float* __restrict__ adv, size_t TN, const double* __restrict__ stats) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = threadIdx.x; i < nblocks; i += GAE_TPB) { a += part[2 * i]; b += part[2 * i + 1]; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = GAE_TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  const double n = (double)TN;
+  const double mean_d = s1[0] / n;
+  const double var = (s2[0] - n * mean_d * mean_d) / (n - 1.0);       // torch.std: unbiased
+  const double sd_d = sqrt(var > 0.0 ? var : 0.0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { part[2 * nblocks] = mean_d; part[2 * nblocks + 1] = sd_d; }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= TN) return;
-  float mean = (float)stats[0], sd = (float)stats[1];
+  const float mean = (float)mean_d, sd = (float)sd_d;
   adv[i] = (adv[i] - mean) / (sd + 1e-8f);
 }
 
@@ -828,8 +837,7 @@ int pbhc_gae(const float* rewards, const float* values, const uint8_t* dones, co
   int nb = (int)((TN + GAE_TPB - 1) / GAE_TPB);
   hipLaunchKernelGGL(k_gae, dim3((unsigned)((NR + GAE_TPB - 1) / GAE_TPB)), dim3(GAE_TPB), 0, st, rewards, values, dones, last_values, T, N, R, gamma, lam, returns);
   hipLaunchKernelGGL(k_adv_sum, dim3(nb), dim3(GAE_TPB), 0, st, returns, values, TN, R, advantages, stats);
-  hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(64), 0, st, stats, nb, (double)TN);
-  hipLaunchKernelGGL(k_adv_norm, dim3(nb), dim3(GAE_TPB), 0, st, advantages, TN, stats + 2 * nb);
+  hipLaunchKernelGGL(k_adv_norm, dim3(nb), dim3(GAE_TPB), 0, st, advantages, TN, stats, nb);
   HIP_CHECK(hipGetLastError());
   return PBHC_OK;
 }

@@ -683,6 +683,29 @@ __global__ __launch_bounds__(256) void k_out_bwd_mfma(const float* __restrict__ 
   if (wave == 0 && kk == 0 && r < A) part_db[pb * A + r] = dbacc;
 }
 
+// ---- the minibatch shuffle: every key's rows gathered by one permutation, one launch ------------------------------------------------------------
+struct GatherJobs { PbhcGatherJob job[PBHC_MAX_GATHER_JOBS]; int vec[PBHC_MAX_GATHER_JOBS]; int n; };
+template <int V>
+__device__ __forceinline__ void gather_row(const float* __restrict__ src, float* __restrict__ dst, int width, int lane) {
+  typedef float vt __attribute__((ext_vector_type(V)));
+  const int nv = width / V;
+  for (int c = lane; c < nv; c += 64) reinterpret_cast<vt*>(dst)[c] = reinterpret_cast<const vt*>(src)[c];
+}
+// a wave per destination row (4 rows per workgroup), all jobs of the row: 16- / 8- / 4-byte pieces as the job's widths and addresses allow
+__global__ __launch_bounds__(256) void k_gather_rows(GatherJobs J, const int64_t* __restrict__ index, int nrows) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int64_t s = index[row];
+  for (int j = 0; j < J.n; ++j) {
+    const PbhcGatherJob job = J.job[j];
+    const float* src = job.src + (size_t)s * job.src_pitch;
+    float* dst = job.dst + (size_t)row * job.width;
+    if (J.vec[j] == 4) gather_row<4>(src, dst, job.width, lane);
+    else if (J.vec[j] == 2) gather_row<2>(src, dst, job.width, lane);
+    else for (int c = lane; c < job.width; c += 64) dst[c] = src[c];
+  }
+}
+
 template <int KT>
 static void out_bwd_launch(int grid, hipStream_t st, const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, int rpb,
                            float* dh, float* part_dw, float* part_db, float* part_cs) {
@@ -767,6 +790,22 @@ int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int
 }
 
 static int g_out_bwd_mfma = 1;
+int pbhc_gather_rows(const PbhcGatherJob* jobs, int num_jobs, const int64_t* index, int nrows, void* stream) {
+  ARG_CHECK(jobs && index && num_jobs >= 1 && num_jobs <= PBHC_MAX_GATHER_JOBS && nrows >= 1);
+  GatherJobs J;
+  J.n = num_jobs;
+  for (int j = 0; j < num_jobs; ++j) {
+    ARG_CHECK(jobs[j].src && jobs[j].dst && jobs[j].width >= 1 && jobs[j].src_pitch >= jobs[j].width);
+    J.job[j] = jobs[j];
+    const uintptr_t a = (uintptr_t)jobs[j].src | (uintptr_t)jobs[j].dst;
+    const int wp = jobs[j].width | jobs[j].src_pitch;
+    J.vec[j] = ((wp & 3) == 0 && (a & 15) == 0) ? 4 : ((wp & 1) == 0 && (a & 7) == 0) ? 2 : 1;
+  }
+  hipLaunchKernelGGL(k_gather_rows, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, J, index, nrows);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
 void pbhc_debug_out_bwd_variant(int mfma) { g_out_bwd_mfma = mfma; }       // test / measurement aid: 0 = the streaming VALU form for every shape
 
 int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,

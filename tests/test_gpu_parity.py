@@ -1072,3 +1072,34 @@ def test_general_tracking_env_with_motion_max_len_runs_and_resamples():
     assert not torch.equal(env._motion_lib.crop_starts, first)
     obs, rew, reset, extras = env.step({"actions": torch.zeros(64, env.num_dof, device=DEV)})
     assert all(torch.isfinite(v).all() for v in obs.values())
+
+
+def test_minibatch_gather_is_one_launch_and_equals_indexing():
+    """`RolloutStorage.mini_batch_generator` shuffles every key by one permutation (data_utils.py:134-152: `flatten(0, 1)[indices]`); the f32 keys
+    — contiguous buffers and the 128-byte-padded observation slabs alike — go through ONE `pbhc_gather_rows` launch, other dtypes through torch
+    indexing: bit-identical to indexing, rows of every width class (16- / 8- / 4-byte pieces)."""
+    from pbhc_amd.agents.modules import RolloutStorage
+
+    T, N = 6, 130
+    st = RolloutStorage(N, T, DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for key, shape, kw in [("actor_obs", (380,), dict(pad_rows=True, tail_slab=True)), ("critic_obs", (630,), dict(pad_rows=True, tail_slab=True)),
+                           ("odd", (23,), {}), ("scalar", (1,), {}), ("even", (6,), {}), ("wide4", (64,), {}), ("dones", (1,), dict(dtype=torch.bool))]:
+        st.register_key(key, shape=shape, **kw)
+        buf = getattr(st, key)
+        if buf.dtype == torch.bool:
+            buf.copy_(torch.rand(buf.shape, device=DEV, generator=g) > 0.5)
+        else:
+            buf.copy_(torch.randn(buf.shape, device=DEV, generator=g))
+    idx = torch.randperm(T * N, device=DEV, generator=g)
+    keys = list(st.stored_keys)
+    batches = list(st.mini_batch_generator(3, 2, keys=keys, indices=idx))
+    assert len(batches) == 6
+    mb = T * N // 3
+    for e in range(2):
+        for i in range(3):
+            b = batches[3 * e + i]
+            for k in keys:
+                ref = getattr(st, k).flatten(0, 1)[idx][i * mb:(i + 1) * mb]
+                assert b[k].is_contiguous() or b[k].shape[0] == mb
+                assert torch.equal(b[k], ref), k
