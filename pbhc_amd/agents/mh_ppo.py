@@ -409,6 +409,32 @@ class MHPPO:
     def _critic_eval_step(self, obs_dict):
         return self.critic.evaluate(obs_dict["critic_obs"])
 
+    def _prefetch_permutation(self, n):
+        """The update's minibatch permutation (data_utils.py:139, `torch.randperm(batch_size)`) does not depend on the rollout's data: its
+        ten sort launches (~125 us) are queued on a stream of their own before the rollout starts and run beside it.  Same generator, same
+        draw per iteration — nothing else draws from torch's device generator in between (policy sampling and env resets are Philox streams
+        keyed by their own counters)."""
+        if self.device.type != "cuda" or os.environ.get("PBHC_PERM_PREFETCH", "1") == "0":
+            return
+        if self.__dict__.get("_perm_stream") is None:
+            self._perm_stream = torch.cuda.Stream(device=self.device)
+            self._perm_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+        if self._perm_buf.numel() != n:
+            self._perm_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+        ps = self._perm_stream
+        ps.wait_stream(torch.cuda.current_stream())           # (the previous update's gather has read the buffer)
+        with torch.cuda.stream(ps):
+            torch.randperm(n, device=self.device, out=self._perm_buf)
+        self._perm_event = ps.record_event()
+
+    def _take_permutation(self, n):
+        ev = self.__dict__.get("_perm_event")
+        if ev is None or self._perm_buf.numel() != n:
+            return None
+        self._perm_event = None
+        torch.cuda.current_stream().wait_event(ev)
+        return self._perm_buf
+
     def _rollout_step(self, obs_dict):
         """mh_ppo.py:270-342.  Per control step: the policy stack + sampling / log-prob / buffer writes (one launch), the fused env step —
         which writes the next observations straight into the next rollout-buffer slab — and ONE done / episode-statistics kernel; the
@@ -418,6 +444,7 @@ class MHPPO:
         keys = list(obs_dict.keys())
         K = _lib.K
         counter = env.globals[K["PBHC_G_STEP_COUNTER"]:].data_ptr()
+        self._prefetch_permutation(T * N)
         std = self.actor.std
         stream = _lib.current_stream()
         with torch.inference_mode():
@@ -615,6 +642,8 @@ class MHPPO:
         if self._need_next:
             keys += ["next_actor_obs", "next_critic_obs"]
         loss["_acc"] = meters[len(names):]                     # {surrogate, value, entropy, kl} summed by the loss kernel itself, one slot per scalar
+        if indices is None:
+            indices = self._take_permutation(self.storage.num_envs * self.storage.num_transitions_per_env)      # (None: drawn by the generator now)
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, keys=keys, indices=indices):
             self._update_ppo(batch, loss)
         acc = loss.pop("_acc")

@@ -438,6 +438,8 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k8 & 1][i][s], b[k8 & 1][j][s], acc[i][j], 0, 0, 0);
+      // (s_setprio 1 / 3 around this block — favouring waves that are issuing MFMAs over co-resident waves in their prologue / epilogue —
+      // measured in the update: 29.64 / 29.67 / 29.63 ms per update without / with priority 1 / 3: nothing)
     }
   };
 
