@@ -235,11 +235,12 @@ class _FusedMLP(torch.autograd.Function):
             gb = l.bias.grad if direct else torch.empty(n, device=d.device)
             part = scratch[offs[i]:offs[i] + MAXB * n]
             k_in = l.in_features
-            if (i == L - 1 and i > 0 and ctx.fused and OUT_BWD and ctx.act in (1, 3) and 8 < n <= 32 and k_in in (64, 128, 192, 256) and l.weight.is_contiguous()
-                    and ins[i].is_contiguous()):
-                # the narrow output layer: weight / bias / input gradient and the activation backward of the layer below in ONE pass over the rows
-                # (ELU / ReLU stacks with 9..32 outputs: measured slower than the four launches on the general-tracking agent's SiLU stacks,
-                # whose derivative needs a second row stream and an exp per element — 58 / 45 us for 29 / 1 outputs)
+            if (i == L - 1 and i > 0 and ctx.fused and OUT_BWD and l.weight.is_contiguous() and ins[i].is_contiguous()
+                    and ((k_in == 128 and 1 <= n <= 32) or (ctx.act in (1, 3) and 8 < n <= 32 and k_in in (64, 192, 256)))):
+                # the narrow output layer: weight / bias / input gradient and the activation backward of the layer below in ONE pass over the rows.
+                # 128 inputs (every shipped stack): on the matrix cores, any activation, 1..32 outputs.  Other widths: the streaming form, ELU /
+                # ReLU stacks with 9..32 outputs only (it measured slower than the four launches on SiLU stacks, whose derivative needs a second
+                # row stream and an exp per element — 58 / 45 us for 29 / 1 outputs)
                 # (`pbhc_linear_out_bwd`; autograd: two library launches of split-K for 0.14 GFLOP, a column sum, a GEMM and an activation pass)
                 gw = l.weight.grad if direct else torch.empty(n, k_in, device=d.device)
                 part_dw = torch.empty(MAXB * n * k_in, device=d.device)    # (a local: alive until the finishing launch below has been queued)
