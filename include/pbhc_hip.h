@@ -267,6 +267,10 @@ typedef struct PbhcEnvConfig {
   float noise_degree, noise_down, noise_up, noise_min, noise_max;
   int32_t num_compute_average_epl;
   int32_t soft_pos_curriculum, soft_vel_curriculum, soft_tau_curriculum;
+  /* rewards.reward_limit.reward_limits_curriculum (legged_robot_base.py:902-939), [0] dof_pos, [1] dof_vel, [2] torque: at every step that
+   * resets an env the value PBHC_G_SOFT_{POS,VEL,TAU}_VAL moves by (1 +/- degree) when the average episode length is below `down` / above `up`
+   * — the limits WIDEN while episodes are short — and is clipped to [min, max] (the shipped yamls have min == max: a constant) */
+  float soft_cur_degree[3], soft_cur_down[3], soft_cur_up[3], soft_cur_min[3], soft_cur_max[3];
   float soft_dof_vel_limit, soft_torque_limit;
   float max_episode_length_s;
   /* observations */

@@ -148,6 +148,18 @@ __global__ __launch_bounds__(64 * PBHC_FIN_CHUNKS) void k_env_finalize(const Pbh
       else if (avg > c.penalty_up) p *= (1.0 + (double)c.penalty_degree);
       glob[PBHC_G_PENALTY_SCALE] = fmin(fmax(p, (double)c.penalty_min), (double)c.penalty_max);
     }
+    {                                     // _update_reward_limits_curriculum, legged_robot_base.py:902-939 (python floats: double)
+      const int on[3] = {c.soft_pos_curriculum, c.soft_vel_curriculum, c.soft_tau_curriculum};
+      const int slot[3] = {PBHC_G_SOFT_POS_VAL, PBHC_G_SOFT_VEL_VAL, PBHC_G_SOFT_TAU_VAL};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (!on[q]) continue;
+        double v = glob[slot[q]];
+        if (avg < c.soft_cur_down[q]) v *= (1.0 + (double)c.soft_cur_degree[q]);
+        else if (avg > c.soft_cur_up[q]) v *= (1.0 - (double)c.soft_cur_degree[q]);
+        glob[slot[q]] = fmin(fmax(v, (double)c.soft_cur_min[q]), (double)c.soft_cur_max[q]);
+      }
+    }
     if (c.noise_curriculum) {             // _update_obs_noise_curriculum, legged_robot_base.py:1117-1126 (after the penalty / limit curricula)
       double v = glob[PBHC_G_NOISE_CURRICULUM];
       if (avg < c.noise_down) v *= (1.0 - (double)c.noise_degree);

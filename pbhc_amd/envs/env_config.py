@@ -329,9 +329,13 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     c.soft_pos_curriculum = int(bool(lc.soft_dof_pos_curriculum))
     c.soft_vel_curriculum = int(bool(lc.soft_dof_vel_curriculum))
     c.soft_tau_curriculum = int(bool(lc.soft_torque_curriculum))
-    for pre in ("soft_dof_pos", "soft_dof_vel", "soft_torque"):
-        if lc[pre + "_curriculum"] and lc[pre + "_min_limit"] != lc[pre + "_max_limit"]:
-            raise NotImplementedError(f"non-degenerate {pre} limit curriculum")        # shipped yamls have min == max
+    for q, pre in enumerate(("soft_dof_pos", "soft_dof_vel", "soft_torque")):       # legged_robot_base.py:902-939 (device rule in k_env_finalize)
+        if lc[pre + "_curriculum"]:
+            c.soft_cur_degree[q] = float(lc[pre + "_curriculum_degree"])
+            c.soft_cur_down[q] = float(lc[pre + "_curriculum_level_down_threshold"])
+            c.soft_cur_up[q] = float(lc[pre + "_curriculum_level_up_threshold"])
+            c.soft_cur_min[q] = float(lc[pre + "_min_limit"])
+            c.soft_cur_max[q] = float(lc[pre + "_max_limit"])
     c.soft_dof_vel_limit = float(rw.reward_limit.soft_dof_vel_limit)
     c.soft_torque_limit = float(rw.reward_limit.soft_torque_limit)
     # ---- features

@@ -688,6 +688,10 @@ class LeggedRobotMotionTracking:
             "average_episode_length": g[K["PBHC_G_AVG_EP_LEN"]], "terminate_when_motion_far_threshold": g[K["PBHC_G_MOTION_FAR_THR"]],
             "reward_mean": g[L0 + K["PBHC_L_REW_MEAN"]],
         }
+        for flag, slot, name in ((self._c.soft_pos_curriculum, "PBHC_G_SOFT_POS_VAL", "soft_dof_pos"), (self._c.soft_vel_curriculum, "PBHC_G_SOFT_VEL_VAL", "soft_dof_vel"),
+                                 (self._c.soft_tau_curriculum, "PBHC_G_SOFT_TAU_VAL", "soft_torque")):
+            if flag:                                      # legged_robot_base.py:753-758
+                out[name + "_curriculum_value"] = g[K[slot]]
         if self._c.terminate_by_contact:
             out["terminate_by_contact"] = g[L0 + K["PBHC_L_TERM_CONTACT"]]
         if self._c.terminate_by_low_height:

@@ -328,6 +328,18 @@ def test_env_step_noise_curriculum_follows_the_oracle():
     _env_step_vs_oracle(512, 4, overrides=ov, noise_curriculum=True)
 
 
+def test_env_step_soft_limit_curricula_follow_the_oracle():
+    """rewards.reward_limit.reward_limits_curriculum with min != max (legged_robot_base.py:902-939; the shipped yamls pin the value with
+    min == max): the three soft-limit fractions move by (1 +/- degree) at every step that resets an env — episodes are short here, so the limits
+    widen step by step until the clip — and the limit penalties are computed against the moving value (device rule in k_env_finalize)."""
+    lc = "rewards.reward_limit.reward_limits_curriculum."
+    ov = {lc + "soft_dof_pos_curriculum": True, lc + "soft_dof_vel_curriculum": True, lc + "soft_torque_curriculum": True}
+    for pre, init, lo, hi, deg in (("soft_dof_pos", 0.5, 0.4, 0.56, 0.05), ("soft_dof_vel", 0.3, 0.2, 0.9, 0.1), ("soft_torque", 0.1, 0.05, 0.9, 0.2)):
+        ov.update({lc + pre + "_initial_limit": init, lc + pre + "_min_limit": lo, lc + pre + "_max_limit": hi, lc + pre + "_curriculum_degree": deg,
+                   lc + pre + "_curriculum_level_down_threshold": 40, lc + pre + "_curriculum_level_up_threshold": 42})
+    _env_step_vs_oracle(512, 4, overrides=ov, soft_limits=True)
+
+
 def test_env_step_close_to_limit_terminations():
     """termination.terminate_when_close_to_{dof_pos,dof_vel,torque}_limit (legged_robot_base.py:449-479; off in the shipped yamls): with a
     per-step probability an env terminates when a joint is beyond its termination limit — the three gates' uniforms are injected (open / closed
@@ -381,7 +393,7 @@ def _lib_K():
 
 
 def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yaml", overrides=None, contact_hits=False, noise_curriculum=False, default_bias=False, gates=None,
-                        redraw_steps=()):
+                        redraw_steps=(), soft_limits=False):
     from oracle.env_v1 import MotionTrackingOracle
     from oracle.fk import sim_fk
     from oracle.motion_lib import MotionLib as OML
@@ -473,6 +485,14 @@ def _env_step_vs_oracle(N, T, tag="horse", cfgname="v1_g1_23dof_horse_stance.yam
         if default_bias and "default_dof_pos" in orc.s:
             close(env.default_dof_pos, orc.s["default_dof_pos"], 1e-7, w + "default_dof_pos")
             assert float((orc.s["default_dof_pos"] - orc.default_dof_pos).abs().max()) > 0.01
+        if soft_limits:
+            log = env.read_log()
+            for name, val in (("soft_dof_pos", orc.soft_pos_val), ("soft_dof_vel", orc.soft_vel_val), ("soft_torque", orc.soft_tau_val)):
+                close(torch.tensor(float(log[name + "_curriculum_value"])), torch.tensor(float(val)), 1e-12, w + name + " curriculum value", rtol=1e-12)
+            if k == T - 1:                                # moved from the initial values (pos: into its clip), and the penalties saw it
+                assert orc.soft_pos_val == 0.56 and 0.3 < orc.soft_vel_val < 0.9 and 0.1 < orc.soft_tau_val < 0.9
+                for term in ("limits_dof_pos", "limits_dof_vel", "limits_torque"):
+                    assert term in env.episode_sums, term
         if noise_curriculum:
             assert orc.noise_curriculum and 0.0 < orc.noise_cur < 0.05
             close(torch.tensor(float(env.read_log()["current_noise_curriculum_value"])), torch.tensor(orc.noise_cur), 1e-9, w + "noise curriculum value")
