@@ -570,6 +570,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // The config is read through the CONSTANT address space: the kernel never writes it, and saying so lets the compiler keep its
   // scalars in SGPRs across the kernel's global stores.
   WG_STAMP(0);
+#ifdef PBHC_STAGGER
+  // experiment: every other workgroup starts PBHC_STAGGER x ~1 us late, so that one half of a CU's workgroups is in its load burst while
+  // the other half computes (see DESIGN §4 for what it measured)
+  if (blockIdx.x & 1)
+    for (int i = 0; i < PBHC_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
   typedef const PbhcEnvConfig __attribute__((address_space(4))) ConstCfg;
   ConstCfg& rt = *(ConstCfg*)cfgp;
 #ifdef PBHC_STATIC_CFG
