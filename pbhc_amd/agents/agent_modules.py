@@ -91,6 +91,31 @@ def _linear_relu(x, lin):
     return F.relu(_linear(x, lin))
 
 
+def _conv_window_grads(x, dz, wp, k, s, need_dx):
+    """dx [B, T, C] (or None) and dw [O, k*C] of the L window GEMMs of a Conv1d backward: dz [B, L, O] (contiguous), x [B, T, C] (contiguous),
+    wp [O, k*C].  One window's product (24 576 rows x 40 x 360: 0.7 GFLOP) fills a fraction of the chip — 18-20 us each at 35 TFLOP/s, sixteen
+    per optimiser step for the motion encoder's first layer — but queueing the independent ones on side streams (the L weight-gradient
+    products; the input-gradient products of windows ceil(k / s) apart, which touch disjoint time steps) measured 85.6 against 75.3 ms per
+    update on MI355X: concurrent small GEMMs slow each other by more than the overlap saves, as every two-stream form of the update did."""
+    B, T, Cin = x.shape
+    L, O = dz.shape[1], dz.shape[2]
+    kC = k * Cin
+    dx = None
+    if need_dx:
+        dx = torch.zeros_like(x)
+        for l in range(L):                                               # overlapping windows: sequential accumulation
+            dx[:, l * s:l * s + k, :].reshape(B, kC).addmm_(dz[:, l, :], wp)
+    P = 1
+    while P < 64 and B % (2 * P) == 0 and B // (2 * P) >= 256:
+        P *= 2
+    part = None
+    for l in range(L):
+        a = x[:, l * s:l * s + k, :].reshape(B, kC).view(P, B // P, kC)
+        g = dz[:, l, :].view(P, B // P, O).transpose(1, 2)
+        part = torch.bmm(g, a) if part is None else torch.baddbmm(part, g, a, out=part)
+    return dx, part.sum(0)
+
+
 class _WindowConv1d(torch.autograd.Function):
     """nn.Conv1d(C -> O, kernel k, stride s, no padding) on x [B, T, C] (time-major rows, the layout the per-step Linear produces) -> [B, L, O].
 
@@ -127,20 +152,8 @@ class _WindowConv1d(torch.autograd.Function):
         L = dy.shape[1]
         dy = dy.contiguous()
         wp = w.permute(0, 2, 1).reshape(O, k * Cin)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(x)
-            for l in range(L):                                           # overlapping windows: sequential accumulation
-                dx[:, l * s:l * s + k, :].reshape(B, k * Cin).addmm_(dy[:, l, :], wp)
-        P = 1
-        while P < 64 and B % (2 * P) == 0 and B // (2 * P) >= 256:
-            P *= 2
-        part = None
-        for l in range(L):
-            a = x[:, l * s:l * s + k, :].reshape(B, k * Cin).view(P, B // P, k * Cin)
-            g = dy[:, l, :].view(P, B // P, O).transpose(1, 2)
-            part = torch.bmm(g, a) if part is None else torch.baddbmm(part, g, a, out=part)
-        dw = part.sum(0).view(O, k, Cin).permute(0, 2, 1)
+        dx, dwp = _conv_window_grads(x, dy, wp, k, s, ctx.needs_input_grad[0])
+        dw = dwp.view(O, k, Cin).permute(0, 2, 1)
         return dx, dw, dy.sum((0, 1)), None, None
 
 
@@ -183,20 +196,8 @@ class _WindowConv1dAct(torch.autograd.Function):
         _lib.check(_lib.lib().pbhc_act_bwd_bias(dy.data_ptr(), saved.data_ptr(), B * L, O, ctx.act, dz.data_ptr(), gb.data_ptr(), scratch.data_ptr(),
                                                 _lib.current_stream()), "pbhc_act_bwd_bias")
         wp = w.permute(0, 2, 1).reshape(O, k * Cin)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(x)
-            for l in range(L):                                           # overlapping windows: sequential accumulation
-                dx[:, l * s:l * s + k, :].reshape(B, k * Cin).addmm_(dz[:, l, :], wp)
-        P = 1
-        while P < 64 and B % (2 * P) == 0 and B // (2 * P) >= 256:
-            P *= 2
-        part = None
-        for l in range(L):
-            a = x[:, l * s:l * s + k, :].reshape(B, k * Cin).view(P, B // P, k * Cin)
-            g = dz[:, l, :].view(P, B // P, O).transpose(1, 2)
-            part = torch.bmm(g, a) if part is None else torch.baddbmm(part, g, a, out=part)
-        dw = part.sum(0).view(O, k, Cin).permute(0, 2, 1)
+        dx, dwp = _conv_window_grads(x, dz, wp, k, s, ctx.needs_input_grad[0])
+        dw = dwp.view(O, k, Cin).permute(0, 2, 1)
         return dx, dw, gb, None, None, None
 
 
