@@ -55,13 +55,36 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
   const float sigma = lane < A ? stdp[lane] : 1.0f;            // Normal(mean, mean*0 + std): sigma is the parameter itself
   const float var = sigma * sigma, lsig = logf(sigma);
   float a_surr = 0.0f, a_vl = 0.0f, a_kl = 0.0f, a_sig = 0.0f;  // lane 0: the group's scalar sums; lane a < A: its d sigma sum
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // LOSS_U tiles per trip, ALL their loads requested before the first is used: with one tile per trip a block's six tiles were six dependent
+  // round trips to memory (17.7 -> 12.0 us for 20 MB at two blocks per CU; six tiles per trip: the same)
+  constexpr int LOSS_U = 3;
+  struct TileIn { float m, x, om, os, a, olp, v, ov, ret; };
+  for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += LOSS_U * gridDim.x) {
+    TileIn in[LOSS_U];
+#pragma unroll
+    for (int u = 0; u < LOSS_U; ++u) {
+      const int tile = tile0 + u * gridDim.x;
+      const int row = tile * LOSS_ROWS + lr_;
+      const bool valid = tile < ntiles && row < B;
+      in[u] = TileIn{0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (valid && lane < A) {
+        const size_t i = (size_t)row * A + lane;
+        in[u].m = mu[i]; in[u].x = actions[i]; in[u].om = old_mu[i]; in[u].os = old_sigma[i];
+      }
+      if (valid) { in[u].a = adv[row]; in[u].olp = old_logp[row]; }
+      if (valid && lane < R) {
+        const size_t i = (size_t)row * R + lane;
+        in[u].v = value[i]; in[u].ov = old_values[i]; in[u].ret = returns[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LOSS_U; ++u) {
+    const int tile = tile0 + u * gridDim.x;
     const int row = tile * LOSS_ROWS + lr_;
-    const bool valid = row < B;
+    const bool valid = tile < ntiles && row < B;
     float lp = 0.0f, kl = 0.0f, dmu_c = 0.0f, dsig_c = 0.0f;     // per-lane pieces
     if (valid && lane < A) {
-      const size_t i = (size_t)row * A + lane;
-      const float m = mu[i], x = actions[i], om = old_mu[i], os = old_sigma[i];
+      const float m = in[u].m, x = in[u].x, om = in[u].om, os = in[u].os;
       const float d = x - m;
       // torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(sigma) - log(sqrt(2 pi))
       lp = -(d * d) / (2.0f * var) - lsig - 0.9189385332046727f;
@@ -74,8 +97,8 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
     const float klrow = gsum32(kl);
     float surr = 0.0f, coef = 0.0f;
     if (valid) {
-      const float a = adv[row];
-      const float ratio = expf(logp - old_logp[row]);
+      const float a = in[u].a;
+      const float ratio = expf(logp - in[u].olp);
       const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
       const float s1 = -a * ratio, s2 = -a * rc;
       surr = fmaxf(s1, s2);
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
     float vl = 0.0f;
     if (valid && lane < R) {
       const size_t i = (size_t)row * R + lane;
-      const float v = value[i], ov = old_values[i], ret = returns[i];
+      const float v = in[u].v, ov = in[u].ov, ret = in[u].ret;
       float g;
       if (clipped_value) {
         const float dv = v - ov;
@@ -115,6 +138,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float* __restrict__ mu, 
       a_vl += vlrow;
       a_kl += klrow;
       if (lane < A) a_sig += coef * dsig_c;
+    }
     }
   }
   if (lane == 0) { sh_s[lr_][0] = a_surr; sh_s[lr_][1] = a_vl; sh_s[lr_][2] = a_kl; }
