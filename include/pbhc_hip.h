@@ -535,8 +535,9 @@ int pbhc_colsum_final(const PbhcColsumJob* jobs, int num_jobs, void* stream);
  *                                                    colsum(dh); finish each with a pbhc_colsum_final job (n = A*K, A, K). */
 int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,
                         float* part_db, float* part_cs, int* num_row_blocks, void* stream);
-/* test / measurement aid: 0 = the streaming VALU form of pbhc_linear_out_bwd for every shape (default 1: K = 128 with the derivative taken from
- * the output runs on the matrix cores) */
+/* test / measurement aid.  bits 0-7: 0 = the streaming VALU form of pbhc_linear_out_bwd for every shape (default 1: K = 128 runs on the matrix
+ * cores); bits 8-15: 32-row tiles per workgroup of the matrix-core form (0 / 1: one — measured in the update: 28.85 / 28.84 / 29.1 ms per update
+ * at 1 / 2 / 3, i.e. fewer partial rows buy nothing) */
 void pbhc_debug_out_bwd_variant(int mfma);
 
 

@@ -819,7 +819,7 @@ int pbhc_act_bwd_partials(const float* dy, const float* saved, int B, int n, int
   return PBHC_OK;
 }
 
-static int g_out_bwd_mfma = 1;
+static int g_out_bwd_mfma = 1, g_out_bwd_tiles_per_wg = 0;
 int pbhc_gather_rows(const PbhcGatherJob* jobs, int num_jobs, const int64_t* index, int nrows, void* stream) {
   ARG_CHECK(jobs && index && num_jobs >= 1 && num_jobs <= PBHC_MAX_GATHER_JOBS && nrows >= 1);
   GatherJobs J;
@@ -836,7 +836,7 @@ int pbhc_gather_rows(const PbhcGatherJob* jobs, int num_jobs, const int64_t* ind
   return PBHC_OK;
 }
 
-void pbhc_debug_out_bwd_variant(int mfma) { g_out_bwd_mfma = mfma; }       // test / measurement aid: 0 = the streaming VALU form for every shape
+void pbhc_debug_out_bwd_variant(int mfma) { g_out_bwd_mfma = mfma & 0xff; g_out_bwd_tiles_per_wg = (mfma >> 8) & 0xff; }       // test / measurement aid: 0 = the streaming VALU form for every shape
 
 int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, const float* w, int M, int A, int K, int act, float* dh, float* part_dw,
                         float* part_db, float* part_cs, int* num_row_blocks, void* stream) {
@@ -845,7 +845,9 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
   hipStream_t st = (hipStream_t)stream;
   if (K == 128 && (saved || act != 2) && g_out_bwd_mfma) {
     const int ntiles = (M + 31) / 32;
-    const int grid = ntiles < PBHC_ACT_MAX_BLOCKS ? ntiles : PBHC_ACT_MAX_BLOCKS;
+    const int tpw = g_out_bwd_tiles_per_wg > 0 ? g_out_bwd_tiles_per_wg : 1;        // tiles per workgroup (measurement aid; 1: every tile its own workgroup)
+    int grid = (ntiles + tpw - 1) / tpw;
+    if (grid > PBHC_ACT_MAX_BLOCKS) grid = PBHC_ACT_MAX_BLOCKS;
     *num_row_blocks = grid;
     if (saved) hipLaunchKernelGGL(k_out_bwd_mfma<true>, dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
     else hipLaunchKernelGGL(k_out_bwd_mfma<false>, dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
