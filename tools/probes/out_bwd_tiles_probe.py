@@ -1,5 +1,6 @@
+"""Update time per iteration (v1, 4096 envs) with k_out_bwd_mfma taking V 32-row tiles per workgroup: python3 tools/probes/out_bwd_tiles_probe.py V"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from pbhc_amd import _lib
