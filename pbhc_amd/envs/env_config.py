@@ -208,7 +208,20 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     # ---- termination
     T = ec.termination
     if T.get("terminate_when_dof_far", False):
+        # motion_tracking.py:345 reduces torch.any(norm(dif_joint_angles) > threshold) over the ENV axis: one env past the threshold resets all
+        # of them — a batch-global decision inside a step (a grid-wide exchange before the reset path; a collective per step under data parallelism)
         raise NotImplementedError("termination.terminate_when_dof_far")
+    if float(ec.get("noise_to_initial_level", 0) or 0) != 0.0:
+        # motion_tracking.py:481-484,538-539 / general_tracking.py:413-416,478-479: normal noise on the state an env is reset to (and on the
+        # observations of that step); 0 in every shipped yaml.  The in-kernel reset path writes the reference state as it is.
+        raise NotImplementedError("noise_to_initial_level != 0 (noise on the reset state)")
+    if ec.get("use_teleop_control", False):
+        raise NotImplementedError("use_teleop_control (a ROS subscriber feeding marker coordinates, motion_tracking.py:112-118)")
+    sdc = ec.get("soft_dynamic_correction", None)
+    if sdc is not None and sdc.get("enable", False):
+        # motion_tracking.py:806-860 blends the SIMULATOR's state towards the reference between physics sub-steps: it acts on the physics, which
+        # the replay stub does not have (the states it hands out are whatever the replay holds)
+        raise NotImplementedError("soft_dynamic_correction (acts inside the simulator's physics sub-steps; the replay stub has none)")
     # legged_robot_base.py:449-479 + isaacgym.py:387-388: probabilistic terminations near the joint limits (one uniform per gate and STEP)
     TS, TP = ec.termination_scales, ec.get("termination_probality", {})
     c.terminate_close_pos = int(bool(T.get("terminate_when_close_to_dof_pos_limit", False)))
