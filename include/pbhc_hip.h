@@ -440,6 +440,9 @@ void pbhc_env_destroy(PbhcEnv* env);
  *                                generate the specialised kernels of known configs ahead of time */
 int pbhc_env_get_config(PbhcEnv* env, PbhcEnvConfig* out);
 int pbhc_env_config_finalize(const PbhcEnvConfig* cfg, PbhcEnvConfig* out);
+/* Dynamic LDS (bytes) of one k_env_step workgroup — 4 envs: state, bodies, reference frame, feature row, skeleton constants, compact
+ * observation maps — for this config; < 0: -(error code).  160 KB per CU / this = resident workgroups per CU (no reference counterpart). */
+int pbhc_env_config_lds_bytes(const PbhcEnvConfig* cfg);
 int pbhc_env_attach_specialised(PbhcEnv* env, const char* so_path);
 int pbhc_env_is_specialised(PbhcEnv* env);
 /* One LeggedRobotBase.step (legged_robot_base.py:239-338) for all envs: 2 launches (step + finalize). */

@@ -88,7 +88,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
            "pbhc_env_profile", "pbhc_env_profile_read", "pbhc_env_profile_overhead", "pbhc_ppo_loss", "pbhc_ppo_loss_scratch_floats", "pbhc_adam_clip",
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
-           "pbhc_linear_act_fwd", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_gather_rows", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
+           "pbhc_linear_act_fwd", "pbhc_env_config_lds_bytes", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_gather_rows", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
            "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule"]
 
@@ -121,6 +121,7 @@ def _load():
     lib.pbhc_env_attach_specialised.argtypes = [vp, C.c_char_p]
     lib.pbhc_env_is_specialised.argtypes = [vp]
     lib.pbhc_env_config_finalize.argtypes = [C.POINTER(PbhcEnvConfig), C.POINTER(PbhcEnvConfig)]
+    lib.pbhc_env_config_lds_bytes.argtypes = [C.POINTER(PbhcEnvConfig)]
     lib.pbhc_env_step.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
     lib.pbhc_env_step_launch.argtypes = [vp, C.POINTER(PbhcStepIO), vp]
     lib.pbhc_env_step_finish.argtypes = [vp, C.POINTER(PbhcStepIO), vp]

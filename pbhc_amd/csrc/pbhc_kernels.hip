@@ -625,6 +625,15 @@ int pbhc_env_config_finalize(const PbhcEnvConfig* cfg, PbhcEnvConfig* out) {
   return finalize_config(cfg, out, &lds_stride, &lds_bytes);
 }
 
+// dynamic LDS of one k_env_step workgroup (4 envs) for this config, or a negative error code.  No device is touched.
+int pbhc_env_config_lds_bytes(const PbhcEnvConfig* cfg) {
+  PbhcEnvConfig fin;
+  int lds_stride = 0;
+  size_t lds_bytes = 0;
+  const int rc = finalize_config(cfg, &fin, &lds_stride, &lds_bytes);
+  return rc != PBHC_OK ? -rc : (int)lds_bytes;
+}
+
 int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double* globals, PbhcEnv** out) {
   ARG_CHECK(cfg && tbl && globals && out);
   PbhcEnv* e = new (std::nothrow) PbhcEnv();
