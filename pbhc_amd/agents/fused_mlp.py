@@ -91,8 +91,10 @@ def _wgrad_library(d, x, out, defer=None):
     B = d.shape[0]
     nk = n * k
     # (chosen in the update itself — bench.py with PBHC_WGRAD_P — not in a back-to-back probe, whose operands are warm in L2: 512 x 380 8 -> 4 parts
-    # -0.35 ms per update, 768 x 630 one GEMM -> 2 parts -0.30, 256 x 512 16 -> 32 and 128 x 512 8 -> 16 another -0.05; 512 x 768 stays one GEMM)
-    P = 0 if n < 64 else 32 if nk <= 128 * 256 else 16 if nk <= 128 * 512 else 32 if nk <= 256 * 512 else 4 if nk <= 512 * 384 else 0 if nk <= 512 * 768 else 2
+    # -0.35 ms per update, 768 x 630 one GEMM -> 2 parts -0.30, 256 x 512 16 -> 32 and 128 x 512 8 -> 16 another -0.05.  Round 3, with the
+    # partial images summed by the backward's one finishing launch instead of a torch.sum each: 512 x 768 one GEMM -> 4 parts and 768 x 630
+    # 2 -> 8 parts, 29.3 -> 28.85 ms per update on one box (16 parts: slower again) — tools/probes/wgrad_parts_sweep.sh)
+    P = 0 if n < 64 else 32 if nk <= 128 * 256 else 16 if nk <= 128 * 512 else 32 if nk <= 256 * 512 else 4 if nk <= 512 * 768 else 8
     if _WGRAD_P:                                       # measurement aid: PBHC_WGRAD_P="512x380:4,256x512:8"
         P = _WGRAD_P.get((n, k), P)
     if P == 0 or B % P or B // P < 256:
