@@ -238,9 +238,9 @@ class _FusedMLP(torch.autograd.Function):
             part = scratch[offs[i]:offs[i] + MAXB * n]
             k_in = l.in_features
             if (i == L - 1 and i > 0 and ctx.fused and OUT_BWD and l.weight.is_contiguous() and ins[i].is_contiguous()
-                    and ((k_in == 128 and 1 <= n <= 32) or (ctx.act in (1, 3) and 8 < n <= 32 and k_in in (64, 192, 256)))):
+                    and ((k_in in (128, 256) and 1 <= n <= 32) or (ctx.act in (1, 3) and 8 < n <= 32 and k_in in (64, 192)))):
                 # the narrow output layer: weight / bias / input gradient and the activation backward of the layer below in ONE pass over the rows.
-                # 128 inputs (every shipped stack): on the matrix cores, any activation, 1..32 outputs.  Other widths: the streaming form, ELU /
+                # 128 / 256 inputs (every shipped stack): on the matrix cores, any activation, 1..32 outputs.  Other widths: the streaming form, ELU /
                 # ReLU stacks with 9..32 outputs only (it measured slower than the four launches on SiLU stacks, whose derivative needs a second
                 # row stream and an exp per element — 58 / 45 us for 29 / 1 outputs)
                 # (`pbhc_linear_out_bwd`; autograd: two library launches of split-K for 0.14 GFLOP, a column sum, a GEMM and an activation pass)

@@ -631,20 +631,22 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
 typedef float outb_f32x16 __attribute__((ext_vector_type(16)));
 typedef float outb_f32x4 __attribute__((ext_vector_type(4)));
 #define OUTM_DS 36                   // row stride of the dy image (floats)
-template <bool SAVED>
-__global__ __launch_bounds__(256) void k_out_bwd_mfma(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ saved,
+// KT = 128 / 256 inputs: KT / 32 waves per workgroup, one 32-column block each
+template <bool SAVED, int KT>
+__global__ __launch_bounds__(2 * KT) void k_out_bwd_mfma(const float* __restrict__ dy, const float* __restrict__ h, const float* __restrict__ saved,
                                                       const float* __restrict__ w, int M, int A, int act, int ntiles, float* __restrict__ dh,
                                                       float* __restrict__ part_dw, float* __restrict__ part_db, float* __restrict__ part_cs) {
   // SAVED: the derivative's argument is a second tensor (SiLU: the pre-activation) — 16 more loads per lane in the same layout
   __shared__ __attribute__((aligned(16))) float dyimg[32 * OUTM_DS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, kk = lane >> 5;
   const int col = 32 * wave + r;
-  for (int i = tid; i < 32 * OUTM_DS; i += 256) dyimg[i] = 0.0f;          // the padding (outputs A..35) stays zero
+  constexpr int NT = 2 * KT;                                               // threads per workgroup
+  for (int i = tid; i < 32 * OUTM_DS; i += NT) dyimg[i] = 0.0f;          // the padding (outputs A..35) stays zero
   float wb[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int n = 8 * (e >> 2) + 4 * kk + (e & 3);
-    wb[e] = n < A ? w[(size_t)n * 128 + col] : 0.0f;
+    wb[e] = n < A ? w[(size_t)n * KT + col] : 0.0f;
   }
   outb_f32x16 accw;
 #pragma unroll
@@ -657,14 +659,14 @@ __global__ __launch_bounds__(256) void k_out_bwd_mfma(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = row0 + 8 * (e >> 2) + 4 * kk + (e & 3);
-      hv[e] = row < M ? h[(size_t)row * 128 + col] : 0.0f;
-      if (SAVED) sv[e] = row < M ? saved[(size_t)row * 128 + col] : 0.0f;
+      hv[e] = row < M ? h[(size_t)row * KT + col] : 0.0f;
+      if (SAVED) sv[e] = row < M ? saved[(size_t)row * KT + col] : 0.0f;
     }
     __syncthreads();                                                     // the previous tile's image has been read (first tile: the zero fill is complete)
     {
       const float* src = dy + (size_t)row0 * A;
       const int lim = min(tile_elems, (M - row0) * A);
-      for (int i = tid; i < tile_elems; i += 256) {
+      for (int i = tid; i < tile_elems; i += NT) {
         const int rr = i / A, n = i - rr * A;
         dyimg[rr * OUTM_DS + n] = i < lim ? src[i] : 0.0f;
       }
@@ -699,17 +701,17 @@ __global__ __launch_bounds__(256) void k_out_bwd_mfma(const float* __restrict__ 
       else if (act == 2) { const float sg = 1.0f / (1.0f + expf(-hh)); gr = sg * (1.0f + hh * (1.0f - sg)); }
       else if (act == 3) gr = hh > 0.0f ? 1.0f : 0.0f;
       const float g = acc[e] * gr;
-      if (row < M) { dh[(size_t)row * 128 + col] = g; cs += g; }
+      if (row < M) { dh[(size_t)row * KT + col] = g; cs += g; }
     }
   }
   const size_t pb = blockIdx.x;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int n = 8 * (e >> 2) + 4 * kk + (e & 3);
-    if (n < A) part_dw[pb * (size_t)(A * 128) + (size_t)n * 128 + col] = accw[e];
+    if (n < A) part_dw[pb * (size_t)(A * KT) + (size_t)n * KT + col] = accw[e];
   }
   cs += __shfl_xor(cs, 32, 64);
-  if (kk == 0) part_cs[pb * 128 + col] = cs;
+  if (kk == 0) part_cs[pb * KT + col] = cs;
   if (wave == 0 && kk == 0 && r < A) part_db[pb * A + r] = dbacc;
 }
 
@@ -843,14 +845,19 @@ int pbhc_linear_out_bwd(const float* dy, const float* h, const float* saved, con
   ARG_CHECK(dy && h && w && dh && part_dw && part_db && part_cs && num_row_blocks && M >= 1 && A >= 1 && A <= 32 && act >= 0 && act <= 3);
   ARG_CHECK(K == 64 || K == 128 || K == 192 || K == 256);
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128 && (saved || act != 2) && g_out_bwd_mfma) {
+  if ((K == 128 || K == 256) && (saved || act != 2) && g_out_bwd_mfma) {
     const int ntiles = (M + 31) / 32;
     const int tpw = g_out_bwd_tiles_per_wg > 0 ? g_out_bwd_tiles_per_wg : 1;        // tiles per workgroup (measurement aid; 1: every tile its own workgroup)
     int grid = (ntiles + tpw - 1) / tpw;
     if (grid > PBHC_ACT_MAX_BLOCKS) grid = PBHC_ACT_MAX_BLOCKS;
     *num_row_blocks = grid;
-    if (saved) hipLaunchKernelGGL(k_out_bwd_mfma<true>, dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
-    else hipLaunchKernelGGL(k_out_bwd_mfma<false>, dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+    if (K == 128) {
+      if (saved) hipLaunchKernelGGL((k_out_bwd_mfma<true, 128>), dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+      else hipLaunchKernelGGL((k_out_bwd_mfma<false, 128>), dim3(grid), dim3(256), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+    } else {
+      if (saved) hipLaunchKernelGGL((k_out_bwd_mfma<true, 256>), dim3(grid), dim3(512), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+      else hipLaunchKernelGGL((k_out_bwd_mfma<false, 256>), dim3(grid), dim3(512), 0, st, dy, h, saved, w, M, A, act, ntiles, dh, part_dw, part_db, part_cs);
+    }
     HIP_CHECK(hipGetLastError());
     return PBHC_OK;
   }

@@ -239,7 +239,7 @@ def test_module_inference_forward_uses_the_stack_kernel_and_matches_layers():
     assert not torch.equal(a, b)                                 # (different summation order: the two paths really are different kernels)
 
 
-@pytest.mark.parametrize("shape", [(24576, 23, 128), (24576, 21, 128), (1000, 23, 128), (37, 1, 64), (4096, 32, 256), (513, 12, 192), (70001, 20, 128), (5, 9, 128), (3000, 1, 128), (24576, 29, 128)])
+@pytest.mark.parametrize("shape", [(24576, 23, 128), (24576, 21, 128), (1000, 23, 128), (37, 1, 64), (4096, 32, 256), (513, 12, 192), (70001, 20, 128), (5, 9, 128), (3000, 1, 128), (24576, 29, 128), (24576, 29, 256), (24577, 1, 256), (100, 32, 256)])
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_linear_out_bwd_matches_fp64(shape, act, mfma):
