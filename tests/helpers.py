@@ -111,6 +111,11 @@ def load_state_into_hip_env(env, st, g=None):
     gl[K["PBHC_G_AVG_EP_LEN"]] = float(st["average_episode_length"])
     gl[K["PBHC_G_MOTION_FAR_THR"]] = float(st["motion_far_threshold"])
     if g is not None:
+        # soft-limit curricula: the trace logs the fraction each step's reward pass used; the first one is the state the trace starts from
+        # (the reference's reset_all() before the trace already moved the initial values once)
+        for slot, lk in (("PBHC_G_SOFT_POS_VAL", "soft_dof_pos"), ("PBHC_G_SOFT_VEL_VAL", "soft_dof_vel"), ("PBHC_G_SOFT_TAU_VAL", "soft_torque")):
+            if "step__log__" + lk + "_curriculum_value" in g:
+                gl[K[slot]] = float(g["step__log__" + lk + "_curriculum_value"][0])
         env.env_origins.copy_(torch.from_numpy(g["env_origins"]).to(dev))
         s._base_com_bias.copy_(torch.from_numpy(g["base_com_bias"]).to(dev))
         s._link_mass_scale.copy_(torch.from_numpy(g["link_mass_scale"]).to(dev))
@@ -239,3 +244,11 @@ def expected_obs_noise(seed, env_ids, step_ctr, group_index, noise, scale, noise
     x ^= x >> np.uint64(16)
     u = (x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
     return torch.from_numpy((u * np.float32(2.0) - np.float32(1.0)) * (np.asarray(noise, np.float32) * np.float32(noise_cur))[None, :] * np.asarray(scale, np.float32)[None, :])
+
+
+# overrides of the reference trace env_v1_walk_softlim.npz (oracle/ref_harness/gen_switch_golden.py: SOFT_LIMITS)
+_LC = "rewards.reward_limit.reward_limits_curriculum."
+SOFT_LIMIT_OVERRIDES = {_LC + "soft_dof_pos_curriculum": True, _LC + "soft_dof_vel_curriculum": True, _LC + "soft_torque_curriculum": True}
+for _pre, _init, _lo, _hi, _deg in (("soft_dof_pos", 0.5, 0.4, 0.56, 0.05), ("soft_dof_vel", 0.3, 0.2, 0.9, 0.1), ("soft_torque", 0.1, 0.05, 0.9, 0.2)):
+    SOFT_LIMIT_OVERRIDES.update({_LC + _pre + "_initial_limit": _init, _LC + _pre + "_min_limit": _lo, _LC + _pre + "_max_limit": _hi, _LC + _pre + "_curriculum_degree": _deg,
+                                 _LC + _pre + "_curriculum_level_down_threshold": 40, _LC + _pre + "_curriculum_level_up_threshold": 42})
