@@ -116,6 +116,8 @@ def load_state_into_hip_env(env, st, g=None):
         for slot, lk in (("PBHC_G_SOFT_POS_VAL", "soft_dof_pos"), ("PBHC_G_SOFT_VEL_VAL", "soft_dof_vel"), ("PBHC_G_SOFT_TAU_VAL", "soft_torque")):
             if "step__log__" + lk + "_curriculum_value" in g:
                 gl[K[slot]] = float(g["step__log__" + lk + "_curriculum_value"][0])
+        if "step__log__current_noise_curriculum_value" in g:                 # likewise for the observation-noise multiplier
+            gl[K["PBHC_G_NOISE_CURRICULUM"]] = float(g["step__log__current_noise_curriculum_value"][0])
         env.env_origins.copy_(torch.from_numpy(g["env_origins"]).to(dev))
         s._base_com_bias.copy_(torch.from_numpy(g["base_com_bias"]).to(dev))
         s._link_mass_scale.copy_(torch.from_numpy(g["link_mass_scale"]).to(dev))
@@ -252,3 +254,8 @@ SOFT_LIMIT_OVERRIDES = {_LC + "soft_dof_pos_curriculum": True, _LC + "soft_dof_v
 for _pre, _init, _lo, _hi, _deg in (("soft_dof_pos", 0.5, 0.4, 0.56, 0.05), ("soft_dof_vel", 0.3, 0.2, 0.9, 0.1), ("soft_torque", 0.1, 0.05, 0.9, 0.2)):
     SOFT_LIMIT_OVERRIDES.update({_LC + _pre + "_initial_limit": _init, _LC + _pre + "_min_limit": _lo, _LC + _pre + "_max_limit": _hi, _LC + _pre + "_curriculum_degree": _deg,
                                  _LC + _pre + "_curriculum_level_down_threshold": 40, _LC + _pre + "_curriculum_level_up_threshold": 42})
+
+# overrides of the reference trace env_v1_walk_termnoise.npz (oracle/ref_harness/gen_switch_golden.py: TERM_NOISE)
+TERM_NOISE_OVERRIDES = {"env.config.termination.terminate_by_contact": True, "env.config.termination.terminate_by_low_height": True,
+                        "env.config.termination_scales.termination_min_base_height": 0.772, "obs.add_noise_currculum": True,
+                        "obs.soft_dof_pos_curriculum_degree": 0.1}

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (GOLDEN, SOFT_LIMIT_OVERRIDES, build_hip_env, clip_from_env_golden, fixture_config, load_env_golden, load_state_into_hip_env,
+from tests.helpers import (GOLDEN, SOFT_LIMIT_OVERRIDES, TERM_NOISE_OVERRIDES, build_hip_env, clip_from_env_golden, fixture_config, load_env_golden, load_state_into_hip_env,
                            skel_from_golden, state_dict_from_golden, synth_replay)
 
 pytestmark = pytest.mark.gpu
@@ -234,11 +234,12 @@ CASES = [("horse", "v1_g1_23dof_horse_stance.yaml"), ("walk", "v1_g1_23dof_walk.
 @pytest.mark.parametrize("tag,cfgname,overrides", [("walk_ctrlV", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "V"}),
                                                    ("walk_ctrlT", "v1_g1_23dof_walk.yaml", {"robot.control.control_type": "T"}),
                                                    ("walk_feetori", "v1_g1_23dof_walk.yaml", {"rewards.reward_scales.feet_heading_alignment": -0.5, "rewards.reward_scales.feet_heading_alignment_contact": -0.3, "rewards.reward_scales.penalty_feet_ori": -0.2, "rewards.reward_scales.penalty_feet_ori_contact": -0.4}),
-                                                   ("walk_softlim", "v1_g1_23dof_walk.yaml", SOFT_LIMIT_OVERRIDES)])
+                                                   ("walk_softlim", "v1_g1_23dof_walk.yaml", SOFT_LIMIT_OVERRIDES),
+                                                   ("walk_termnoise", "v1_g1_23dof_walk.yaml", TERM_NOISE_OVERRIDES)])
 def test_env_step_matches_reference_trace_of_a_switch(tag, cfgname, overrides):
-    """control types "V" and "T" (legged_robot_base.py:809-817), the four foot-orientation reward terms (:1030-1079) and the soft-limit
-    curricula with min != max (:902-939) — no shipped yaml uses them: the reference's own traces with the switch on
-    (oracle/ref_harness/gen_switch_golden.py)"""
+    """control types "V" and "T" (legged_robot_base.py:809-817), the four foot-orientation reward terms (:1030-1079), the soft-limit
+    curricula with min != max (:902-939), terminate_by_contact / terminate_by_low_height (:434-447) and the observation-noise curriculum
+    (:591-592,637-646) — no shipped yaml uses them: the reference's own traces with the switch on (oracle/ref_harness/gen_switch_golden.py)"""
     test_env_step_matches_reference_trace(tag, cfgname, overrides)
     if tag == "walk_softlim":                            # the fractions themselves, step by step (logged by the reference's reward pass)
         g = load_env_golden(tag)
@@ -298,7 +299,10 @@ def test_env_step_matches_reference_trace(tag, cfgname, overrides=None):
         log = env.read_log()
         for lk in ["terminate_by_gravity", "terminate_by_motion_far", "terminate_by_time_out", "upper_body_diff_norm", "joint_pos_diff_norm", "action_clip_frac"]:
             close(torch.tensor(log[lk]), g["step__log__" + lk][k], 1e-4, w + "log " + lk)
-        for lk in ("soft_dof_pos_curriculum_value", "soft_dof_vel_curriculum_value", "soft_torque_curriculum_value"):
+        for lk in ("terminate_by_contact", "terminate_by_low_height"):
+            if "step__log__" + lk in g:
+                close(torch.tensor(log[lk]), g["step__log__" + lk][k], 1e-4, w + "log " + lk)
+        for lk in ("soft_dof_pos_curriculum_value", "soft_dof_vel_curriculum_value", "soft_torque_curriculum_value", "current_noise_curriculum_value"):
             # the reference logs the fraction its reward pass USED in a step; after our step k the global holds the one step k + 1 will use
             if "step__log__" + lk in g and k + 1 < g["step__log__" + lk].shape[0]:
                 ref = float(g["step__log__" + lk][k + 1])
