@@ -550,7 +550,10 @@ class MHPPO:
                 ran = False
                 if graph_ok:
                     env.simulator.use_device_cursor()
-                    key = (id(st), env._io_epoch, N, T)
+                    # everything a captured env step froze: the rollout slabs, the env's io struct (its epoch moves with every pointer the env
+                    # re-points), the simulator's replay window (a new one is picked up lazily inside the next env.step(), i.e. AFTER this key
+                    # is read: the version itself belongs to the key) and which kernel — generic or specialised — the launch names
+                    key = (id(st), env._io_epoch, env.simulator.replay_version, bool(getattr(env, "is_specialised", False)), N, T)
                     gc = self.__dict__.get("_rollout_graph")
                     if gc is None or gc[0] != key:
                         gc = self._capture_rollout(key, run_loop, actor_eager, env, post_done, T)

@@ -216,11 +216,12 @@ class LeggedRobotMotionTracking:
 
     def specialise(self, mode="jit", verbose=False):
         """Run this env's steps on a build of k_env_step specialised to its config (pbhc_amd/specialise.py): "jit" compiles on a cache
-        miss (~15 s of hipcc, once per config and source version), "cached" only uses an existing object, "off" returns to the generic
+        miss (~3 s of hipcc, once per config, source and compiler version), "cached" only uses an existing object, "off" returns to the generic
         kernel.  Same source, same results; returns True when a specialised kernel is attached."""
         from .. import specialise as _spec
 
         self._specialise_mode = mode
+        self._io_epoch = getattr(self, "_io_epoch", 0) + 1         # a captured graph of steps names the kernel it was recorded with
         return _spec.attach(self._env, mode, verbose=verbose)
 
     @property

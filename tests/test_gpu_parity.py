@@ -651,8 +651,11 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     assert ih.check_onnx(file, algo.inference_model, algo.get_example_obs(), atol=1e-5) <= 1e-5
 
 
-def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True, rollout_graph=False, rollouts=3):
-    """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state"""
+def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True, rollout_graph=False, rollouts=3, train_between=False, new_replay_at=None):
+    """three rollouts (eager, graph capture, graph replay) from the same seeds; returns the last rollout's buffer + env state.
+    train_between: the timed loop of bench.py / learn() — `_training_step()` after every rollout (a fixed permutation per iteration), so the
+    weights the captured policy launch reads change under the graph.  new_replay_at: `simulator.set_replay()` with another window before
+    rollout number `new_replay_at` (a captured graph holds the old window's addresses)."""
     import os
 
     os.environ["PBHC_ROLLOUT_GRAPH"] = "1" if rollout_graph else "0"
@@ -679,12 +682,29 @@ def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True, ro
             import bench
 
             env.simulator.set_replay(*bench.make_replay_on_device(env, rollouts * algo.num_steps_per_env + 2, seed=5))
-        for _ in range(rollouts):
+        used = []
+        gperm = torch.Generator().manual_seed(23)
+        pflat_start = algo._pflat.clone() if train_between else None
+        for r in range(rollouts):
+            if new_replay_at is not None and r == new_replay_at:
+                import bench
+
+                env.simulator.set_replay(*bench.make_replay_on_device(env, (rollouts - r) * algo.num_steps_per_env + 3, seed=9))
             algo.storage.clear()
             obs = algo._rollout_step(obs)
+            used.append(bool(getattr(algo, "_rollout_used_graph", False)))
+            if train_between:
+                n = algo.storage.num_envs * algo.storage.num_transitions_per_env
+                algo._training_step(indices=torch.randperm(n, generator=gperm).to(DEV))
         torch.cuda.synchronize()
         st = algo.storage
         out = {k: getattr(st, k).clone() for k in st.stored_keys}
+        out["_used_graph_each"] = torch.tensor(used)
+        if train_between:
+            for k in ("_pflat", "_mflat", "_vflat", "_lr", "_adam_step", "_gflat"):
+                out[k] = getattr(algo, k).clone()
+            out["cur_reward_sum"], out["cur_episode_length"] = algo.cur_reward_sum.clone(), algo.cur_episode_length.clone()
+            out["_pflat_start"] = pflat_start
         out["_used_graph"] = torch.tensor([bool(getattr(algo, "_rollout_used_graph", False))])
         out["common_step_counter"] = torch.tensor([env.common_step_counter])
         out["frame_cursor"] = env.simulator.frame_cursor.clone().cpu()
@@ -720,6 +740,37 @@ def test_rollout_as_one_graph_equals_the_eager_loop():
     a = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=True, rollouts=5)
     b = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=False, rollouts=5)
     assert bool(a.pop("_used_graph")) and not bool(b.pop("_used_graph"))
+    assert a.pop("_used_graph_each").tolist() == [False, True, True, True, True] and not b.pop("_used_graph_each").any()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_graph_rollout_update_graph_replay_equals_the_eager_loop():
+    """The path bench.py times and learn() runs (mh_ppo.py:222-247): rollout as ONE replayed hipGraph -> `_training_step` (20 optimiser steps:
+    the flat weights the captured policy launch reads are rewritten in place, the policy stack is re-packed before the next replay, the Adam
+    pass leaves the gradient buffer zeroed) -> replay of the SAME graph -> ...  Four iterations against the step-by-step loop with the same
+    per-iteration permutation: every rollout-buffer key, the flat parameters, both Adam moments, the learning rates, the step counts, the
+    env's globals / episode sums and the episode statistics are bit-identical."""
+    kw = dict(batched=True, fused_sample=True, rollouts=4, train_between=True)
+    a = _rollouts_with_split(True, "v1", rollout_graph=True, **kw)
+    b = _rollouts_with_split(True, "v1", rollout_graph=False, **kw)
+    assert a.pop("_used_graph_each").tolist() == [False, True, True, True] and not b.pop("_used_graph_each").any()
+    a.pop("_used_graph"); b.pop("_used_graph")
+    assert not torch.equal(a["_pflat"], a["_pflat_start"])           # (the weights do move under the graph)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_graph_rollout_is_recaptured_after_a_new_replay_window():
+    """`simulator.set_replay()` between two rollouts: the env picks the new window up lazily inside its next step, i.e. after MHPPO has looked
+    its cached rollout graph up — the graph's key therefore carries the simulator's replay version (and whether the step kernel is the
+    specialised one), a stale graph would replay the OLD window's frame addresses.  Graph vs eager, new window before the fourth of five
+    rollouts: bit-identical."""
+    kw = dict(batched=True, fused_sample=True, rollouts=5, new_replay_at=3)
+    a = _rollouts_with_split(True, "v1", rollout_graph=True, **kw)
+    b = _rollouts_with_split(True, "v1", rollout_graph=False, **kw)
+    assert a.pop("_used_graph_each").tolist() == [False, True, True, True, True] and not b.pop("_used_graph_each").any()
+    a.pop("_used_graph"); b.pop("_used_graph")
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
