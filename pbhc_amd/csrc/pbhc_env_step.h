@@ -71,8 +71,8 @@ struct Lds {
     BP = 404,                                                                        // body pos3/quat4/vel3/ang3 x Bxp, then the reference's, same shapes
     RED_WORDS = 80, FUT_WORDS = 10 * PBHC_MAX_FUTURE                                 // reductions; general tracking: per-step future scratch
   };
-  int bq, bv, bw, rp, rq, rv, rw, red, fut, feat;
-  __host__ __device__ explicit Lds(int Bx, int mode) {
+  int bq = 0, bv = 0, bw = 0, rp = 0, rq = 0, rv = 0, rw = 0, red = 0, fut = 0, feat = 0;
+  __host__ __device__ constexpr explicit Lds(int Bx, int mode) {
     const int p = (Bx + 3) & ~3;
     bq = BP + 3 * p; bv = bq + 4 * p; bw = bv + 3 * p;
     rp = bw + 3 * p; rq = rp + 3 * p; rv = rq + 4 * p; rw = rv + 3 * p;
@@ -500,6 +500,28 @@ constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
     if (c.groups[g].num_runs < 0) return false;
   return true;
 }
+// LDS plan of one k_env_step workgroup (PBHC_EPB envs) for a config.  `use_runs`: the build writes the observation rows as unrolled
+// runs (the config-specialised kernel whose groups all have a run table) — such a build stages no compact maps, and it may keep the
+// HISTORY block out of the feature row: the old history then waits in the reference waves' registers and is staged, after bar2, over the
+// rigid-body arrays of the simulator state, which are dead by then (`hist_in_bodies`; needs the history to be the last block of the
+// feature index space, every row written by the reference waves, and a history no larger than those arrays / the registers).  That is
+// 5 KB of LDS per workgroup for the walk config: 29.6 KB instead of 39.5 — FIVE workgroups per CU instead of four.  The launch is bound by
+// what a CU holds in flight (an env's chain is ~11 us whatever the env count), so occupancy is throughput.
+struct StepLds { int stride, hist_in_bodies, map_words, bytes; };
+__host__ __device__ constexpr StepLds step_lds_plan(const PbhcEnvConfig& c, bool use_runs) {
+  const int Bx = c.skel.num_bodies_ext, p = (Bx + 3) & ~3;
+  const Lds lo(Bx, c.tracking_mode);
+  const int hoff = c.feat_off[PBHC_F_HISTORY];
+  bool all_b = true;
+  for (int g = 0; g < c.num_groups; ++g)
+    if (c.groups[g].role != 1) all_b = false;
+  const bool hb = use_runs && all_b && hoff + c.hist_dim == c.feat_dim && c.hist_dim <= 13 * p && c.hist_dim <= (384 / PBHC_G) * PBHC_G;
+  const int feat_words = hb ? hoff : c.feat_dim;
+  const int stride = lo.feat + ((feat_words + 3) & ~3);
+  const int mapw = use_runs ? 0 : c.map_lds_words;
+  const int words = PBHC_EPB * stride + ((Bx * (11 + PBHC_MAX_DEPTH) + 3) & ~3) + mapw;
+  return StepLds{stride, hb ? 1 : 0, mapw, words * 4};
+}
 // the uniform of element j of row `stream`: the first word of the env's Philox quad of this step (keyed by env / step only: every lane
 // computes the same one, so the value does not depend on WHICH lane writes element j), re-keyed by (row, j) and passed through a bijective
 // 32-bit finaliser — every writer of observation noise (list, per-element map, unrolled runs) uses this one function, so the generic and
@@ -531,9 +553,11 @@ __device__ __forceinline__ void obs_write_noisy(const uint32_t* mg, int k0, int 
 // is left per element is one LDS read at an immediate offset, the scale as a literal, the clip and one store — no list, no map word, no
 // segment table (the per-element paths above: ~25 instructions per element pair).  WHICH: 0 every run, 1 the runs that read no post-reset
 // feature, 2 the ones that do.  Same arithmetic per element as the map paths: (x + noise) * scale, clip.
+// `fhist`: where feature indices >= `hoff` (the HISTORY block) live, as a base for the same index (feat itself unless the block is staged
+// elsewhere: step_lds_plan); the table builder never lets a run straddle `hoff`
 template <int WHICH>
-__device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, float* __restrict__ outg, unsigned int ob,
-                                               float clipobs, float noise_cur, const uint32_t* pre) {
+__device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, const float* fhist, int hoff, float* __restrict__ outg,
+                                               unsigned int ob, float clipobs, float noise_cur, const uint32_t* pre) {
 #pragma unroll
   for (int r = 0; r < m.num_runs; ++r) {
     const PbhcObsRun& R = m.runs[r];
@@ -544,7 +568,7 @@ __device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t str
       // iteration, so the whole row is ONE basic block and the LDS reads of many iterations are in flight together (with a branch per
       // run tail every iteration waited out its own LDS round trip: ~100 cycles each)
       const int i = min(i0 + lane, R.len - 1);
-      float x = feat[R.src + i];
+      float x = (R.src >= hoff ? fhist : feat)[R.src + i];
       if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)(R.dst + i)) * 2.0f - 1.0f) * (R.noise * noise_cur);
       x = x * R.scale;
       if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
@@ -553,12 +577,24 @@ __device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t str
   }
 }
 
+#ifdef PBHC_STATIC_CFG
+constexpr int spec_min_waves() {
+  const int n = (160 * 1024) / step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).bytes;
+  return n < 1 ? 1 : (n > 5 ? 5 : n);
+}
+#endif
 // MODE 0: LeggedRobotMotionTracking (motion_tracking.py), MODE 1: LeggedRobotGeneralTracking (general_tracking.py)
 template <int MODE>
 // waves per SIMD the register allocation must allow: the v1 kernel's LDS footprint admits 4 workgroups = 16 waves per CU (<= 128 VGPRs);
 // general tracking holds twice the LDS per env (2 workgroups per CU)
 #ifndef PBHC_MIN_WAVES
+#ifdef PBHC_STATIC_CFG
+// a workgroup puts one wave on every SIMD: waves per SIMD = workgroups per CU = what the config's LDS plan admits (160 KB), at most 5 here —
+// 6 would leave 80 VGPRs
+#define PBHC_MIN_WAVES spec_min_waves()
+#else
 #define PBHC_MIN_WAVES (MODE ? 2 : 4)
+#endif
 #endif
 // (waves_per_eu pins the allocation target too: LDS admits no more than PBHC_MIN_WAVES waves per SIMD, so aiming at a higher occupancy
 // — the compiler stopped at 96 VGPRs and spilled — buys nothing)
@@ -624,18 +660,29 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
 #endif
   const int map_words = use_runs ? 0 : c.map_lds_words;
   const bool obs_by_role = use_runs || map_words > 0;
+  // where the HISTORY block of the feature index space lives (step_lds_plan): in the feature row, or — staged by the reference waves after
+  // bar2 — over the simulator body arrays
+#ifdef PBHC_STATIC_CFG
+  constexpr bool hist_b = step_lds_plan(kStaticCfg, use_runs).hist_in_bodies != 0;
+#else
+  const bool hist_b = false;
+#endif
+  float* const histl = hist_b ? bp : feat + hoff;
+  const float* const fhist = histl - hoff;
   const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
   STAMP(0);
 
   // ---------------- per-env scalars (tiny loads; each role loads what it uses, the reset path re-reads the clip meta) -----------------
-#define LOAD_CLIP_META()                                                                                               \
+#define LOAD_CLIP_ID()                                                                                                 \
   const int mid = (int)io.motion_ids[envc];                                                                            \
-  const f3 origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u)); \
+  const f3 origin = mk3(at(io.env_origins, (u32)envc * 3u), at(io.env_origins, (u32)envc * 3u + 1u), at(io.env_origins, (u32)envc * 3u + 2u));
+#define LOAD_CLIP_META_OF_ID()                                                                                         \
   float m_len = tbl.single_len, m_dt = tbl.single_dt;          /* this env's clip: length, frame time, frames, first table row */ \
   int m_nf = tbl.single_num_frames, m_row0 = 0;                                                                        \
   if (tbl.num_motions != 1) {                                  /* single clip: its meta travels in the kernel arguments */ \
     m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid]; \
   }
+#define LOAD_CLIP_META() LOAD_CLIP_ID() LOAD_CLIP_META_OF_ID()
   const long long ep1 = io.episode_length_buf[envc] + 1;
   const float start = io.motion_start_times[envc];
 
@@ -705,13 +752,49 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
     WAVE_LDS_FENCE();
     // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
+#ifndef PBHC_ABL_FK
     fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+#else       // (timing ablations, -DPBHC_ABL_*: what a phase costs is read off the launch time without it; results are meaningless)
+    if (valid && lane < Bx) { st3(bp + 3 * lane, ld3(root)); st4(bq + 4 * lane, ld4(root + 3)); st3(bv + 3 * lane, ld3(root + 7)); st3(bw + 3 * lane, ld3(root + 10)); }
+#endif
     STAMP(2);
   } else {
-    LOAD_CLIP_META();
-    // =============== role B, interval 0: every other load of the step, issued back to back (indices clamped, not predicated: one basic
-    // block), then _pre_physics_step (motion_tracking.py:749-768) and the torques from the pre-step state (legged_robot_base.py:795-838)
+    LOAD_CLIP_ID();
+    // =============== role B, interval 0: every other load of the step.  ORDER (loads return in issue order): (1) the env scalars the
+    // reference rows' addresses hang on — episode length, start time, clip id: issued above; (2) every load that depends on nothing but
+    // the env index, back to back (indices clamped, not predicated: one basic block); (3) — once (1) is back, with (2) still in flight — the
+    // two table rows.  Round 3 issued (2) BEHIND (3), i.e. after the first round trip had come back: two full trips to memory (6.5 k cycles
+    // to this role's first stamp) where one and an L2 hit do.  Then _pre_physics_step (motion_tracking.py:749-768) and the torques from the
+    // pre-step state (legged_robot_base.py:795-838).
+    const float frootB = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
     const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
+    float creg[128 / PBHC_G];
+    {
+      const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
+      const u32 cbase = (u32)envc * (u32)(B * 3);
+#pragma unroll
+      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
+    }
+    // operands of the pre-physics step / torques / joint-space sums: consumed after bar1
+#pragma unroll
+    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
+    a_in = at(io.actions_in, eDc + dc);
+    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);
+    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc);
+    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
+    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
+    adelayB = io.action_delay_idx[envc];
+    const float mlenB = io.motion_len[envc];
+    didx = c.randomize_ctrl_delay ? (int)adelayB : 0;
+    bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
+    {
+      const int nlm = max(c.dr_link_mass_dim, 1);
+      lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
+    }
+    combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
+    fric = io.dr_friction[envc];
+    __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks (2) below the wait for (1))
+    LOAD_CLIP_META_OF_ID();                                     // (a library: one more dependent trip, clip id -> clip meta, with (2) in flight)
     // reference rows: address from the env scalars, loads issued now, consumed in phase D
     float blend = 0.0f;
     const float* r0 = tbl.frames;
@@ -734,33 +817,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       rd0 = r0[dc]; rd1 = r1[dc]; rdv0 = r0[D + dc]; rdv1 = r1[D + dc];
       rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
-    float creg[128 / PBHC_G];
-    {
-      const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
-      const u32 cbase = (u32)envc * (u32)(B * 3);
-#pragma unroll
-      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
-    }
-    // operands of the pre-physics step / torques / joint-space sums: issued last, consumed after bar1
-#pragma unroll
-    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
-    a_in = at(io.actions_in, eDc + dc);
-    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);
-    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc);
-    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
-    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
-    adelayB = io.action_delay_idx[envc];
-    const float frootB = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
-    const float mlenB = io.motion_len[envc];
-    didx = c.randomize_ctrl_delay ? (int)adelayB : 0;
-    bmass = (MODE && io.dr_base_mass) ? io.dr_base_mass[envc] : 1.0f;
-    {
-      const int nlm = max(c.dr_link_mass_dim, 1);
-      lmreg = at(c.dr_link_mass_dim > 0 ? io.dr_link_mass : io.dr_base_com, (u32)envc * (u32)nlm + (u32)min(lane, nlm - 1));
-    }
-    combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
-    fric = io.dr_friction[envc];
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef PBHC_ABL_RNG
     if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? 0.5f : rng_uniform(rt.seed, env, step_ctr, 1, d);     // in-kernel draw: computed while the loads fly
+#endif
     if (valid) {
       // contact forces and the previous contacts
 #pragma unroll
@@ -787,7 +847,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
     STAMPB(1);
     // ---- phase D: reference frame: lerp / slerp of the two frame rows (MotionLibBase.get_motion_state motion_lib_base.py:123-259)
+#ifdef PBHC_ABL_PHASED
+    if (false) {
+#else
     if (valid) {
+#endif
       const float a = 1.0f - blend, bb = blend;
       if (lane < D) { rdof[lane] = a * rd0 + bb * rd1; rdofv[lane] = a * rdv0 + bb * rdv1; }
       if (lane < 2) {
@@ -822,7 +886,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const u32 hbase = (u32)envc * (u32)(io.hist_pitch ? io.hist_pitch : c.hist_dim);
       const int hlast = c.hist_dim - 1;
 #pragma unroll
+#ifndef PBHC_ABL_HIST
       for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+#else
+      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = 0.0f;
+#endif
     }
     // per-dof constants of the config: one batch of loads at the head of the interval
     k_tl = c.torque_limits[dc]; k_dp = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
@@ -875,7 +943,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // One lane per quantity and ONE code path per function: lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of
     // the pitch, lanes 4-6 the three base-frame rotations, lane 7 the reference time (lane 0 doing all of it in turn was ~450 instructions
     // of the chain; roll and pitch only exist where an observation reads them: general tracking).
+#ifdef PBHC_ABL_PHASEC
+    if (false) {
+#else
     if (valid) {
+#endif
       const f4 rq4 = ld4(root + 3);
       if (lane < 3) {
         float sinr, cosr, sinp, siny, cosy;
@@ -902,7 +974,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       }
     }
     WAVE_LDS_FENCE();
+#ifndef PBHC_ABL_RNG
     philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar1 next
+#else
+    nzb[0] = env ^ step_ctr; nzb[1] = nzb[2] = nzb[3] = 0;
+#endif
     STAMPB(3);
   }
   LDS_BARRIER();                                               // bar1: A's body state and B's reference frame / scalars are in LDS
@@ -928,7 +1004,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const int o_lbp = c.feat_off[PBHC_F_LOCAL_BODY_POS], o_lbr = c.feat_off[PBHC_F_LOCAL_BODY_ROT];
       const int o_dif = c.feat_off[PBHC_F_DIF_LOCAL_RIGID_BODY_POS], o_loc = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_POS];
       const int o_vr = c.feat_off[PBHC_F_VR_3POINT_POS], o_lv = c.feat_off[PBHC_F_LOCAL_REF_RIGID_BODY_VEL], o_gv = c.feat_off[PBHC_F_GLOBAL_REF_RIGID_BODY_VEL];
+#ifdef PBHC_ABL_EBODY
+      for (int b = lane; b < 0; b += PBHC_G) {
+#else
       for (int b = lane; b < Bx; b += PBHC_G) {
+#endif
         f3 rpos = ld3(rp + 3 * b);
         f3 dp = sub3(rpos, ld3(bp + 3 * b));
         float n2 = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
@@ -1042,14 +1122,25 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       misc[M_GRAV] = grav; misc[M_FAR] = far; misc[M_END] = tend; misc[M_TOUT_LEN] = tlen;
       misc[M_TIMEOUT] = tout;
       misc[M_RESET] = (grav != 0.0f || far != 0.0f || tout != 0.0f || refz != 0.0f || refori != 0.0f || bodyz != 0.0f || tcontact != 0.0f || tlowh != 0.0f) ? 1.0f : 0.0f;
+#ifdef PBHC_ABL_NORESET
+      misc[M_RESET] = 0.0f;
+#endif
     }
     WAVE_LDS_FENCE();
+#ifndef PBHC_ABL_RNG
     philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar2 next
+#else
+    nzb[0] = env ^ step_ctr; nzb[1] = nzb[2] = nzb[3] = 0;
+#endif
     STAMP(4);
   } else {
     // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the
     // post-reset features of a NON-terminated env (what phase H of role A computes after a reset), the observation maps -> LDS ========
-    if (valid) {                                                 // the history row -> feature row
+#ifdef PBHC_ABL_HIST
+    if (false) {
+#else
+    if (valid && !hist_b) {                                      // the history row -> feature row (hist_b: it stays in registers until bar2)
+#endif
 #pragma unroll
       for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) feat[hoff + i] = hreg[u]; }
       if (c.hist_dim > PBHC_HREG * PBHC_G)
@@ -1067,6 +1158,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     float s_maxjp = 0, s_jp2 = 0, s_jv2 = 0, s_tau2 = 0, s_ar = 0, s_qd2 = 0, s_qacc2 = 0, s_lpos = 0, s_lvel = 0, s_ltau = 0, s_coll = 0;
     float g_pos = 0.0f, g_vel = 0.0f, g_tau = 0.0f;
     if (valid) {
+      // the optional simulator-surface outputs (the rigid-body arrays are re-used after bar2: step_lds_plan)
+      if (io.rigid_body_state)
+        for (int b = lane; b < B; b += PBHC_G) {
+          float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
+          st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
+        }
+      if (io.contact_forces)
+        for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
       // outputs of the PRE-reset reference (a reset rewrites the root entries of rp / rq after bar2)
       if (io.ref_body_pos_extend)
         for (int i = lane; i < Bx * 3; i += PBHC_G) at(io.ref_body_pos_extend, (u32)env * (u32)(Bx * 3) + (u32)i) = rp[i];
@@ -1075,7 +1174,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const float soft_pos = (float)glob[PBHC_G_SOFT_POS_VAL], soft_vel = (float)glob[PBHC_G_SOFT_VEL_VAL], soft_tau = (float)glob[PBHC_G_SOFT_TAU_VAL];
       const float inv_dt = 1.0f / dt;
       const int o_dja = c.feat_off[PBHC_F_DIF_JOINT_ANGLES], o_djv = c.feat_off[PBHC_F_DIF_JOINT_VELOCITIES];
+#ifdef PBHC_ABL_JOINT
+      if (false) {
+#else
       if (d < D) {
+#endif
         const int dd = d;
         float dj = rdof[dd] - q[dd], djv = rdofv[dd] - qd[dd];
         feat[o_dja + dd] = dj; feat[o_djv + dd] = djv;
@@ -1181,8 +1284,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // a terminated env's history is zero in the observations of this very step (history_handler.py:33-38 via reset_envs_idx).  The copy of
   // the history row into the feature row is role B's, between bar1 and bar2; each role zeroes it for itself here, ahead of its own
   // observation passes (both store zeros: no order between the two is needed)
-  if (valid && (misc[M_RESET] != 0.0f || (roleB && gateB))) {
-    for (int i = lane; i < c.hist_dim; i += PBHC_G) feat[hoff + i] = 0.0f;
+  if (hist_b) {
+    // the old history leaves the reference waves' registers only now, over the simulator body arrays (nobody reads those after bar2);
+    // every row that holds history is written by these waves, so the hand-over is wave-local
+    if (roleB && valid) {
+      const bool z = misc[M_RESET] != 0.0f || gateB;
+#pragma unroll
+      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) histl[i] = z ? 0.0f : hreg[u]; }
+    }
+    WAVE_LDS_FENCE();
+  } else if (valid && (misc[M_RESET] != 0.0f || (roleB && gateB))) {
+    for (int i = lane; i < c.hist_dim; i += PBHC_G) histl[i] = 0.0f;
     WAVE_LDS_FENCE();
   }
 
@@ -1203,8 +1315,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
     float* __restrict__ const outg = io.obs[g];                                                                                     \
     const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
-    if (LATE_TOO) obs_write_runs<0>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                            \
-    else obs_write_runs<1>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                                     \
+    if (LATE_TOO) obs_write_runs<0>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);               \
+    else obs_write_runs<1>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);                        \
   }
 #define OBS_GROUPS_LATE_RUNS(ROLE)                                                                                                  \
   _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
@@ -1212,7 +1324,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
     float* __restrict__ const outg = io.obs[g];                                                                                     \
     const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
-    obs_write_runs<2>(c.groups[g], 16 + g, lane, feat, outg, ob, clipobs, noise_cur, nzb);                                          \
+    obs_write_runs<2>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);                             \
   }
 #endif
 #define OBS_GROUPS_MAP(ROLE, LATE_TOO)                                                                                              \
@@ -1243,8 +1355,29 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       obs_write_list_unaligned(mg, n_early, nlist, lane, PBHC_G, feat, outg, ob, c.groups[g].dim, c.groups[g].clip, clipobs);       \
     obs_write_noisy(mg, nn_early, nn, lane, PBHC_G, feat, outg, ob, c.groups[g].clip, clipobs, noise_cur, 16 + g, nzb); \
   }
+#ifdef PBHC_ABL_OBSX4
+// timing experiment: the same rows, the same bytes, stored 16 bytes per lane straight from the feature row (contents meaningless)
+#define OBS_GROUPS(ROLE, LATE_TOO) do {                                                                                             \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups || c.groups[g].role != (ROLE)) continue;                                                                  \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    _Pragma("unroll") for (int q0 = 0; q0 < (c.groups[g].dim + 3) / 4; q0 += PBHC_G) {                                             \
+      const int q = min(q0 + lane, (c.groups[g].dim + 3) / 4 - 1);                                                                  \
+      float4 v = *reinterpret_cast<const float4*>(feat + 4 * (q & 127));                                                            \
+      v.x *= clipobs;                                                                                                               \
+      *reinterpret_cast<float4*>(&at(outg, ob + (unsigned int)(4 * q))) = v;                                                        \
+    }                                                                                                                               \
+  } } while (0)
+#define OBS_GROUPS_LATE(ROLE) do { } while (0)
+#elif !defined(PBHC_ABL_OBS)
 #define OBS_GROUPS(ROLE, LATE_TOO) do { if (use_runs) { OBS_GROUPS_RUNS(ROLE, LATE_TOO) } else { OBS_GROUPS_MAP(ROLE, LATE_TOO) } } while (0)
 #define OBS_GROUPS_LATE(ROLE) do { if (use_runs) { OBS_GROUPS_LATE_RUNS(ROLE) } else { OBS_GROUPS_LATE_MAP(ROLE) } } while (0)
+#else
+#define OBS_GROUPS(ROLE, LATE_TOO) do { } while (0)
+#define OBS_GROUPS_LATE(ROLE) do { } while (0)
+#endif
   float rew_total = 0.0f, etr_val = 0.0f;
 
   if (!roleB) {
@@ -1252,7 +1385,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // (a) lane k < 10: e_k = exp(-err_k / sigma_k).  (b) lane i <-> term i: cheap selects.
     if (valid && lane < PBHC_NUM_SIGMA) {
       const float e = red[R_ERR0 + lane];
+#ifndef PBHC_ABL_F
       red[R_EXP0 + lane] = expf(-e / pf_sigma);
+#else
+      red[R_EXP0 + lane] = e * pf_sigma;
+#endif
     }
     WAVE_LDS_FENCE();
     STAMP(25);
@@ -1265,7 +1402,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         // reads (one round trip), every value computed by every lane, each lane keeping the one its term id names — instead of a switch per
         // lane, whose cases ran one after the other, each behind its own LDS reads (1.7 k cycles of the chain).  The specialised build drops
         // the terms its config does not have (TERM folds to a literal there).
-#ifdef PBHC_STATIC_CFG
+#ifdef PBHC_ABL_F
+#define TERM(name) false
+#elif defined(PBHC_STATIC_CFG)
 #define TERM(name) cfg_has_term(kStaticCfg, PBHC_R_##name)
 #else
 #define TERM(name) true
@@ -1535,15 +1674,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
   } else {
     // =============== role B, interval 2b: state outputs, future targets, the observation rows assigned to this role ================
-    if (valid) {
-      if (io.rigid_body_state)
-        for (int b = lane; b < B; b += PBHC_G) {
-          float* o = &at(io.rigid_body_state, ((u32)env * (u32)B + (u32)b) * 13u);
-          st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
-        }
-      if (io.contact_forces)
-        for (int i = lane; i < B * 3; i += PBHC_G) at(io.contact_forces, (u32)env * (u32)(B * 3) + (u32)i) = cf[i];
-    }
     // ---- general tracking: future reference targets (general_tracking.py:500-565) ----------------------------------------------
     // S lookups at motion_times + steps[s]*dt with motion_times = ep_len*dt + start (ep_len already incremented).
     // Pass 1, lane s <-> step s: frame pair, root-frame quantities, anchor pose -> features + per-step scratch.
@@ -1653,7 +1783,11 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         }
       }
     }
+#ifdef PBHC_ABL_WB
+    if (false) {
+#else
     if (roleB) {
+#endif
       // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405), by the reference waves: everything it
       // stores is final in LDS since bar3 (a reset's new state included), these waves have nothing else left, and the arrays are the ones
       // they loaded in their prologue — while the dynamics waves go straight on to the partial sums (1.3 k cycles off the chain)

@@ -32,6 +32,9 @@ int pbhc_spec_abi_version(void) { return PBHC_ABI_VERSION; }
 int pbhc_spec_mode(void) { return PBHC_SPEC_MODE; }
 const PbhcEnvConfig* pbhc_spec_config(void) { return &kStaticCfg; }
 const void* pbhc_spec_kernel(void) { return (const void*)k_env_step<PBHC_SPEC_MODE>; }
+// this build's LDS plan (step_lds_plan: no compact maps when the rows are unrolled runs, the history block out of the feature row)
+int pbhc_spec_lds_stride(void) { return step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).stride; }
+int pbhc_spec_lds_bytes(void) { return step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).bytes; }
 #ifdef PBHC_STAMPS          // diagnostic builds only (PBHC_SPEC_DEFINES=-DPBHC_STAMPS, tools/kernel_probe.py): this object's own stamp buffers
 int pbhc_spec_read_stamps(unsigned long long* out, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return PBHC_EHIP;

@@ -463,6 +463,8 @@ struct PbhcEnv {
   hipEvent_t ev0[PBHC_PROFILE_RING], ev1[PBHC_PROFILE_RING];
   const void* spec_fn;       // config-specialised k_env_step (pbhc_env_attach_specialised), or nullptr: the generic kernel
   void* spec_dl;
+  int spec_lds_stride;       // ... and its own LDS plan (step_lds_plan)
+  size_t spec_lds_bytes;
 };
 
 extern "C" {
@@ -653,6 +655,8 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->prof_count = 0;
   e->spec_fn = nullptr;
   e->spec_dl = nullptr;
+  e->spec_lds_stride = 0;
+  e->spec_lds_bytes = 0;
   if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_partials, (size_t)e->nblocks * 2 * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_skc, SKC_WORDS * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); (void)hipFree(e->d_partials); delete e; return PBHC_ENOMEM; }
@@ -695,7 +699,8 @@ int pbhc_env_attach_specialised(PbhcEnv* e, const char* so_path) {
   fn_i abi = (fn_i)dlsym(dl, "pbhc_spec_abi_version"), mode = (fn_i)dlsym(dl, "pbhc_spec_mode");
   fn_c cfgf = (fn_c)dlsym(dl, "pbhc_spec_config");
   fn_k kern = (fn_k)dlsym(dl, "pbhc_spec_kernel");
-  if (!abi || !mode || !cfgf || !kern || abi() != PBHC_ABI_VERSION) {
+  fn_i lds_stride = (fn_i)dlsym(dl, "pbhc_spec_lds_stride"), lds_bytes = (fn_i)dlsym(dl, "pbhc_spec_lds_bytes");
+  if (!abi || !mode || !cfgf || !kern || !lds_stride || !lds_bytes || abi() != PBHC_ABI_VERSION) {
     dlclose(dl);
     snprintf(g_err, sizeof(g_err), "pbhc_env_attach_specialised: %s is not a specialised step kernel of this ABI version", so_path);
     return PBHC_EINVAL;
@@ -714,7 +719,9 @@ int pbhc_env_attach_specialised(PbhcEnv* e, const char* so_path) {
     return PBHC_EINVAL;
   }
   const void* fn = kern();
-  if (e->lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+  e->spec_lds_stride = lds_stride();
+  e->spec_lds_bytes = (size_t)lds_bytes();
+  if (e->spec_lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->spec_lds_bytes));
   e->spec_fn = fn;
   e->spec_dl = dl;
   return PBHC_OK;
@@ -816,10 +823,12 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   const float* a_skc = e->d_skc;
   const uint32_t* a_map = e->cfg.map_image;
   PbhcStepIO a_io = *io;
-  void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&e->lds_stride, (void*)&a_skc, (void*)&a_map};
+  int a_stride = e->spec_fn ? e->spec_lds_stride : e->lds_stride;
+  const size_t a_lds = e->spec_fn ? e->spec_lds_bytes : e->lds_bytes;
+  void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map};
   const void* fn = e->spec_fn ? e->spec_fn : (e->cfg.tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>);
-  if (e->profile) HIP_CHECK(hipExtLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, e->lds_bytes, st, pe0, pe1, 0));
-  else HIP_CHECK(hipLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, e->lds_bytes, st));
+  if (e->profile) HIP_CHECK(hipExtLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st, pe0, pe1, 0));
+  else HIP_CHECK(hipLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st));
   if (e->profile) e->prof_count++;
   e->step_ctr++;
   HIP_CHECK(hipGetLastError());

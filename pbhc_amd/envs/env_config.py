@@ -415,7 +415,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     off = 0
     feat_off = {}
     for name, n in fdim.items():
-        if name in used:
+        if name in used and name != "HISTORY":
             feat_off[name] = off
             c.feat_off[K["PBHC_F_" + name]] = off
             off += n
@@ -424,6 +424,11 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         if name not in used:
             c.feat_off[K["PBHC_F_" + name]] = trash
             off = max(off, trash + n)
+    # HISTORY is the LAST block of the feature index space: a specialised kernel keeps it out of the LDS feature row (csrc/pbhc_env_step.h:
+    # step_lds_plan — the old history waits in registers and is staged over dead arrays once the termination flags are known)
+    feat_off["HISTORY"] = off
+    c.feat_off[K["PBHC_F_HISTORY"]] = off
+    off += fdim["HISTORY"]
     c.feat_dim = off
     # readiness class of every feature word (see the compact maps below): which phase of the step kernel produces it
     CLASS0 = {"HISTORY", "ZERO", "BASE_LIN_VEL", "BASE_ANG_VEL", "PROJECTED_GRAVITY", "REF_MOTION_PHASE", "RELYAW", "ROLL_PITCH", "DR_BASE_COM",
@@ -557,7 +562,7 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         for j in range(len(src)):
             late_j = int(feat_class[src[j]]) == 2
             if runs and runs[-1][0] + runs[-1][2] == dst[j] and runs[-1][1] + runs[-1][2] == src[j] and runs[-1][3] == late_j \
-                    and runs[-1][4] == sc[j] and runs[-1][5] == ns[j]:
+                    and runs[-1][4] == sc[j] and runs[-1][5] == ns[j] and src[j] != feat_off["HISTORY"]:        # (no run straddles the history block)
                 runs[-1][2] += 1
             else:
                 runs.append([dst[j], src[j], 1, late_j, sc[j], ns[j]])
@@ -605,7 +610,9 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
     # already writes — stays with role 1.
     fut_lo = min([feat_off[n_] for n_ in feat_off if n_.startswith("FUT_")] or [1 << 30])
     fut_hi = max([feat_off[n_] + fdim[n_] for n_ in feat_off if n_.startswith("FUT_")] or [-1])
-    load = [float(_os.environ.get("PBHC_ROLE0_HANDICAP", "0.1")) * sum(len(m[2]) for m in maps), 0.0]    # (env var: measurement aid)
+    # Round 4: v1 hands EVERY row to role 1 — with them the history block leaves the LDS feature row (step_lds_plan: a fifth workgroup per
+    # CU), and role 0, the chain that sets a workgroup's duration, ends with its reward / reset phases.
+    load = [float(_os.environ.get("PBHC_ROLE0_HANDICAP", "0.1" if mode == 1 else "1e9")) * sum(len(m[2]) for m in maps), 0.0]    # (env var: measurement aid)
     for i in sorted(range(len(maps)), key=lambda i_: -len(maps[i_][2])):
         reads_future = any(fut_lo <= s_ < fut_hi for s_ in maps[i][2])
         r_ = 1 if (reads_future or load[1] <= load[0]) else 0

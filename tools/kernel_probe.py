@@ -29,16 +29,17 @@ if env.is_specialised and "-DPBHC_STAMPS" in os.environ.get("PBHC_SPEC_DEFINES",
 if os.environ.get("PBHC_PROBE_EAGER_OUTPUTS", "0") == "1":
     env.set_eager_outputs(True)
 act = torch.zeros(N, env.num_dof, device="cuda:0")
+STEPS = int(os.environ.get("PBHC_PROBE_STEPS", "100"))
 for _ in range(20):
     env.step({"actions": act})
 env.set_profiling(True)
-for _ in range(100):
+for _ in range(STEPS):
     env.step({"actions": act})
 if os.environ.get("PBHC_PROBE_RESET_WG0", "0") == "1":       # the stamped workgroup's env 0 times out in the last launch: phase stamps of the reset path
     env.episode_length_buf[0] = 10 ** 6
     env.step({"actions": act})
 buf = (C.c_float * 512)(); cnt = C.c_int(0)
-_lib.check(lib.pbhc_env_profile_read(env._env, buf, 100, C.byref(cnt)))
+_lib.check(lib.pbhc_env_profile_read(env._env, buf, min(STEPS, 100), C.byref(cnt)))
 ov = C.c_float(0.0)
 if hasattr(lib, "pbhc_env_profile_overhead"):
     _lib.check(lib.pbhc_env_profile_overhead(env._env, _lib.current_stream(), C.byref(ov)))     # what the event pair reads beyond the kernel (20 us spin calibration)
