@@ -215,7 +215,11 @@ class PPO:
         hist = [(n, p) for n, p in named if not self._is_main(n)]
         self._n_main = sum(p.numel() for _, p in main)
         self._n_hist = sum(p.numel() for _, p in hist)
-        n = self._n_main + self._n_hist
+        # four spare floats between the two segments (in every flat buffer, so that one offset serves them all): slot `_n_main` of the
+        # GRADIENT buffer carries the minibatch KL mean through the data-parallel all-reduce of the main segment — one collective per
+        # optimiser step, every rank then takes the same learning-rate branch (as MHPPO does, mh_ppo.py: `_gflat[na + nc]`)
+        self._o_hist = self._n_main + 4
+        n = self._o_hist + self._n_hist
         self._pflat = torch.zeros(n, device=dev)
         self._gflat = torch.zeros(n, device=dev)
         self._mflat = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]     # per optimiser (the hist segment of [0] stays unused)
@@ -223,6 +227,8 @@ class PPO:
         self._slice_of = {}
         o = 0
         for nme, p in main + hist:
+            if hist and p is hist[0][1]:
+                o = self._o_hist
             k = p.numel()
             self._pflat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self._pflat[o:o + k].view_as(p)
@@ -258,7 +264,7 @@ class PPO:
         the declared stacks living in it that their next backward may store instead of accumulate"""
         from . import fused_mlp
 
-        (self._gflat[: self._n_main] if which == "main" else self._gflat[self._n_main:]).zero_()
+        (self._gflat[: self._n_main] if which == "main" else self._gflat[self._o_hist:]).zero_()
         for q in self._direct_stacks[which]:
             fused_mlp.grads_zeroed(q)
 
@@ -569,9 +575,14 @@ class PPO:
             std = alg.std.detach()
             self._gflat[so:so + sn] = self._g_sigma * ((std >= alg.min_sigma) & (std <= alg.max_sigma))
         if self._dp:
+            # ONE all-reduce per optimiser step: the main segment's gradients and, in the slot behind them, this rank's minibatch KL mean —
+            # averaged by the collective itself; the learning-rate rule (ppo_mimic.py:617-630) then runs on the all-rank KL as one launch
+            nb = self._n_main + adapt
             if adapt:
-                pdist.kl_lr_rule_(self._lr, self._loss_scalars[3], self.desired_kl)
-            pdist.allreduce_mean_(self._gflat[: self._n_main])
+                self._gflat[self._n_main:nb].copy_(self._loss_scalars[3:4])
+            pdist.allreduce_mean_(self._gflat[:nb])
+            if adapt:
+                _lib.check(lib.pbhc_kl_lr_rule(self._lr.data_ptr(), 2, self._gflat[self._n_main:].data_ptr(), float(self.desired_kl), st), "pbhc_kl_lr_rule")
         self._adam(0, 0, self._n_main, self._lr[0:1])
         if "_acc" in loss:
             pass                                           # (summed by the loss kernel's finishing block)
@@ -588,8 +599,8 @@ class PPO:
         self._zero_grads("hist")
         hist_loss.backward()
         if self._dp:
-            pdist.allreduce_mean_(self._gflat[self._n_main:])
-        self._adam(1, self._n_main, self._n_hist, self._lr_hist)
+            pdist.allreduce_mean_(self._gflat[self._o_hist:])
+        self._adam(1, self._o_hist, self._n_hist, self._lr_hist)
         loss["hist_latent_loss"] += hist_loss.detach()
         return loss
 

@@ -257,3 +257,109 @@ def test_equal_seeds_give_different_streams_but_equal_weights(tmp_path):
     assert not torch.allclose(a["actions"], b["actions"])                         # action noise (in-kernel Philox, sample seed)
     assert not torch.allclose(a["start"], b["start"])                             # start phases (reset_all: host generator; resets: env Philox)
     assert not torch.allclose(a["kp"], b["kp"])                                   # episodic domain randomisation
+
+
+# ---- ppo_mimic (general tracking, BASELINE configs[4]) under data parallelism ------------------------------------------------------
+def _v2_make_algo(g, N):
+    from tests.helpers import PPO_V2_NARROW
+    from tests.test_gpu_parity_v2 import _v2_algo
+
+    cfg, env, algo = _v2_algo(N, PPO_V2_NARROW)
+    algo.alg.load_state_dict({k[len("w0__"):]: v for k, v in g.items() if k.startswith("w0__")}, strict=True)
+    algo._train_mode()
+    algo.counter = int(g["counter0"])
+    return algo
+
+
+def _v2_load_storage(algo, g, sl):
+    for k in algo.storage.stored_keys:
+        if k in ("returns", "advantages"):
+            continue
+        getattr(algo.storage, k).copy_(g["st__" + k][:, sl].to(DEV))
+
+
+def _v2_state(algo):
+    sd = {"w." + k: v.detach().cpu().clone() for k, v in algo.alg.state_dict().items()}
+    sd["lr"] = algo._lr.cpu().clone()
+    return sd
+
+
+def _v2_run(algo, g, sl, perm_ppo, perm_dagger):
+    """returns -> one PPO `_training_step` (priv_reg coefficient from the golden's counter) -> one DAgger step; snapshots after each"""
+    last = {k[len("last__"):]: v[sl].to(DEV) for k, v in g.items() if k.startswith("last__")}
+    with torch.no_grad():
+        algo._compute_returns(last)
+    adv = algo.storage.advantages.cpu().clone()
+    loss1 = algo._training_step(indices=perm_ppo.to(DEV))
+    torch.cuda.synchronize()
+    s1 = _v2_state(algo)
+    _v2_load_storage(algo, g, sl)                                   # (the DAgger step reads observations only; the buffer was cleared, not erased)
+    loss2 = algo._training_step_dagger(indices=perm_dagger.to(DEV))
+    torch.cuda.synchronize()
+    s2 = _v2_state(algo)
+    return dict(adv=adv, s1=s1, s2=s2, priv_reg=float(loss1["priv_reg_loss"]), hist_loss=float(loss2["hist_latent_loss"]), counter=algo.counter)
+
+
+def _v2_rank_main(rank, world, port, perms, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from pbhc_amd import dist as pdist
+
+        g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_v2.npz")).items()}
+        n = g["st__actions"].shape[1] // world
+        algo = _v2_make_algo(g, n)
+        assert algo.world_size == world and algo._dp
+        sl = slice(rank * n, (rank + 1) * n)
+        _v2_load_storage(algo, g, sl)
+        pdist.reset_counters()
+        out = _v2_run(algo, g, sl, perms[0][rank], perms[1][rank])
+        out["all_reduces"] = int(pdist.COUNTERS["all_reduce"])
+        out["steps"] = algo.num_learning_epochs * algo.num_mini_batches
+        if rank == 0:
+            torch.save(out, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ppo_mimic_two_ranks_equal_one_big_batch(tmp_path):
+    """`ppo_mimic.PPO` sharded over 2 ranks (gloo, both on this GPU) against 1 process with all the envs, on the reference's rollout buffer
+    (tests/golden/ppo_v2.npz, `priv_reg` coefficient 0.05 at its counter): globally normalised advantages (ppo_mimic.py:489-491), the PPO step
+    (:596-691: rank-averaged gradients of the main segment, ONE learning-rate decision from the all-rank KL carried in the gradient bucket),
+    the DAgger regression of the history encoder (:693-709) — weights after each, learning rate, loss meters; and the collective count:
+    one all-reduce per optimiser step + the advantage moments."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "ppo_v2.npz")).items()}
+    T, N = g["st__actions"].shape[:2]
+    world, n = 2, N // 2
+    gen = torch.Generator().manual_seed(3)
+    perms = [[torch.randperm(T * n, generator=gen) for _ in range(world)] for _ in range(2)]          # [ppo | dagger][rank]
+    algo = _v2_make_algo(g, N)
+    nmb = algo.num_mini_batches
+    mbr = (T * n) // nmb
+    to_global = lambda r, p: (p // n) * N + r * n + (p % n)
+    big = [torch.cat([torch.cat([to_global(r, perms[j][r][i * mbr:(i + 1) * mbr]) for r in range(world)]) for i in range(nmb)]) for j in range(2)]
+    assert sorted(big[0].tolist()) == list(range(T * N))
+    # ---- 1 process x N envs
+    _v2_load_storage(algo, g, slice(0, N))
+    ref = _v2_run(algo, g, slice(0, N), big[0], big[1])
+    del algo
+    # ---- 2 processes x N/2 envs
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_v2_rank_main, args=(world, _free_port(), perms, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)
+    assert torch.allclose(got["adv"], ref["adv"][:, :n], atol=2e-5, rtol=1e-5)
+    assert got["counter"] == ref["counter"]
+    for stage in ("s1", "s2"):
+        assert torch.allclose(got[stage]["lr"], ref[stage]["lr"], rtol=1e-6), stage                    # same KL decisions on every step
+        for k, v in ref[stage].items():
+            if k == "lr":
+                continue
+            assert torch.allclose(got[stage][k], v, atol=2e-4, rtol=2e-4), (stage, k)                  # AdamW-amplified rounding (see test_ppo_mimic_update_matches_reference)
+            assert float((got[stage][k] - v).norm() / v.norm().clamp(min=1e-6)) < 2e-4, (stage, k)
+    # the history encoder does not move in the PPO step, everything else does not move in the DAgger step
+    hk = [k for k in ref["s1"] if "history_encoder" in k]
+    assert hk and all(torch.equal(got["s1"][k], g["w0__" + k[2:]]) for k in hk)
+    assert all(torch.equal(got["s2"][k], got["s1"][k]) for k in ref["s1"] if k != "lr" and "history_encoder" not in k)
+    assert abs(got["hist_loss"] - ref["hist_loss"]) < 2e-3 * max(1.0, abs(ref["hist_loss"]))            # (each rank meters its own shard)
+    # collectives: advantage moments (1) + one per PPO optimiser step + one per DAgger step
+    assert got["all_reduces"] == 1 + 2 * got["steps"], (got["all_reduces"], got["steps"])
