@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 8
+#define PBHC_ABI_VERSION 9
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -388,6 +388,10 @@ typedef struct PbhcStepIO {
    * env in this step, after its torques and before its observations — `_update_tasks_callback` with domain_rand.reinit_epis_rand > 0
    * (legged_robot_base.py:390-395 -> _episodic_domain_randomization(all env ids) :599-635).  Same draws as a reset's (Philox streams / ovr_*). */
   int32_t redraw_all;
+  /* written by pbhc_env_step_launch itself (callers leave it 0): 1 when every observation row may be stored 16 bytes per lane — obs[g]
+   * 16-byte aligned, its pitch a multiple of 4 floats and >= the row width rounded up to 4 (the env-owned and the rollout-buffer rows are:
+   * padded to 128-byte lines); the words between a row's width and that bound are then written (zeros). */
+  int32_t obs_wide;
 } PbhcStepIO;
 
 typedef struct PbhcEnv PbhcEnv;   /* opaque */

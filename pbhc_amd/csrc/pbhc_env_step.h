@@ -410,6 +410,32 @@ __device__ __forceinline__ void motion_lookup_meta(const PbhcMotionTable& tbl, i
 // which the observation write-out and the load phase were 45 %); split, the chain is ~40 % shorter and a SIMD holds 4 waves.
 // All LDS traffic of an env stays inside ITS two waves: within a wave the hardware executes DS instructions in order, so phases of
 // one role need no barrier at all; the five workgroup barriers below are the points where the roles exchange data.
+#define STATE_WRITEBACK()                                                                                                          \
+      for (int dd = lane; dd < D; dd += PBHC_G) {                                                                                                     \
+        at(io.actions, eD + dd) = act[dd];                                                                                                            \
+        at(io.last_actions, eD + dd) = act[dd];                                                                                                       \
+        at(io.actions_after_delay, eD + dd) = actd[dd];                                                                                               \
+        at(io.torques, eD + dd) = tau[dd];                                                                                                            \
+        at(io.dof_state, (eD + dd) * 2) = q[dd];                                                                                                      \
+        at(io.dof_state, (eD + dd) * 2 + 1) = qd[dd];                                                                                                 \
+        at(io.last_dof_pos, eD + dd) = q[dd];                                                                                                         \
+        at(io.last_dof_vel, eD + dd) = qd[dd];                                                                                                        \
+      }                                                                                                                                               \
+      if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];                                                                     \
+      if (lane < NF) {                                                                                                                                \
+        const u32 fo = (u32)env * (u32)NF + (u32)lane;                                                                                                \
+        at(io.feet_air_time, fo) = misc[M_FAT0 + lane];                                                                                               \
+        at(io.contacts, fo) = misc[M_CONTACT0 + lane];                                                                                                \
+        at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];                                                                                             \
+        at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];                                                                                           \
+        at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];                                                                                        \
+      }                                                                                                                                               \
+      if (lane == 0) {                                                                                                                                \
+        io.episode_length_buf[env] = (long long)misc[M_EPLEN];                                                                                        \
+        io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];                                                                                  \
+        io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;                                                                                            \
+        io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;                                                                                       \
+      }                                                                                                                                               
 extern __shared__ float smem[];
 
 #define PBHC_TPB (2 * PBHC_G * PBHC_EPB)                   // threads per workgroup of k_env_step: two roles x 32 lanes x 4 envs
@@ -507,7 +533,8 @@ constexpr bool obs_runs_complete(const PbhcEnvConfig& c) {
 // feature index space, every row written by the reference waves, and a history no larger than those arrays / the registers).  That is
 // 5 KB of LDS per workgroup for the walk config: 29.6 KB instead of 39.5 — FIVE workgroups per CU instead of four.  The launch is bound by
 // what a CU holds in flight (an env's chain is ~11 us whatever the env count), so occupancy is throughput.
-struct StepLds { int stride, hist_in_bodies, map_words, bytes; };
+#define PBHC_SEG 128                                      // floats of an observation row composed in LDS and stored 16 bytes per lane at a time
+struct StepLds { int stride, hist_in_bodies, map_words, bytes, stage; };
 __host__ __device__ constexpr StepLds step_lds_plan(const PbhcEnvConfig& c, bool use_runs) {
   const int Bx = c.skel.num_bodies_ext, p = (Bx + 3) & ~3;
   const Lds lo(Bx, c.tracking_mode);
@@ -515,12 +542,22 @@ __host__ __device__ constexpr StepLds step_lds_plan(const PbhcEnvConfig& c, bool
   bool all_b = true;
   for (int g = 0; g < c.num_groups; ++g)
     if (c.groups[g].role != 1) all_b = false;
+#ifdef PBHC_NO_HISTB          // (measurement aid: the round-3 LDS plan)
+  const bool hb = false;
+#else
   const bool hb = use_runs && all_b && hoff + c.hist_dim == c.feat_dim && c.hist_dim <= 13 * p && c.hist_dim <= (384 / PBHC_G) * PBHC_G;
+#endif
   const int feat_words = hb ? hoff : c.feat_dim;
-  const int stride = lo.feat + ((feat_words + 3) & ~3);
+  // (hist_in_bodies builds also compose their rows in a PBHC_SEG-float staging segment per env: obs_write_wide)
+  const int stage = lo.feat + ((feat_words + 3) & ~3);
+#ifdef PBHC_WIDE_ROWS
+  const int stride = stage + (hb ? PBHC_SEG : 0);
+#else
+  const int stride = stage;
+#endif
   const int mapw = use_runs ? 0 : c.map_lds_words;
   const int words = PBHC_EPB * stride + ((Bx * (11 + PBHC_MAX_DEPTH) + 3) & ~3) + mapw;
-  return StepLds{stride, hb ? 1 : 0, mapw, words * 4};
+  return StepLds{stride, hb ? 1 : 0, mapw, words * 4, stage};
 }
 // the uniform of element j of row `stream`: the first word of the env's Philox quad of this step (keyed by env / step only: every lane
 // computes the same one, so the value does not depend on WHICH lane writes element j), re-keyed by (row, j) and passed through a bijective
@@ -583,6 +620,78 @@ constexpr int spec_min_waves() {
   return n < 1 ? 1 : (n > 5 ? 5 : n);
 }
 #endif
+// The same rows 16 BYTES PER LANE (round 4).  At 32 768 envs the launch is bound by the vector-memory pipeline, not by bytes or arithmetic
+// (profiles/round4_k_env_step_memory_pipeline.txt: the address unit of a CU busy 65 % of the launch, 92 wave-instructions per wave of which
+// nearly all carried 4 bytes per lane), and a third of those instructions were the dword stores of these rows.  A row is composed PBHC_SEG
+// floats at a time in a staging segment of the env's LDS — every run piece that falls into the segment written by the lanes as above
+// (lane <-> element: consecutive LDS words), same arithmetic, same noise words — and leaves as ONE ds_read_b128 + global_store_dwordx4 per
+// segment: a quarter of the store instructions, whole 128-byte lines.  DS instructions of a wave execute in order, so one segment buffer
+// serves all segments of all rows.  PASS 0: every segment for an env that keeps its state, the segments without post-reset features for
+// a terminated one; PASS 1 (after bar3): the remaining segments of a terminated env.  Needs io.obs_wide (rows 16-byte aligned, padded).
+__device__ __forceinline__ void wide_compose(const PbhcOutMap& m, int s0, uint32_t stream, int lane, const float* feat, const float* fhist, int hoff, float* stg,
+                                             float clipobs, float noise_cur, const uint32_t* pre) {
+  const int s1 = min(s0 + PBHC_SEG, m.dim);
+#pragma unroll
+  for (int r = 0; r < m.num_runs; ++r) {
+    const PbhcObsRun& R = m.runs[r];
+    const int lo = max(R.dst, s0), hi = min(R.dst + R.len, s1);            // this run's piece of the segment, in row elements
+    if (lo >= hi) continue;
+#pragma unroll
+    for (int i0 = lo; i0 < hi; i0 += PBHC_G) {
+      const int j = min(i0 + lane, hi - 1);                                   // (lanes past the piece repeat its last element: one basic block)
+      float x = (R.src >= hoff ? fhist : feat)[R.src + (j - R.dst)];
+      if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)j) * 2.0f - 1.0f) * (R.noise * noise_cur);
+      x = x * R.scale;
+      if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
+      stg[j - s0] = x;
+    }
+  }
+  if (s1 == m.dim && (m.dim & 3) != 0 && lane < 4 - (m.dim & 3)) stg[m.dim - s0 + lane] = 0.0f;      // the row's padding up to a whole quad
+}
+__device__ __forceinline__ void wide_flush(const PbhcOutMap& m, int s0, int lane, const float* stg, float* __restrict__ outg, unsigned int ob) {
+  const int nq = (min(s0 + PBHC_SEG, m.dim) - s0 + 3) >> 2;
+  const int q = min(lane, nq - 1);
+  const float4 v = *reinterpret_cast<const float4*>(stg + 4 * q);
+  *reinterpret_cast<float4*>(&at(outg, ob + (unsigned int)(s0 + 4 * q))) = v;
+}
+constexpr bool seg_has_late(const PbhcOutMap& m, int s0) {
+  for (int r = 0; r < m.num_runs; ++r)
+    if (m.runs[r].late && m.runs[r].dst < s0 + PBHC_SEG && m.runs[r].dst + m.runs[r].len > s0) return true;
+  return false;
+}
+template <int PASS>
+__device__ __forceinline__ void obs_write_wide(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, const float* fhist, int hoff, float* stagel,
+                                               float* __restrict__ outg, unsigned int ob, float clipobs, float noise_cur, const uint32_t* pre, bool rs) {
+#pragma unroll
+  for (int s0 = 0; s0 < m.dim; s0 += PBHC_SEG) {
+    const bool has_late = seg_has_late(m, s0);
+    if (PASS == 1 && !has_late) continue;
+    const bool doit = PASS == 0 ? (!rs || !has_late) : rs;
+    if (doit) {
+      wide_compose(m, s0, stream, lane, feat, fhist, hoff, stagel, clipobs, noise_cur, pre);
+      WAVE_LDS_FENCE();
+      wide_flush(m, s0, lane, stagel, outg, ob);
+      WAVE_LDS_FENCE();
+    }
+  }
+}
+// The common case — neither env of the wave resets — as ONE basic block: every segment of the row, composed alternately in two staging
+// buffers, segment k leaving (ds_read_b128 + store) after segment k+1 has been composed: the flush's LDS round trip and the next
+// segment's feature reads are in flight together (with one buffer every segment waited out compose -> read-back -> store: ~300 cycles
+// each, 11 segments per env).  `stg2`: the second buffer (the skeleton image's LDS, dead since the FK).
+__device__ __forceinline__ void obs_write_wide_all(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, const float* fhist, int hoff, float* stg0, float* stg1,
+                                                   float* __restrict__ outg, unsigned int ob, float clipobs, float noise_cur, const uint32_t* pre, int* parity) {
+  int par = *parity;
+#pragma unroll
+  for (int s0 = 0; s0 < m.dim; s0 += PBHC_SEG) {
+    wide_compose(m, s0, stream, lane, feat, fhist, hoff, par ? stg1 : stg0, clipobs, noise_cur, pre);
+    WAVE_LDS_FENCE();
+    wide_flush(m, s0, lane, par ? stg1 : stg0, outg, ob);
+    par ^= 1;
+  }
+  *parity = par;
+}
+
 // MODE 0: LeggedRobotMotionTracking (motion_tracking.py), MODE 1: LeggedRobotGeneralTracking (general_tracking.py)
 template <int MODE>
 // waves per SIMD the register allocation must allow: the v1 kernel's LDS footprint admits 4 workgroups = 16 waves per CU (<= 128 VGPRs);
@@ -626,7 +735,19 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   const bool roleB = wave >= 2;                                            // wave-uniform (alternating the roles' waves between co-resident
                                                                            // workgroups, so that every SIMD holds two waves of each role, measured no change)
   const int le = ((wave & 1) << 1) | ((threadIdx.x >> 5) & 1);             // env slot of this half-wave in the workgroup
-  const int env = blockIdx.x * PBHC_EPB + le;
+  typedef unsigned int u32;
+  // Which 4 envs this workgroup steps.  The dispatcher deals workgroups to the 8 XCDs round-robin (workgroup b -> XCD b % 8), and every XCD
+  // has its own L2: with env block = b, the [N, 23]-float state arrays — 92-byte rows, 368 bytes per workgroup — put every 128-byte line
+  // that two neighbouring workgroups share into TWO L2s, each of which fetches it and writes its half back as a partial line.  XCD x
+  // takes a CONTIGUOUS range of env blocks instead (bijective for any block count), so neighbours meet in one L2: whole-line write-backs,
+  // one fetch per line.  (The partial-sum rows stay indexed by env block: k_env_finalize adds them up in the same order as ever.)
+#ifdef PBHC_NO_XCD_MAP
+  const u32 wgb = blockIdx.x;
+#else
+  const u32 nb_ = gridDim.x, xq_ = nb_ >> 3, xr_ = nb_ & 7u, xcd_ = blockIdx.x & 7u;
+  const u32 wgb = xcd_ * xq_ + min(xcd_, xr_) + (blockIdx.x >> 3);
+#endif
+  const int env = (int)wgb * PBHC_EPB + le;
   const bool valid = env < N;
   float* S = smem + (size_t)le * lds_stride;
   float *act = S + Lds::ACT, *actd = S + Lds::ACTD, *tau = S + Lds::TAU, *q = S + Lds::Q, *qd = S + Lds::QD;
@@ -639,7 +760,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   const size_t fk = (size_t)(io.frame_index >= 0 ? io.frame_index : io.frame_cursor[0] % io.num_frames) * (size_t)N;
   // Addressing: every per-env tensor is indexed as <uniform 64-bit base> + <32-bit unsigned lane offset> (`at`), which the compiler emits
   // as the SGPR-base form of global_load / global_store (pbhc_env_create / pbhc_env_step check that num_envs x row pitch < 2^30 elements).
-  typedef unsigned int u32;
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
   float* skc = smem + (size_t)PBHC_EPB * lds_stride;          // [SKC_WORDS] skeleton constants, shared by the workgroup
   uint32_t* mapl = (uint32_t*)(skc + ((Bx * SKC_W + 3) & ~3));    // [map_lds_words] compact observation maps, shared by the workgroup
@@ -669,6 +789,33 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
 #endif
   float* const histl = hist_b ? bp : feat + hoff;
   const float* const fhist = histl - hoff;
+#ifdef PBHC_STATIC_CFG
+  float* const stagel = S + step_lds_plan(kStaticCfg, use_runs).stage;       // (hist_b builds only)
+  float* const stage2 = skc + le * PBHC_SEG;                                  // second staging segment: the skeleton image, dead since the FK (bar1)
+  static_assert(!hist_b || PBHC_EPB * PBHC_SEG <= SKC_WORDS, "second staging buffer");
+#ifndef PBHC_WIDE_ROWS        // the 16-byte form is opt-in (-DPBHC_WIDE_ROWS): measured, not adopted — see obs_write_wide
+  const bool wide = false;
+#else
+  const bool wide = hist_b && io.obs_wide != 0;
+#endif
+#define OBS_GROUPS_WIDE_ALL()                                                                                                       \
+  { int par_ = 0;                                                                                                                   \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups) continue;                                                                                                \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    obs_write_wide_all(c.groups[g], 16 + g, lane, feat, fhist, hoff, stagel, stage2, io.obs[g], (u32)env * (u32)pitch_g, clipobs, noise_cur, nzb, &par_); \
+  } }
+#define OBS_GROUPS_WIDE(PASS, RS)                                                                                                   \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups) continue;                                                                                                \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    obs_write_wide<PASS>(c.groups[g], 16 + g, lane, feat, fhist, hoff, stagel, io.obs[g], (u32)env * (u32)pitch_g, clipobs, noise_cur, nzb, RS); \
+  }
+#else
+  const bool wide = false;
+#define OBS_GROUPS_WIDE(PASS, RS)
+#define OBS_GROUPS_WIDE_ALL()
+#endif
   const int o_pos = 2 * D + 2, o_rot = o_pos + 3 * Bx, o_vel = o_rot + 4 * Bx, o_ang = o_vel + 3 * Bx;     // columns of a packed motion-table row
   STAMP(0);
 
@@ -713,16 +860,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   float s_key = 0, s_keyn = 0, s_lkey = 0, s_lkeyn = 0, s_lkrot = 0, s_kvel = 0, s_kang = 0, s_lupn = 0, s_llon = 0, s_lvrn = 0, s_bodyz = 0;
 
   if (!roleB) {
-    // =============== role A, interval 0: the replay frame + the skeleton constants -> LDS (what the FK chain waits for), then the loads
-    // of its later phases.  Each role-A wave stages the WHOLE constant image for itself (identical words from both waves: benign), so the
-    // chain starts after one memory round trip and waits for nobody.
-#define SKC_REGSW ((SKC_WORDS + 63) / 64)
-    float skreg[SKC_REGSW];
-    {
-      const int n = Bx * SKC_W, wl = threadIdx.x & 63;
-#pragma unroll
-      for (int u = 0; u < SKC_REGSW; ++u) skreg[u] = skc_img[min(wl + u * 64, n - 1)];
-    }
+    // =============== role A, interval 0: the replay frame -> LDS (what the FK chain waits for), then the loads of its later phases.
+    // The skeleton constants are staged by the reference waves (bar0 below): round 3 had EACH dynamics wave load the whole 2.5 KB image
+    // for itself — 10 of its 25 load instructions and 9 % of the bytes a workgroup pulls through the CU's vector-memory pipeline, which
+    // is what bounds the launch at large env counts (profiles/round4_k_env_step_memory_pipeline.txt).
     const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
     const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
@@ -740,11 +881,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       psrc0 = pt.v[lane]; psrc1 = pt.v[lane + PBHC_G];
     }
 
-    {
-      const int n = Bx * SKC_W, wl = threadIdx.x & 63;
-#pragma unroll
-      for (int u = 0; u < SKC_REGSW; ++u) { const int i = wl + u * 64; if (i < n) skc[i] = skreg[u]; }
-    }
+    LDS_BARRIER();                                             // bar0: the skeleton image is in LDS (an L2 hit: long before this wave's frame is)
     STAMP(1);
     if (valid) {
       if (d < D) { q[d] = fq; qd[d] = fqd; }
@@ -759,6 +896,15 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
 #endif
     STAMP(2);
   } else {
+    // the skeleton constants for the dynamics waves' FK: ONE copy per workgroup, the first thing these two waves request (an L2 hit)
+#define SKC_REGSB ((SKC_WORDS + 2 * 64 - 1) / (2 * 64))
+    float skregB[SKC_REGSB];
+    {
+      const int n = Bx * SKC_W, wl = threadIdx.x & 127;
+#pragma unroll
+      for (int u = 0; u < SKC_REGSB; ++u) skregB[u] = skc_img[min(wl + u * 128, n - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     LOAD_CLIP_ID();
     // =============== role B, interval 0: every other load of the step.  ORDER (loads return in issue order): (1) the env scalars the
     // reference rows' addresses hang on — episode length, start time, clip id: issued above; (2) every load that depends on nothing but
@@ -794,6 +940,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
     fric = io.dr_friction[envc];
     __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks (2) below the wait for (1))
+    {
+      const int n = Bx * SKC_W, wl = threadIdx.x & 127;
+#pragma unroll
+      for (int u = 0; u < SKC_REGSB; ++u) { const int i = wl + u * 128; if (i < n) skc[i] = skregB[u]; }
+    }
+    LDS_BARRIER();                                              // bar0
     LOAD_CLIP_META_OF_ID();                                     // (a library: one more dependent trip, clip id -> clip meta, with (2) in flight)
     // reference rows: address from the env scalars, loads issued now, consumed in phase D
     float blend = 0.0f;
@@ -1667,6 +1819,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
     WAVE_LDS_FENCE();
     STAMP(8);
+#ifndef PBHC_ABL_WB
+    if (hist_b && valid) { STATE_WRITEBACK(); }                  // phase J on THIS role (see interval 3)
+#endif
     // ---------------- observation rows of the groups assigned to this role (helpers.py:128-152, legged_robot_base.py:787-793,326-331,
     // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)
     if (valid && obs_by_role) {
@@ -1736,7 +1891,15 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     if (valid && obs_by_role) {
       // a surviving env: every pair; a terminated env: all but the pairs that read post-reset features (after bar3)
-      if (misc[M_RESET] != 0.0f || gateB || io.redraw_all != 0) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
+      const bool rs = misc[M_RESET] != 0.0f || gateB || io.redraw_all != 0;
+      if (wide) {
+        // (a wave holds two envs: the one-block form when neither resets — wave-uniform, ~98 % of the waves)
+#ifdef PBHC_WIDE_ONEBUF       // (measurement aid)
+        { OBS_GROUPS_WIDE(0, rs) }
+#else
+        if (__builtin_amdgcn_ballot_w64(rs) == 0) { OBS_GROUPS_WIDE_ALL() } else { OBS_GROUPS_WIDE(0, rs) }
+#endif
+      } else if (rs) { OBS_GROUPS(1, false); } else { OBS_GROUPS(1, true); }
     }
     STAMPB(5);
   }
@@ -1745,7 +1908,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // a terminated env (~1 % of them): the pairs of role B's rows that read post-reset features, by role B itself — it is idle from here to bar4
   // while role A, the chain that sets the kernel's duration, writes the state back (round 2: role A wrote them before bar3, +2.8 k cycles on
   // exactly the workgroups that finish last)
-  if (roleB && valid && obs_by_role && (misc[M_RESET] != 0.0f || io.redraw_all != 0)) { OBS_GROUPS_LATE(1); }
+  if (roleB && valid && obs_by_role && (misc[M_RESET] != 0.0f || io.redraw_all != 0)) {
+    if (wide) { OBS_GROUPS_WIDE(1, true) } else { OBS_GROUPS_LATE(1); }
+  }
 
   // =============== interval 3: state write-back (role A) ================================================================================
   if (valid) {
@@ -1786,36 +1951,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
 #ifdef PBHC_ABL_WB
     if (false) {
 #else
-    if (roleB) {
+    if (roleB && !hist_b) {
 #endif
       // ---------------- phase J: state write-back (_post_compute_observations_callback :398-405), by the reference waves: everything it
       // stores is final in LDS since bar3 (a reset's new state included), these waves have nothing else left, and the arrays are the ones
-      // they loaded in their prologue — while the dynamics waves go straight on to the partial sums (1.3 k cycles off the chain)
-      for (int dd = lane; dd < D; dd += PBHC_G) {
-        at(io.actions, eD + dd) = act[dd];
-        at(io.last_actions, eD + dd) = act[dd];
-        at(io.actions_after_delay, eD + dd) = actd[dd];
-        at(io.torques, eD + dd) = tau[dd];
-        at(io.dof_state, (eD + dd) * 2) = q[dd];
-        at(io.dof_state, (eD + dd) * 2 + 1) = qd[dd];
-        at(io.last_dof_pos, eD + dd) = q[dd];
-        at(io.last_dof_vel, eD + dd) = qd[dd];
-      }
-      if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];
-      if (lane < NF) {
-        const u32 fo = (u32)env * (u32)NF + (u32)lane;
-        at(io.feet_air_time, fo) = misc[M_FAT0 + lane];
-        at(io.contacts, fo) = misc[M_CONTACT0 + lane];
-        at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];
-        at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];
-        at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];
-      }
-      if (lane == 0) {
-        io.episode_length_buf[env] = (long long)misc[M_EPLEN];
-        io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];
-        io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;
-        io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;
-      }
+      // they loaded in their prologue — while the dynamics waves go straight on to the partial sums (1.3 k cycles off the chain).
+      // (hist_b builds: the reference waves write every observation row and are the longer role after bar2 — there the dynamics waves
+      // do this right after their phase H, while they would otherwise wait at bar3.)
+      STATE_WRITEBACK();
     }
   }
 
@@ -1841,7 +1984,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     v0 += __shfl_xor(v0, PBHC_G, 2 * PBHC_G);                 // env 0 + env 1 of this wave
     v1 += __shfl_xor(v1, PBHC_G, 2 * PBHC_G);
     if ((threadIdx.x & PBHC_G) == 0) {
-      float* prow = partials + ((u32)blockIdx.x * 2u + (u32)wave) * (u32)PBHC_NP;
+      float* prow = partials + (wgb * 2u + (u32)wave) * (u32)PBHC_NP;
       prow[lane] = v0;
       prow[lane + PBHC_G] = v1;
     }

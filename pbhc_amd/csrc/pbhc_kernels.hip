@@ -823,6 +823,11 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   const float* a_skc = e->d_skc;
   const uint32_t* a_map = e->cfg.map_image;
   PbhcStepIO a_io = *io;
+  a_io.obs_wide = 1;
+  for (int g = 0; g < e->cfg.num_groups; ++g) {
+    const int pitch = io->obs_pitch[g] ? io->obs_pitch[g] : e->cfg.groups[g].pitch;
+    if (((uintptr_t)io->obs[g] & 15) != 0 || (pitch & 3) != 0 || pitch < ((e->cfg.groups[g].dim + 3) & ~3)) a_io.obs_wide = 0;
+  }
   int a_stride = e->spec_fn ? e->spec_lds_stride : e->lds_stride;
   const size_t a_lds = e->spec_fn ? e->spec_lds_bytes : e->lds_bytes;
   void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map};
