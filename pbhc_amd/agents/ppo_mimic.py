@@ -29,7 +29,7 @@ from .. import _lib
 from .. import dist as pdist
 from .agent_modules import Actor, ActorCritic
 from .mh_ppo import PhaseTimer, _load_checkpoint, _make_writer, policy_forward_graphs
-from .modules import RolloutStorage
+from .modules import BaseModule, RolloutStorage
 
 
 class _FlatAdamWView:
@@ -437,54 +437,99 @@ class PPO:
         return mu, value, latent
 
     def _rollout_step(self, obs_dict):
-        """ppo_mimic.py:371-438.  Per control step: encoders + actor + critic forward (GEMMs), ONE sample/log-prob/buffer-write kernel,
-        the fused env step writing the next observations into the next rollout slab, ONE bootstrap/done/episode-stat kernel."""
+        """ppo_mimic.py:371-438.  Per control step: encoders + actor + critic forward, ONE sample/log-prob/buffer-write kernel, the fused env
+        step writing the next observations into the next rollout slab, ONE bootstrap/done/episode-stat kernel.  Round 4, as MHPPO's rollout
+        (mh_ppo.py `_rollout_step`): the MLP stacks (actor, critic, privileged encoder) run as ONE launch each from packed weights — constant
+        over the rollout — and the T control steps are ONE captured hipGraph (fork / join edges instead of stream events; the steps read the
+        replay frame from the device-side cursor); the first rollout, and any rollout the env cannot promise to be free of host-side events
+        (`rollout_graph_safe`), runs the loop step by step with one captured forward per step."""
+        from . import fused_mlp
+        from .mh_ppo import MHPPO
+
         st, env, lib = self.storage, self.env, _lib.lib()
         T, N, A, R = self.num_steps_per_env, env.num_envs, self.num_act, self.num_rew_fn
         keys = list(self._obs_width.keys())
         K = _lib.K
         counter = env.globals[K["PBHC_G_STEP_COUNTER"]:].data_ptr()
-        stream = _lib.current_stream()
         with torch.inference_mode():
-            sigma = self.alg.sigma().contiguous()
+            sigma = self.__dict__.get("_sigma_buf")
+            if sigma is None:
+                sigma = self._sigma_buf = torch.empty(A, device=self.device)          # fixed address: the captured sampling kernel reads it
+            sigma.copy_(self.alg.sigma())
             for k in keys:
                 getattr(st, k)[0].copy_(obs_dict[k])
             mode = bool(self.hist_encoding)                    # the captured forward depends on the latent source
-            fwd = policy_forward_graphs(self, lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2], key=mode)
-            # the dependent chain of a control step is env step -> policy forward -> sampling -> env step; the env step's one-workgroup reduction
-            # and the bootstrap / episode-statistics kernel run next to the policy forward on a branch stream (joined before the sampling kernel,
-            # which reads the step counter the reduction advances)
-            split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
-            cur = torch.cuda.current_stream()
-            if split:
-                br = self.__dict__.setdefault("_branch_stream", None) or torch.cuda.Stream(device=self.device)
-                self._branch_stream = br
-                post_done = self.__dict__.setdefault("_post_done", torch.cuda.Event())
-                env.set_finalize_stream(br)
-            for t in range(T):
-                mu, value = fwd(t)
-                if split and t > 0:
-                    cur.wait_event(post_done)
-                    env.finalize_joined()
-                _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter,
-                                                  st.actions[t].data_ptr(), st.action_mean[t].data_ptr(), st.action_sigma[t].data_ptr(),
-                                                  st.actions_log_prob[t].data_ptr(), st.values[t].data_ptr(), stream), "pbhc_policy_sample")
-                env.set_obs_outputs({k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs)
-                nxt, rewards, dones, infos = env.step({"actions": st.actions[t]})
+            a = self.alg.actor
+            stacks = [m.module for m in (a.actor_module, self.alg.critic, a.priv_encoder) if m is not None and isinstance(m, BaseModule) and m._fused]
+            stacks = [q for q in stacks if os.environ.get("PBHC_STACK_NETS_V2", "1") != "0" and fused_mlp.pack_stack(q)]
+            try:
+                eager_fwd = lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2]
+                # the dependent chain of a control step is env step -> policy forward -> sampling -> env step; the env step's one-workgroup
+                # reduction and the bootstrap / episode-statistics kernel run next to the policy forward on a branch stream (joined before the
+                # sampling kernel, which reads the step counter the reduction advances)
+                split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
+                cur = torch.cuda.current_stream()
+                br = None
                 if split:
-                    with torch.cuda.stream(br):
-                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                         float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                         self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), br.cuda_stream), "pbhc_rollout_post")
-                        post_done.record(br)
-                else:
-                    _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), st.values[t].data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), N, R,
-                                                     float(self.gamma), st.rewards[t].data_ptr(), st.dones[t].data_ptr(), self.cur_reward_sum.data_ptr(),
-                                                     self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), stream), "pbhc_rollout_post")
-            if split:
-                cur.wait_stream(br)
-                env.set_finalize_stream(None)
+                    br = self.__dict__.get("_branch_stream") or torch.cuda.Stream(device=self.device)
+                    self._branch_stream = br
+                    env.set_finalize_stream(br)
+                post_done = [self.__dict__.setdefault("_post_done", torch.cuda.Event())]
+                sc = self.__dict__.get("_step_ptrs")
+                if sc is None or sc[0] is not st:
+                    P = lambda x: x.data_ptr()
+                    sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t]), P(st.values[t])),
+                                    post=(P(st.rewards[t]), P(st.dones[t])), values=P(st.values[t]), act={"actions": st.actions[t]},
+                                    obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)])
+                    self._step_ptrs = sc
+                steps = sc[1]
+                sum_p, len_p, stat_p, gamma = self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
+
+                def run_loop(cur, fwd_call):
+                    stream = cur.cuda_stream
+                    if split:
+                        br.wait_stream(cur)
+                    for t in range(T):
+                        sp = steps[t]
+                        mu, value = fwd_call(t)
+                        if split and t > 0:
+                            cur.wait_event(post_done[0])
+                            env.finalize_joined()
+                        _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter, *sp["sample"], stream),
+                                   "pbhc_policy_sample")
+                        env.set_obs_outputs(sp["obs_out"])
+                        nxt, rewards, dones, infos = env.step(sp["act"])
+                        ps = br.cuda_stream if split else stream
+                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R, gamma, *sp["post"],
+                                                         sum_p, len_p, stat_p, ps), "pbhc_rollout_post")
+                        if split:
+                            post_done[0].record(br)
+                    if split:
+                        cur.wait_stream(br)
+
+                graph_ok = (os.environ.get("PBHC_ROLLOUT_GRAPH", "1") != "0" and split and self.__dict__.get("_rollouts_done", 0) >= 1
+                            and not self.__dict__.get("_rollout_graph_failed", False) and hasattr(env, "rollout_graph_safe") and env.rollout_graph_safe(T))
+                ran = False
+                if graph_ok:
+                    env.simulator.use_device_cursor()
+                    key = (id(st), env._io_epoch, env.simulator.replay_version, bool(getattr(env, "is_specialised", False)), N, T, mode, bool(stacks))
+                    gc = self.__dict__.get("_rollout_graph")
+                    if gc is None or gc[0] != key:
+                        gc = MHPPO._capture_rollout(self, key, run_loop, eager_fwd, env, post_done, T)
+                    if gc is not None:
+                        gc[1].replay()
+                        env.after_graph_steps(T)
+                        ran = True
+                self._rollout_used_graph = ran
+                if not ran:
+                    run_loop(cur, policy_forward_graphs(self, eager_fwd, key=(mode, bool(stacks))))      # (one captured forward per step)
+                if split:
+                    env.set_finalize_stream(None)
+            finally:
+                for q in stacks:
+                    fused_mlp.release_stack(q)
             st.step = T
+            self._rollouts_done = self.__dict__.get("_rollouts_done", 0) + 1
             if self._dp and self._stat_mode == "rollout":
                 self.env.sync_globals()                # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()

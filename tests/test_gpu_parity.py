@@ -702,7 +702,12 @@ def _rollouts_with_split(split, agent="v1", batched=False, fused_sample=True, ro
         out["_used_graph_each"] = torch.tensor(used)
         if train_between:
             for k in ("_pflat", "_mflat", "_vflat", "_lr", "_adam_step", "_gflat"):
-                out[k] = getattr(algo, k).clone()
+                v = getattr(algo, k)
+                if isinstance(v, (list, tuple)):                   # (ppo_mimic: one moment buffer per optimiser)
+                    for i, vi in enumerate(v):
+                        out[f"{k}{i}"] = vi.clone()
+                else:
+                    out[k] = v.clone()
             out["cur_reward_sum"], out["cur_episode_length"] = algo.cur_reward_sum.clone(), algo.cur_episode_length.clone()
             out["_pflat_start"] = pflat_start
         out["_used_graph"] = torch.tensor([bool(getattr(algo, "_rollout_used_graph", False))])
@@ -732,28 +737,32 @@ def test_rollout_branch_stream_equals_one_stream(agent):
         assert torch.equal(a[k], b[k]), k
 
 
-def test_rollout_as_one_graph_equals_the_eager_loop():
-    """MHPPO's default rollout replays ONE hipGraph for the 24 control steps (policy stack + sampling, fused env step, its reduction, the
-    done / episode-statistics kernel; frame index from the device-side cursor): a schedule, not arithmetic — after five rollouts (eager,
-    capture + replay, three replays) every buffer, the env's globals / episode sums, the episode statistics, the step counter and the replay
-    cursor are bit-identical to the step-by-step loop."""
-    a = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=True, rollouts=5)
-    b = _rollouts_with_split(True, "v1", batched=True, fused_sample=True, rollout_graph=False, rollouts=5)
+@pytest.mark.parametrize("agent", ["v1", "v2"])
+def test_rollout_as_one_graph_equals_the_eager_loop(agent):
+    """The agents' default rollout replays ONE hipGraph for the control steps of a rollout (MHPPO: policy stack + sampling, fused env step,
+    its reduction, the done / episode-statistics kernel; ppo_mimic.PPO: encoders + packed actor / critic stacks, sampling, env step, reduction,
+    bootstrap kernel; frame index from the device-side cursor): a schedule, not arithmetic — after five rollouts (eager, capture + replay,
+    three replays) every buffer, the env's globals / episode sums, the episode statistics, the step counter and the replay cursor are
+    bit-identical to the step-by-step loop (mh_ppo.py:270-342, ppo_mimic.py:369-440)."""
+    v1 = agent == "v1"
+    a = _rollouts_with_split(True, agent, batched=v1, fused_sample=True, rollout_graph=True, rollouts=5)
+    b = _rollouts_with_split(True, agent, batched=v1, fused_sample=True, rollout_graph=False, rollouts=5)
     assert bool(a.pop("_used_graph")) and not bool(b.pop("_used_graph"))
     assert a.pop("_used_graph_each").tolist() == [False, True, True, True, True] and not b.pop("_used_graph_each").any()
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
 
-def test_graph_rollout_update_graph_replay_equals_the_eager_loop():
+@pytest.mark.parametrize("agent", ["v1", "v2"])
+def test_graph_rollout_update_graph_replay_equals_the_eager_loop(agent):
     """The path bench.py times and learn() runs (mh_ppo.py:222-247): rollout as ONE replayed hipGraph -> `_training_step` (20 optimiser steps:
     the flat weights the captured policy launch reads are rewritten in place, the policy stack is re-packed before the next replay, the Adam
     pass leaves the gradient buffer zeroed) -> replay of the SAME graph -> ...  Four iterations against the step-by-step loop with the same
     per-iteration permutation: every rollout-buffer key, the flat parameters, both Adam moments, the learning rates, the step counts, the
     env's globals / episode sums and the episode statistics are bit-identical."""
-    kw = dict(batched=True, fused_sample=True, rollouts=4, train_between=True)
-    a = _rollouts_with_split(True, "v1", rollout_graph=True, **kw)
-    b = _rollouts_with_split(True, "v1", rollout_graph=False, **kw)
+    kw = dict(batched=agent == "v1", fused_sample=True, rollouts=4, train_between=True)
+    a = _rollouts_with_split(True, agent, rollout_graph=True, **kw)
+    b = _rollouts_with_split(True, agent, rollout_graph=False, **kw)
     assert a.pop("_used_graph_each").tolist() == [False, True, True, True] and not b.pop("_used_graph_each").any()
     a.pop("_used_graph"); b.pop("_used_graph")
     assert not torch.equal(a["_pflat"], a["_pflat_start"])           # (the weights do move under the graph)

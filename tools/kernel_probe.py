@@ -11,7 +11,9 @@ from bench import build, make_replay_on_device
 from pbhc_amd import _lib
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg, env, _ = build(N, "cuda:0", 0)
+WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "v1_walk"          # kernel_probe.py N [workload [clips]]: bench.py's WORKLOADS
+CLIPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cfg, env, _ = build(N, "cuda:0", 0, workload=WORKLOAD, num_clips=CLIPS)
 env.reset_all()
 env.simulator.set_replay(*make_replay_on_device(env, 130, 1))
 lib = _lib.lib()

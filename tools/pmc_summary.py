@@ -45,12 +45,13 @@ def counter_values(d, name, kernel="k_env_step"):
 
 if __name__ == "__main__":
     fetch_dir, write_dir, out = sys.argv[1:4]
+    what = sys.argv[4] if len(sys.argv) > 4 else "tools/kernel_probe.py 4096 (v1 walk, 4096 envs)"
     fv, wv = counter_values(fetch_dir, "FETCH_SIZE"), counter_values(write_dir, "WRITE_SIZE")
     if not fv or not wv:
         raise SystemExit(f"no k_env_step rows found (FETCH {len(fv)}, WRITE {len(wv)})")
     rec = {"kernel": "k_env_step", "source_sha16": source_hash(), "sources": SOURCES, "launches": [len(fv), len(wv)],
            "FETCH_SIZE_KiB_median": statistics.median(fv), "WRITE_SIZE_KiB_median": statistics.median(wv),
-           "note": "rocprofv3 --pmc, separate passes, tools/kernel_probe.py 4096 (v1 walk, 4096 envs); on gfx950 FETCH_SIZE counts 64 B per 128-B request "
+           "note": "rocprofv3 --pmc, separate passes, " + what + "; on gfx950 FETCH_SIZE counts 64 B per 128-B request "
                    "(MI355X_MICROARCH.md, HBM): bytes read = 2 x FETCH_SIZE; both counters are in KiB"}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
