@@ -143,6 +143,11 @@ def finish_deferred():
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, seq, *params):
+        ctx.grad_cols = None
+        return _FusedMLP._fwd(ctx, x, seq)
+
+    @staticmethod
+    def _fwd(ctx, x, seq):
         lin = [m for m in seq if isinstance(m, nn.Linear)]
         act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
         saved_in, saved_act = [], []
@@ -198,6 +203,13 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        dx, flat = _FusedMLP._bwd(ctx, dout, ctx.needs_input_grad[0])
+        return (dx, None, *flat)
+
+    @staticmethod
+    def _bwd(ctx, dout, need_dx):
+        """-> (input gradient or None, [gw, gb] per layer in forward order).  `ctx.grad_cols = c0`: only the input columns [c0, in) carry a
+        gradient (_FusedMLPCat) — the first layer's input-gradient GEMM runs on that column slice of its weight alone."""
         lib, st = _lib.lib(), _lib.current_stream()
         lin = [m for m in ctx.seq if isinstance(m, nn.Linear)]
         L = ctx.n
@@ -278,8 +290,8 @@ class _FusedMLP(torch.autograd.Function):
                                                      scratch[offs[i - 1]:].data_ptr(), C.byref(nb), B, k, n, ctx.act, st), "pbhc_linear_dgrad_act")
                 d = dn
                 have_partials = True
-            elif i > 0 or ctx.needs_input_grad[0]:
-                d = d @ l.weight
+            elif i > 0 or need_dx:
+                d = d @ (l.weight if (i > 0 or ctx.grad_cols is None) else l.weight[:, ctx.grad_cols:])
         for part_w, out_w in deferred:                              # [P, n, k] partials -> the weight gradient: the same fixed-order column sum
             jobs.append((part_w.data_ptr(), out_w.data_ptr(), part_w.shape[0], out_w.numel()))
             keep += [part_w, out_w]
@@ -293,11 +305,28 @@ class _FusedMLP(torch.autograd.Function):
             ctx.live = None
             if len(seq._fused_live) == 0:
                 seq._fused_shared = False
-        dx = d if ctx.needs_input_grad[0] else None
+        dx = d if need_dx else None
         flat = []
         for gw, gbias in reversed(ret_w):
             flat += [gw, gbias]
-        return (dx, None, *flat)
+        return dx, flat
+
+
+class _FusedMLPCat(torch.autograd.Function):
+    """The same stack applied to cat([x_const, x_grad], -1) where only `x_grad` carries a gradient — ppo_mimic's actor / critic stacks read
+    [observations | encoder outputs] (ppo_mimic.py:596-630 via agent_modules.py:118-128): autograd's form computes the first layer's input
+    gradient for EVERY input column (24 576 x 512 x ~700: 0.14 ms per stack and optimiser step) and CatBackward then throws the observation
+    columns away.  Here the input-gradient GEMM runs on the weight's trailing columns alone and is returned for `x_grad` directly."""
+
+    @staticmethod
+    def forward(ctx, x_const, x_grad, seq, *params):
+        ctx.grad_cols = x_const.shape[-1]
+        return _FusedMLP._fwd(ctx, torch.cat([x_const, x_grad], dim=-1), seq)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, flat = _FusedMLP._bwd(ctx, dout, ctx.needs_input_grad[1])
+        return (None, dx, None, *flat)
 
 
 OUT_BWD = os.environ.get("PBHC_FUSED_OUT_BWD", "1") != "0"
@@ -398,3 +427,12 @@ def forward(seq, x):
         if isinstance(m, nn.Linear):
             params += [m.weight, m.bias]
     return _FusedMLP.apply(x, seq, *params)
+
+
+def forward_cat(seq, x_const, x_grad):
+    """seq(cat([x_const, x_grad], -1)) with the input gradient formed for `x_grad` only (see _FusedMLPCat)"""
+    params = []
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            params += [m.weight, m.bias]
+    return _FusedMLPCat.apply(x_const, x_grad, seq, *params)

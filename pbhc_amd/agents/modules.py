@@ -65,6 +65,17 @@ class BaseModule(nn.Module):
         return self.module(x)
 
 
+def apply_cat(mod, x_const, x_grad):
+    """`mod(cat([x_const, x_grad], -1))` for a BaseModule whose leading input columns `x_const` (observations) carry no gradient: on the
+    fused training path the first layer's input gradient is then formed for the `x_grad` columns only (fused_mlp._FusedMLPCat)"""
+    if (mod._fused and x_grad.is_cuda and x_grad.dim() == 2 and torch.is_grad_enabled() and not x_const.requires_grad
+            and (x_grad.requires_grad or mod.module[0].weight.requires_grad)):
+        from . import fused_mlp
+
+        return fused_mlp.forward_cat(mod.module, x_const, x_grad)
+    return mod(torch.cat([x_const, x_grad], dim=-1))
+
+
 class PPOActor(nn.Module):
     def __init__(self, obs_dim_dict, module_config_dict, num_actions, init_noise_std):
         super().__init__()

@@ -29,7 +29,7 @@ from .. import _lib
 from .. import dist as pdist
 from .agent_modules import Actor, ActorCritic
 from .mh_ppo import PhaseTimer, _load_checkpoint, _make_writer, policy_forward_graphs
-from .modules import BaseModule, RolloutStorage
+from .modules import BaseModule, RolloutStorage, apply_cat
 
 
 class _FlatAdamWView:
@@ -432,8 +432,9 @@ class PPO:
         a = self.alg.actor
         emb = a.motion_encoding(b["future_motion_targets"])
         latent = a.history_encoding(b["prop_history"]) if hist_encoding else a.priv_encoding(b["priv_obs"])
-        mu = a.actor_module(torch.cat([b["actor_obs"], emb, latent], dim=-1))
-        value = self.alg.critic(torch.cat([b["actor_obs"], b["priv_obs"], emb], dim=-1)) if want_value else None
+        # (the stacks read [observations | encoder outputs]: only the encoder columns carry a gradient — modules.apply_cat)
+        mu = apply_cat(a.actor_module, b["actor_obs"], torch.cat([emb, latent], dim=-1))
+        value = apply_cat(self.alg.critic, torch.cat([b["actor_obs"], b["priv_obs"]], dim=-1), emb) if want_value else None
         return mu, value, latent
 
     def _rollout_step(self, obs_dict):
