@@ -76,6 +76,31 @@ def slerp_jump_bound(q0, q1, base=5e-5):
     return torch.where(sh < 1.4e-3, base + jump, torch.full_like(jump, base)).float()
 
 
+def trace_slerp_bounds(oml, ep_before, start_before, ep_after, start_after, reset, dt, base):
+    """Per-element bounds for the two slerp-made quantities of a REFERENCE TRACE step (round 3 gave them a two-tier blanket: up to 2 % of the
+    elements 40x off), from the frame pair each env's lookup blended — recoverable from the trace's own state: the step looks the reference
+    up at (episode_length + 2) dt + start with the values BEFORE the step (motion_tracking.py:554,588), a reset at (0 + 1) dt + its new start
+    (motion_tracking.py:477-507).  -> (bodies [N, Bx, 1] for ref_body_rot_extend, root [N, 1] for the root rotation a reset wrote): `base`
+    outside the flip zone / scale conditioning of THAT pair (slerp_scale_bound), the pair's own bound inside."""
+    c = oml.cat["grs_t"]
+    z = torch.zeros_like(ep_before)
+    t1 = (ep_before + 2).float() * dt + start_before
+    f0, f1, _ = oml.calc_frame_blend(t1, oml.motion_len[z], oml.num_frames[z], oml.motion_dt[z])
+    bodies = base + slerp_scale_bound(c[f0], c[f1])                             # [N, Bx, 1]
+    t2 = (ep_after * 0 + 1).float() * dt + start_after
+    g0, g1, _ = oml.calc_frame_blend(t2, oml.motion_len[z], oml.num_frames[z], oml.motion_dt[z])
+    root = torch.where(reset.bool()[:, None], base + slerp_scale_bound(c[g0][:, 0], c[g1][:, 0]), torch.full((len(z), 1), base))
+    return bodies, root
+
+
+def _probe(line):
+    """PBHC_TOLERANCE_PROBE=<file>: append one line per bounded quantity (profiles/round4_tolerance_probe.txt is a copy of one run)"""
+    path = os.environ.get("PBHC_TOLERANCE_PROBE")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+
+
 def close(a, b, tol, what, rtol=None, hard=None, frac=0.0, tol_override=None):
     tol = tol if tol_override is None else tol_override
     a = torch.as_tensor(a).detach().float().cpu()
@@ -92,6 +117,9 @@ def close(a, b, tol, what, rtol=None, hard=None, frac=0.0, tol_override=None):
         assert float(err.max()) <= hard, (what, "hard bound", float(err.max()))
         assert float(bad.float().mean()) <= frac, (what, float(err.max()), float(bad.float().mean()))
         return
+    if torch.is_tensor(tol) and os.environ.get("PBHC_TOLERANCE_PROBE"):
+        _probe(f"{what}: worst residual / bound {float((err / lim.clamp(min=1e-12)).max()):.3f}, max residual {float(err.max()):.2e}, elements above 3e-5 "
+               f"{int((err > 3e-5 + 3e-5 * b.abs()).sum())} of {err.numel()}, loosest bound {float(tol.max()):.2e}")
     assert not bool(bad.any()), (what, float(err.max()), int(bad.sum()), bad.nonzero()[:5].tolist())
 
 
@@ -258,6 +286,9 @@ def test_env_step_matches_reference_trace(tag, cfgname, overrides=None):
     tg = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     env.simulator.set_replay(tg(g["replay_root"]), tg(g["replay_dof_pos"]), tg(g["replay_dof_vel"]), tg(g["replay_contact"]))
     K = __import__("pbhc_amd._lib", fromlist=["K"]).K
+    from oracle.motion_lib import MotionLib as OML                 # (the frame pairs the trace's lookups blended: for the per-element slerp bounds)
+
+    oml = OML(skel_from_golden(), [clip_from_env_golden(g)])
     for k in range(T):
         st = lambda name, dt=torch.float32: tg(g["step__state__" + name][k]).to(dt)
         env.set_injected_draws(u_rfi=tg(g["step__u_rfi"][k]), start_time=st("motion_start_times"), kp=st("kp_scale"), kd=st("kd_scale"),
@@ -267,8 +298,12 @@ def test_env_step_matches_reference_trace(tag, cfgname, overrides=None):
         w = f"{tag} step {k}: "
         assert torch.equal(reset.cpu(), torch.from_numpy(g["step__reset_buf_out"][k])), w + "reset_buf"
         assert torch.equal(extras["time_outs"].cpu(), torch.from_numpy(g["step__time_outs"][k])), w + "time_outs"
+        # the two slerp-made quantities: bounded per element by the frame pair THIS env blended (trace_slerp_bounds), 2e-5 / 3e-5 elsewhere
+        gs = lambda name, j: torch.from_numpy(g["state0__" + name] if j < 0 else g["step__state__" + name][j])
+        rot_tol, root_tol = trace_slerp_bounds(oml, gs("episode_length_buf", k - 1), gs("motion_start_times", k - 1), gs("episode_length_buf", k),
+                                               gs("motion_start_times", k), torch.from_numpy(g["step__reset_buf_out"][k]), float(env.dt), 2e-5)
         close(extras["ref_body_pos_extend"], g["step__ref_body_pos_extend"][k], 2e-5, w + "ref_body_pos_extend")
-        close(extras["ref_body_rot_extend"], g["step__ref_body_rot_extend"][k], 2e-5, w + "ref_body_rot_extend", **SLERP)
+        close(extras["ref_body_rot_extend"], g["step__ref_body_rot_extend"][k], rot_tol.expand(-1, -1, 4), w + "ref_body_rot_extend", rtol=2e-5)
         close(env.simulator._rigid_body_pos, g["step__x___rigid_body_pos_extend"][k][:, :env.num_bodies], 2e-5, w + "body pos")
         close(rew, g["step__rew_buf"][k], 3e-5, w + "rew_buf", rtol=1e-4)
         for ok in ["actor_obs", "critic_obs"]:
@@ -277,7 +312,9 @@ def test_env_step_matches_reference_trace(tag, cfgname, overrides=None):
                      "contacts_filt", "last_dof_vel", "motion_start_times"]:
             close(getattr(env, name), g["step__state__" + name][k], 3e-5, w + "state " + name)
         close(env.simulator.dof_pos, g["step__state__dof_pos"][k], 3e-5, w + "dof_pos")
-        close(env.simulator.robot_root_states[:, :10], g["step__state__root_states"][k][:, :10], 3e-5, w + "root_states", **SLERP)
+        rs_tol = torch.full((N, 10), 3e-5)
+        rs_tol[:, 3:7] = (root_tol + 1e-5).expand(-1, 4)                          # (a surviving env's root state is the replay frame itself)
+        close(env.simulator.robot_root_states[:, :10], g["step__state__root_states"][k][:, :10], rs_tol, w + "root_states", rtol=3e-5)
         # a reset writes the looked-up root angular velocity of the reference motion: bounded by ITS conditioning (angvel_tol), everything else 3e-5
         ref_w = torch.from_numpy(g["step__state__root_states"][k][:, 10:])
         close(env.simulator.robot_root_states[:, 10:], ref_w, angvel_tol(ref_w, float(env._motion_lib._motion_dt[0]), k=32.0, base=3e-5), w + "root ang vel", rtol=3e-5)

@@ -28,12 +28,12 @@ def test_generic_kernel_replays_the_reference_traces(monkeypatch, tag, cfgname):
     test_env_step_matches_reference_trace(tag, cfgname)
 
 
-@pytest.mark.parametrize("tag,cfgname", V2_CASES)
-def test_generic_kernel_replays_the_general_tracking_traces(monkeypatch, tag, cfgname):
+@pytest.mark.parametrize("tag,cfgname,robot", V2_CASES)
+def test_generic_kernel_replays_the_general_tracking_traces(monkeypatch, tag, cfgname, robot):
     monkeypatch.setenv("PBHC_SPECIALISE", "off")
     from tests.test_gpu_parity_v2 import test_general_tracking_step_matches_reference_trace
 
-    test_general_tracking_step_matches_reference_trace(tag, cfgname)
+    test_general_tracking_step_matches_reference_trace(tag, cfgname, robot)
 
 
 @pytest.mark.parametrize("cfgname,general,N", [("v1_g1_23dof_walk.yaml", False, 1024), ("v2_g1_29dof_teacher.yaml", True, 256)])
