@@ -85,7 +85,9 @@ def sim_fk(skel, root_state, dof_pos, dof_vel):
     local_q = R.wxyz_to_xyzw(torch.as_tensor(skel["local_rot_wxyz"]).float())
     N = root_state.shape[0]
     pos = [root_state[:, 0:3]]
-    rot = [root_state[:, 3:7]]
+    # the chain hangs on the UNIT root rotation (a replay frame's quaternion can be off unit length by the reference slerp's scale error; the
+    # kernels do the same: csrc/pbhc_env_step.h fk_walk); the root body itself keeps the frame's quaternion (restored below)
+    rot = [R.normalize(root_state[:, 3:7])]
     vel = [root_state[:, 7:10]]
     ang = [root_state[:, 10:13]]
     for i in range(1, B):
@@ -98,4 +100,5 @@ def sim_fk(skel, root_state, dof_pos, dof_vel):
         w_i = ang[p] + R.quat_rotate(q_i, axis[i - 1].expand(N, 3)) * dof_vel[:, i - 1 : i]
         v_i = vel[p] + torch.cross(ang[p], p_i - pos[p], dim=-1)
         pos.append(p_i); rot.append(q_i); vel.append(v_i); ang.append(w_i)
+    rot[0] = root_state[:, 3:7]
     return torch.stack(pos, 1), torch.stack(rot, 1), torch.stack(vel, 1), torch.stack(ang, 1)

@@ -303,6 +303,11 @@ class MHPPO:
         """zero the flat gradient buffer and tell the declared stacks (their next backward may store instead of accumulate)"""
         from . import fused_mlp
 
+        # INVARIANT behind the shortcut: between the Adam pass of one optimiser step (pbhc_adam_clip2(zero_grad=1) leaves the buffer zeroed)
+        # and this call nothing runs a backward through a module whose .grad views the flat buffer.  _update_ppo is the only writer on the
+        # training path; load() and the eager update clear the flag; PBHC_CHECK_GRAD_CLEAN=1 verifies it (one reduction + a sync per step).
+        if getattr(self, "_gflat_clean", False) and os.environ.get("PBHC_CHECK_GRAD_CLEAN", "0") == "1":
+            assert float(self._gflat[: self._n_actor + self._n_critic].abs().sum()) == 0.0, "a gradient was written outside _update_ppo"
         if not getattr(self, "_gflat_clean", False):      # (clean: the last Adam pass left it zeroed and nothing has written it since)
             self._gflat.zero_()
         self._gflat_clean = False
@@ -353,6 +358,7 @@ class MHPPO:
         if ckpt_path is None:
             return None
         d = _load_checkpoint(ckpt_path, self.device)
+        self._gflat_clean = False            # (whatever touched the gradients meanwhile: the next update zeroes the flat buffer itself)
         self.actor.load_state_dict(d["actor_model_state_dict"])
         self.critic.load_state_dict(d["critic_model_state_dict"])
         if self.load_optimizer:

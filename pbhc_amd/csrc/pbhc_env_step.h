@@ -92,9 +92,10 @@ enum {
   M_TCONTACT, M_TLOWH,                                          // termination causes: contact on a terminating body, low base height
   M_TPOSLIM, M_TVELLIM, M_TTAULIM, M_TGATE,                     // ... close to a joint position / velocity / torque limit (role B), any of them
   M_ORIGIN0, M_ORIGIN1, M_ORIGIN2, M_CLIP_LEN, M_CLIP_DT, M_CLIP_NF, M_CLIP_ROW0,     // env origin + clip meta (role B's prologue loads) for role A's reset path
-  M_PJOINT, M_PEPLEN, M_PETR, M_PETRSQ, M_PREW, M_ZERO                                // partial-sum columns that are computed values; a zero for the unused ones
+  M_PJOINT, M_PEPLEN, M_PETR, M_PETRSQ, M_PREW, M_ZERO,                               // partial-sum columns that are computed values; a zero for the unused ones
+  M_NZB                                                                               // the observation-noise base word of this env and step (dynamics -> reference waves)
 };
-static_assert(M_ZERO < 56, "MISC region");
+static_assert(M_NZB < 56, "MISC region");
 
 // Where column k of an env's partial-sum row comes from: a slot of the env's reduction row (RED) or of its scalar block (MISC).  Lane k of
 // the dynamics wave copies it at the end of the step (one lane writing the ~35 columns in turn was 1.8 k cycles of every workgroup's tail).
@@ -254,7 +255,10 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
       const float* kb = skc + b * SKC_W;
       const int n = __float_as_int(kb[10]);
       f3 p = ld3(root), v = ld3(root + 7), w = ld3(root + 10);
-      f4 r = ld4(root + 3);
+      // the chain starts from the UNIT root rotation (a replay frame's quaternion may be off unit length by the reference slerp's scale
+      // error, up to 4e-4: a rotation is a rotation); the root body itself keeps the frame's quaternion as it is
+      const f4 rraw = ld4(root + 3);
+      f4 r = quat_unit_fast(rraw);
       for (int i = 0; i < n; ++i) {
         const int a = __float_as_int(kb[11 + i]);
         const float* ka = skc + a * SKC_W;
@@ -273,6 +277,7 @@ __device__ __forceinline__ void fk_walk(const float* skc, int B, int Bx, int lan
         r = quat_mul(r, eq);
         p = pe;
       }
+      if (b == 0) r = rraw;
       st3(bp + 3 * b, p); st4(bq + 4 * b, r); st3(bv + 3 * b, v); st3(bw + 3 * b, w);
     }
   LDS_BARRIER();
@@ -304,7 +309,8 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
       const float* kb = skc + b * SKC_W;
       const int n = __float_as_int(kb[10]);
       f3 p = ld3(root), v = ld3(root + 7), w = ld3(root + 10);
-      f4 r = ld4(root + 3);
+      const f4 rraw = ld4(root + 3);
+      f4 r = quat_unit_fast(rraw);                                 // (unit root rotation for the chain: see fk_walk)
       // The walk is a chain of dependent levels, each needing the joint's constants (an index read, then reads addressed by it): software
       // pipelined by hand — the index two levels ahead and the constants one level ahead are requested before this level's arithmetic, so
       // both LDS round trips run under ~500 cycles of VALU work instead of in front of it.  Reads past the chain's end repeat the last joint.
@@ -336,6 +342,7 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
         r = quat_mul(r, eq);
         p = pe;
       }
+      if (b == 0) r = rraw;
       P[it] = p; V[it] = v; W[it] = w; R[it] = r;
     }
   }
@@ -348,6 +355,133 @@ __device__ __forceinline__ void fk_walk_wave(const float* skc, int B, int Bx, in
   }
   STAMP(22);
 }
+
+// ---- the same rigid-body state by POINTER JUMPING (round 4; config-specialised builds of robots with <= 32 bodies incl. extended).
+// The walk above is the longest dependent stretch of the step: every lane composes its body's whole root -> body chain, depth-of-the-deepest-
+// body levels of ~130 instructions each (7 for the 23-DoF G1: ~5.5 k cycles of a 21 k-cycle workgroup).  Rigid transforms with twists
+// compose associatively, so the chain is evaluated as a prefix product instead: lane b starts with the segment parent(b) -> b
+//     R = q_local (x) q_joint(q),  p = offset,  w = R(q_local) axis * q-dot,  v = 0          (pose / twist of b relative to, and in the frame of, its parent;
+//                                                                                           body 0: the root state relative to the world)
+// and in round r = 0, 1, 2, ... replaces it by  S(anc) o S(b)  where anc is b's ancestor 2^r levels up, whose segment — fetched from ITS
+// lane's registers with ds_bpermute_b32 (the LDS crossbar, no LDS memory, no barrier) — reaches 2^r levels further:
+//     R = R1 R2,  p = p1 + R1 p2,  w = w1 + R1 w2,  v = v1 + w1 x (R1 p2) + R1 v2 .
+// After ceil(log2(depth + 1)) rounds (3 for the 23-DoF G1, 4 for 29 DoF) every segment starts at the world: 3 x ~100 instructions instead of
+// 7 x ~130, same arithmetic as the walk up to the association order (the stand-alone FK kernel keeps the walk: the two agree to 2e-6,
+// tests/test_gpu_parity.py: lazy vs stored rigid-body state).  Extended bodies take their parent's finished state afterwards, with the
+// reference's own formula (see fk_walk).  The per-body constants come from a 20-float row of `skj` per lane, straight into registers:
+// no skeleton image in LDS, no bar0.
+//   skj row b: [off.xyz, anc1 | q_local.xyzw | axis.xyz, anc2 | u.xyz (= R(q_local) axis), anc4 | anc8, ext_parent (-1: a real body), -, -]
+#define SKJ_W 20
+__host__ __device__ inline float skj_word(const PbhcSkeleton& sk, int i) {
+  const int b = i / SKJ_W, w = i - b * SKJ_W;
+  const bool ext = b >= sk.num_bodies;
+  auto anc = [&](int dist) -> int {                            // ancestor `dist` levels up, -1 if b is less than `dist` below the root (or extended)
+    if (ext || sk.depth[b] < dist) return -1;
+    int a = b;
+    for (int k = 0; k < dist; ++k) a = sk.parent[a];
+    return a;
+  };
+  auto asf = [](int v) { float f; memcpy(&f, &v, sizeof(f)); return f; };
+  float ax[3] = {0.0f, 0.0f, 0.0f};
+  if (b >= 1 && !ext) {
+    const float* a = sk.dof_axis[b - 1];
+    const float nrm = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-9f);
+    for (int k = 0; k < 3; ++k) ax[k] = a[k] / nrm;
+  }
+  const float* lw = sk.local_rot_wxyz[b];
+  const float qx = lw[1], qy = lw[2], qz = lw[3], qw = lw[0];
+  if (w < 3) return sk.offset[b][w];
+  if (w == 3) return asf(anc(1));
+  if (w < 8) return w == 4 ? qx : w == 5 ? qy : w == 6 ? qz : qw;
+  if (w < 11) return ax[w - 8];
+  if (w == 11) return asf(anc(2));
+  if (w < 15) {                                                 // u = R(q_local) axis (double precision on the host)
+    const double x = qx, y = qy, z = qz, ww = qw, vx = ax[0], vy = ax[1], vz = ax[2];
+    const double tx = 2.0 * (y * vz - z * vy), ty = 2.0 * (z * vx - x * vz), tz = 2.0 * (x * vy - y * vx);
+    const double u[3] = {vx + ww * tx + (y * tz - z * ty), vy + ww * ty + (z * tx - x * tz), vz + ww * tz + (x * ty - y * tx)};
+    return (float)u[w - 12];
+  }
+  if (w == 15) return asf(anc(4));
+  if (w == 16) return asf(anc(8));
+  if (w == 17) return asf(ext ? sk.parent[b] : -1);
+  return 0.0f;
+}
+__host__ __device__ constexpr bool skel_fk_jump(int num_bodies_ext, int max_depth) {
+#ifdef PBHC_FK_WALK           // (measurement aid: the chain walk)
+  return false;
+#else
+  return num_bodies_ext <= PBHC_G && max_depth + 1 <= 16;
+#endif
+}
+constexpr bool cfg_fk_jump(const PbhcEnvConfig& c) { return skel_fk_jump(c.skel.num_bodies_ext, c.skel.max_depth); }
+__host__ __device__ constexpr int skel_fk_rounds(int max_depth) { return max_depth + 1 <= 2 ? 1 : max_depth + 1 <= 4 ? 2 : max_depth + 1 <= 8 ? 3 : 4; }
+__device__ __forceinline__ float fk_lane_get(float v, int byte_addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+#pragma clang fp contract(fast)
+// kr: this lane's skj row (5 x float4), rounds = ceil(log2(max_depth + 1)) <= 4 (a literal in specialised builds); every lane of the wave
+// calls it (bpermute reads inactive lanes as 0)
+__device__ __forceinline__ void fk_jump_wave(const float4 (&kr)[5], int rounds, int B, int Bx, int lane, bool valid, const float* root, const float* q, const float* qd,
+                                             float* bp, float* bq, float* bv, float* bw) {
+  const int b = lane;
+  const int half = (int)(threadIdx.x & 32u);                   // this env's 32 lanes inside the wave
+  const bool real = valid && b < B, extb = valid && b >= B && b < Bx;
+  f4 R = mk4(0.0f, 0.0f, 0.0f, 1.0f);
+  f3 P = mk3(0.0f, 0.0f, 0.0f), W = P, V = P;
+  if (real) {
+    if (b == 0) { P = ld3(root); R = quat_unit_fast(ld4(root + 3)); V = ld3(root + 7); W = ld3(root + 10); }     // (unit root rotation for the chain: see fk_walk)
+    else {
+      const float qj = q[b - 1], qdj = qd[b - 1];
+      R = fk_mul(mk4(kr[1].x, kr[1].y, kr[1].z, kr[1].w), quat_from_angle_unit_axis(qj, mk3(kr[2].x, kr[2].y, kr[2].z)));
+      P = mk3(kr[0].x, kr[0].y, kr[0].z);
+      W = mk3(kr[3].x * qdj, kr[3].y * qdj, kr[3].z * qdj);
+    }
+  }
+  STAMP(20);
+  const int ancs[4] = {__float_as_int(kr[0].w), __float_as_int(kr[2].w), __float_as_int(kr[3].w), __float_as_int(kr[4].x)};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= rounds) break;
+    const int a = ancs[r];
+    const bool act = real && a >= 0;
+    const int addr = (half + max(a, 0)) << 2;
+    const f4 R1 = mk4(fk_lane_get(R.x, addr), fk_lane_get(R.y, addr), fk_lane_get(R.z, addr), fk_lane_get(R.w, addr));
+    const f3 P1 = mk3(fk_lane_get(P.x, addr), fk_lane_get(P.y, addr), fk_lane_get(P.z, addr));
+    const f3 W1 = mk3(fk_lane_get(W.x, addr), fk_lane_get(W.y, addr), fk_lane_get(W.z, addr));
+    const f3 V1 = mk3(fk_lane_get(V.x, addr), fk_lane_get(V.y, addr), fk_lane_get(V.z, addr));
+    const fkm33 M = fk_matrix(R1);
+    const f3 rp = fk_mv(M, P), rw = fk_mv(M, W), rv = fk_mv(M, V);
+    const f4 Rn = fk_mul(R1, R);
+    const f3 Vn = add3(fk_add_cross(V1, W1, rp), rv);
+    if (act) { R = Rn; P = add3(P1, rp); W = add3(W1, rw); V = Vn; }
+  }
+  if (real) {
+    const float n = __builtin_amdgcn_rsqf(fmaxf(R.x * R.x + R.y * R.y + R.z * R.z + R.w * R.w, 1e-18f));
+    R = mk4(R.x * n, R.y * n, R.z * n, R.w * n);
+  }
+  STAMP(21);
+  const f4 Rchain = R;                                         // (what the extended bodies hang on: the root's is the unit one)
+  if (real && b == 0) R = ld4(root + 3);                       // the root body keeps the frame's quaternion as it is
+  {
+    // extended bodies (motion_tracking.py:619-643): the parent's finished state, then p = R_ext(R_par off) + p_par, q = q_par q_ext,
+    // w = w_par, v = v_par + w_par x off (offset NOT rotated, sic) — as fk_walk
+    const int ep = __float_as_int(kr[4].y);
+    const int addr = (half + max(ep, 0)) << 2;
+    const f4 R1 = mk4(fk_lane_get(Rchain.x, addr), fk_lane_get(Rchain.y, addr), fk_lane_get(Rchain.z, addr), fk_lane_get(Rchain.w, addr));
+    const f3 P1 = mk3(fk_lane_get(P.x, addr), fk_lane_get(P.y, addr), fk_lane_get(P.z, addr));
+    const f3 W1 = mk3(fk_lane_get(W.x, addr), fk_lane_get(W.y, addr), fk_lane_get(W.z, addr));
+    const f3 V1 = mk3(fk_lane_get(V.x, addr), fk_lane_get(V.y, addr), fk_lane_get(V.z, addr));
+    if (extb) {
+      const f3 off = mk3(kr[0].x, kr[0].y, kr[0].z);
+      const f4 eq = mk4(kr[1].x, kr[1].y, kr[1].z, kr[1].w);
+      P = add3(quat_rotate(eq, quat_rotate(R1, off)), P1);
+      V = add3(V1, cross3(W1, off));
+      R = quat_mul(R1, eq);
+      W = W1;
+    }
+  }
+  if (valid && b < Bx) { st3(bp + 3 * b, P); st4(bq + 4 * b, R); st3(bv + 3 * b, V); st3(bw + 3 * b, W); }
+  STAMP(22);
+}
+#pragma clang fp contract(off)
 
 // ---- frame blend (motion_lib_base.py:503-513) -------------------------------------------------
 __device__ __forceinline__ void frame_blend(float t, float len, int nf, float dt, int* f0, int* f1, float* blend) {
@@ -556,7 +690,12 @@ __host__ __device__ constexpr StepLds step_lds_plan(const PbhcEnvConfig& c, bool
   const int stride = stage;
 #endif
   const int mapw = use_runs ? 0 : c.map_lds_words;
-  const int words = PBHC_EPB * stride + ((Bx * (11 + PBHC_MAX_DEPTH) + 3) & ~3) + mapw;
+#ifdef PBHC_WIDE_ROWS
+  const bool skc_lds = true;                                  // (the second staging segment lives there)
+#else
+  const bool skc_lds = !cfg_fk_jump(c);                       // the pointer-jumping chain keeps its constants in registers (fk_jump_wave)
+#endif
+  const int words = PBHC_EPB * stride + (skc_lds ? ((Bx * (11 + PBHC_MAX_DEPTH) + 3) & ~3) : 0) + mapw;
   return StepLds{stride, hb ? 1 : 0, mapw, words * 4, stage};
 }
 // the uniform of element j of row `stream`: the first word of the env's Philox quad of this step (keyed by env / step only: every lane
@@ -709,7 +848,8 @@ template <int MODE>
 // — the compiler stopped at 96 VGPRs and spilled — buys nothing)
 __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_waves_per_eu(PBHC_MIN_WAVES, PBHC_MIN_WAVES))) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
-                                                              int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img) {
+                                                              int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img,
+                                                              const float* __restrict__ skj_img) {
   // `rt`: the run-time config (device memory).  `c`: the same values, or — in a config-specialised build — a constexpr copy
   // whose scalars fold into the instruction stream; pointers, seed, env count and reference yaw always come from `rt`.
   // The config is read through the CONSTANT address space: the kernel never writes it, and saying so lets the compiler keep its
@@ -784,9 +924,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // bar2 — over the simulator body arrays
 #ifdef PBHC_STATIC_CFG
   constexpr bool hist_b = step_lds_plan(kStaticCfg, use_runs).hist_in_bodies != 0;
+  constexpr bool fk_jump = cfg_fk_jump(kStaticCfg);                             // the rigid-body chain by pointer jumping (fk_jump_wave)
+  constexpr int fk_rounds = skel_fk_rounds(kStaticCfg.skel.max_depth);
 #else
   const bool hist_b = false;
+  const bool fk_jump = skel_fk_jump(Bx, sk.max_depth);                          // (the generic kernel: the same algorithm, decided per launch)
+  const int fk_rounds = skel_fk_rounds(sk.max_depth);
 #endif
+  // hist_b builds: the per-dof episodic DR draws of a reset (gain / torque-noise scales, queue) are the reference waves' — they own the
+  // kp / kd features and idle at bar3 in exactly the workgroups that finish last (the ones with a terminated env), while the dynamics
+  // waves still have the reward phase and the rest of the reset in front of them
+  const bool dr_on_b = hist_b;
   float* const histl = hist_b ? bp : feat + hoff;
   const float* const fhist = histl - hoff;
 #ifdef PBHC_STATIC_CFG
@@ -864,6 +1012,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // The skeleton constants are staged by the reference waves (bar0 below): round 3 had EACH dynamics wave load the whole 2.5 KB image
     // for itself — 10 of its 25 load instructions and 9 % of the bytes a workgroup pulls through the CU's vector-memory pipeline, which
     // is what bounds the launch at large env counts (profiles/round4_k_env_step_memory_pipeline.txt).
+    float4 kr[5];                                              // fk_jump: this lane's body constants, straight into registers
+    if (fk_jump) {
+      const float4* __restrict__ row = reinterpret_cast<const float4*>(skj_img + SKJ_W * min(lane, Bx - 1));
+#pragma unroll
+      for (int u = 0; u < 5; ++u) kr[u] = row[u];
+    }
     const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
     const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
@@ -881,7 +1035,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       psrc0 = pt.v[lane]; psrc1 = pt.v[lane + PBHC_G];
     }
 
-    LDS_BARRIER();                                             // bar0: the skeleton image is in LDS (an L2 hit: long before this wave's frame is)
+    if (!fk_jump) LDS_BARRIER();                               // bar0: the skeleton image is in LDS (an L2 hit: long before this wave's frame is)
     STAMP(1);
     if (valid) {
       if (d < D) { q[d] = fq; qd[d] = fqd; }
@@ -890,16 +1044,54 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     // =============== role A, interval 1: rigid-body state of the new frame (sim-stub FK), wave-local ==============================
 #ifndef PBHC_ABL_FK
-    fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+    if (fk_jump) fk_jump_wave(kr, fk_rounds, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+    else fk_walk_wave(skc, B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
 #else       // (timing ablations, -DPBHC_ABL_*: what a phase costs is read off the launch time without it; results are meaningless)
     if (valid && lane < Bx) { st3(bp + 3 * lane, ld3(root)); st4(bq + 4 * lane, ld4(root + 3)); st3(bv + 3 * lane, ld3(root + 7)); st3(bw + 3 * lane, ld3(root + 10)); }
 #endif
+    // ---- phase C: per-env scalars of the root state (legged_robot_base.py:346-380).  One lane per quantity and ONE code path per function:
+    // lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of the pitch, lanes 4-6 the three base-frame rotations (lane 0
+    // doing all of it in turn was ~450 instructions; roll and pitch only exist where an observation reads them: general tracking).
+#ifdef PBHC_ABL_PHASEC
+    if (false) {
+#else
+    if (valid) {
+#endif
+      const f4 rq4 = ld4(root + 3);
+      if (lane < 3) {
+        float sinr, cosr, sinp, siny, cosy;
+        euler_xyz_args(rq4, &sinr, &cosr, &sinp, &siny, &cosy);
+        const f3 hx = quat_rotate(rq4, mk3(1.0f, 0.0f, 0.0f));                  // calc_heading rotations.py:257-268
+        const float ang = atan2f(lane == 0 ? siny : (lane == 1 ? hx.y : sinr), lane == 0 ? cosy : (lane == 1 ? hx.x : cosr));
+        if (lane == 0) feat[c.feat_off[PBHC_F_RELYAW]] = ang - rt.ref_init_yaw;
+        else if (lane == 1) st4(misc + M_HINV, quat_from_angle_z(-ang));        // calc_heading_quat_inv rotations.py:296-306
+        else if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH]] = ang;
+      } else if (lane == 3) {
+        if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = euler_xyz(rq4).y;
+      } else if (lane <= 6) {
+        // the same rotation of three different vectors
+        const f3 vin = lane == 4 ? ld3(root + 7) : (lane == 5 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
+        const f3 vo = quat_rotate_inverse(rq4, vin);
+        const int off = lane == 4 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 5 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
+        st3(feat + off, vo);
+        if (lane == 6) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
+      }
+    }
+    // the observation-noise base of this env and step (obs_noise_u): ONE Philox call per env, here — these waves wait at bar1 —, handed
+    // to whichever wave writes a row through LDS
+#ifndef PBHC_ABL_RNG
+    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);
+#else
+    nzb[0] = env ^ step_ctr; nzb[1] = nzb[2] = nzb[3] = 0;
+#endif
+    if (valid && lane == 0) misc[M_NZB] = __uint_as_float(nzb[0]);
+    WAVE_LDS_FENCE();
     STAMP(2);
   } else {
     // the skeleton constants for the dynamics waves' FK: ONE copy per workgroup, the first thing these two waves request (an L2 hit)
 #define SKC_REGSB ((SKC_WORDS + 2 * 64 - 1) / (2 * 64))
     float skregB[SKC_REGSB];
-    {
+    if (!fk_jump) {
       const int n = Bx * SKC_W, wl = threadIdx.x & 127;
 #pragma unroll
       for (int u = 0; u < SKC_REGSB; ++u) skregB[u] = skc_img[min(wl + u * 128, n - 1)];
@@ -940,12 +1132,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
     fric = io.dr_friction[envc];
     __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks (2) below the wait for (1))
-    {
+    if (!fk_jump) {
       const int n = Bx * SKC_W, wl = threadIdx.x & 127;
 #pragma unroll
       for (int u = 0; u < SKC_REGSB; ++u) { const int i = wl + u * 128; if (i < n) skc[i] = skregB[u]; }
+      LDS_BARRIER();                                            // bar0
     }
-    LDS_BARRIER();                                              // bar0
     LOAD_CLIP_META_OF_ID();                                     // (a library: one more dependent trip, clip id -> clip meta, with (2) in flight)
     // reference rows: address from the env scalars, loads issued now, consumed in phase D
     float blend = 0.0f;
@@ -1086,51 +1278,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     }
     clipcnt = group_sum(clipcnt);
     WAVE_LDS_FENCE();
-    // ---- phase C: per-env scalars (legged_robot_base.py:346-380; time of the reference frame motion_tracking.py:554,588) ---------
-    // Here, on the reference waves, which reach bar1 ~3 k cycles before the dynamics waves (whose FK chain sets the kernel's duration: on
-    // those waves these ~2 k cycles were pure critical path).  The root state of the new frame comes from this role's own load of it; the
-    // LDS copy is written by both roles with identical words.
+    // ---- phase C, this role's share: the reference time / phase (motion_tracking.py:554,588).  The scalars derived from the root state
+    // (heading, base-frame velocities, gravity: legged_robot_base.py:346-380) are the dynamics waves' since round 4 — with the chain
+    // evaluated by pointer jumping those waves reach bar1 first (the reverse of round 3).
     if (valid && lane < 13) root[lane] = frootB;
-    WAVE_LDS_FENCE();
-    // One lane per quantity and ONE code path per function: lanes 0-2 evaluate the three atan2 (yaw, heading, roll), lane 3 the asin of
-    // the pitch, lanes 4-6 the three base-frame rotations, lane 7 the reference time (lane 0 doing all of it in turn was ~450 instructions
-    // of the chain; roll and pitch only exist where an observation reads them: general tracking).
-#ifdef PBHC_ABL_PHASEC
-    if (false) {
-#else
-    if (valid) {
-#endif
-      const f4 rq4 = ld4(root + 3);
-      if (lane < 3) {
-        float sinr, cosr, sinp, siny, cosy;
-        euler_xyz_args(rq4, &sinr, &cosr, &sinp, &siny, &cosy);
-        const f3 hx = quat_rotate(rq4, mk3(1.0f, 0.0f, 0.0f));                  // calc_heading rotations.py:257-268
-        const float ang = atan2f(lane == 0 ? siny : (lane == 1 ? hx.y : sinr), lane == 0 ? cosy : (lane == 1 ? hx.x : cosr));
-        if (lane == 0) feat[c.feat_off[PBHC_F_RELYAW]] = ang - rt.ref_init_yaw;
-        else if (lane == 1) st4(misc + M_HINV, quat_from_angle_z(-ang));        // calc_heading_quat_inv rotations.py:296-306
-        else if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH]] = ang;
-      } else if (lane == 3) {
-        if (MODE) feat[c.feat_off[PBHC_F_ROLL_PITCH] + 1] = euler_xyz(rq4).y;
-      } else if (lane <= 6) {
-        // the same rotation of three different vectors
-        const f3 vin = lane == 4 ? ld3(root + 7) : (lane == 5 ? ld3(root + 10) : mk3(0.0f, 0.0f, -1.0f));
-        const f3 vo = quat_rotate_inverse(rq4, vin);
-        const int off = lane == 4 ? c.feat_off[PBHC_F_BASE_LIN_VEL] : (lane == 5 ? c.feat_off[PBHC_F_BASE_ANG_VEL] : c.feat_off[PBHC_F_PROJECTED_GRAVITY]);
-        st3(feat + off, vo);
-        if (lane == 6) { misc[M_GX] = vo.x; misc[M_GY] = vo.y; misc[M_GZ] = vo.z; }
-      } else if (lane == 7) {
-        const float t = (float)(ep1 + 1) * dt + start;
-        misc[M_EPLEN] = (float)ep1;
-        misc[M_START] = start; misc[M_MLEN] = mlenB;
-        feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlenB;
-      }
+    if (valid && lane == 7) {
+      const float t = (float)(ep1 + 1) * dt + start;
+      misc[M_EPLEN] = (float)ep1;
+      misc[M_START] = start; misc[M_MLEN] = mlenB;
+      feat[c.feat_off[PBHC_F_REF_MOTION_PHASE]] = t / mlenB;
     }
     WAVE_LDS_FENCE();
-#ifndef PBHC_ABL_RNG
-    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar1 next
-#else
-    nzb[0] = env ^ step_ctr; nzb[1] = nzb[2] = nzb[3] = 0;
-#endif
     STAMPB(3);
   }
   LDS_BARRIER();                                               // bar1: A's body state and B's reference frame / scalars are in LDS
@@ -1279,11 +1437,6 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
 #endif
     }
     WAVE_LDS_FENCE();
-#ifndef PBHC_ABL_RNG
-    philox4x32((uint32_t)rt.seed, (uint32_t)(rt.seed >> 32), env, step_ctr, 16, 0u, nzb);       // noise base: this wave waits for bar2 next
-#else
-    nzb[0] = env ^ step_ctr; nzb[1] = nzb[2] = nzb[3] = 0;
-#endif
     STAMP(4);
   } else {
     // =============== role B, interval 2a: pre-physics step + torques, joint-space differences + reductions, foot norms, the
@@ -1450,6 +1603,31 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
   }
 
+  if (roleB) nzb[0] = __float_as_uint(misc[M_NZB]);        // (the dynamics waves' Philox word; they keep their own copy in registers)
+  if (dr_on_b && roleB && valid && (misc[M_RESET] != 0.0f || gateB || io.redraw_all != 0)) {
+    // _episodic_domain_randomization of a terminated (or re-drawn) env, per-dof part (legged_robot_base.py:599-631): the same Philox stream
+    // and injected-draw overrides as the dynamics waves' form (phase G), the new gains straight into the features the late rows read
+    const int o_kp = c.feat_off[PBHC_F_DR_KP], o_kd = c.feat_off[PBHC_F_DR_KD];
+    for (int dd = lane; dd < D; dd += PBHC_G) {
+      float ur[4];
+      pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, dd, ur);
+      if (c.randomize_pd_gain) {
+        const float kpn = io.ovr_kp ? at(io.ovr_kp, eD + dd) : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
+        const float kdn = io.ovr_kd ? at(io.ovr_kd, eD + dd) : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
+        at(io.kp_scale, eD + dd) = kpn;
+        at(io.kd_scale, eD + dd) = kdn;
+        feat[o_kp + dd] = kpn;
+        feat[o_kd + dd] = kdn;
+      }
+      if (c.randomize_rfi_lim)
+        at(io.rfi_lim_scale, eD + dd) = io.ovr_rfi_lim ? at(io.ovr_rfi_lim, eD + dd) : (c.rfi_lim_range[1] - c.rfi_lim_range[0]) * ur[2] + c.rfi_lim_range[0];
+      if (c.use_rao)
+        at(io.rao_scale, eD + dd) = io.ovr_rao ? at(io.ovr_rao, eD + dd) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
+      if (c.randomize_ctrl_delay)
+        for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
+    }
+    WAVE_LDS_FENCE();
+  }
   const float clipobs = c.clip_observations;     // config scalars used inside the store loops live in locals
   const int ngroups = c.num_groups;
   // Observation rows: group g is written by the role the host assigned it to (PbhcOutMap.role, balanced by row width), 32 lanes per env.
@@ -1724,8 +1902,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       }
       for (int dd = lane; dd < D; dd += PBHC_G) {
         if (do_reset) { act[dd] = 0.0f; actd[dd] = 0.0f; }
-        float ur[4];                                    // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
-        pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, dd, ur);
+        float ur[4] = {0.0f, 0.0f, 0.0f, 0.0f};          // the four episodic draws of this dof (kp, kd, rfi limit, rao) from one Philox call
+        if (!dr_on_b) pbhc::rng_uniform4(rt.seed, env, step_ctr, 2, dd, ur);
+        if (dr_on_b) {
+        } else {
         if (c.randomize_pd_gain) {
           kpA = io.ovr_kp ? at(io.ovr_kp, eD + dd) : (c.kp_range[1] - c.kp_range[0]) * ur[0] + c.kp_range[0];
           kdA = io.ovr_kd ? at(io.ovr_kd, eD + dd) : (c.kd_range[1] - c.kd_range[0]) * ur[1] + c.kd_range[0];
@@ -1738,6 +1918,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
           at(io.rao_scale, eD + dd) = io.ovr_rao ? at(io.ovr_rao, eD + dd) : (c.rao_lim - (-c.rao_lim)) * ur[3] + (-c.rao_lim);
         if (c.randomize_ctrl_delay)
           for (int k = 0; k < Q; ++k) at(io.action_queue, ((u32)env * (u32)Q + (u32)k) * (u32)D + (u32)dd) = 0.0f;     // queue *= 0 (finite values)
+        }
         if (c.randomize_default_dof_pos && io.default_dof_pos) {    // legged_robot_base.py:632-635 (its own Philox stream: off in the shipped yamls)
           float ub[4];
           pbhc::rng_uniform4(rt.seed, env, step_ctr, 9, dd, ub);
@@ -1808,8 +1989,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         feat[o_q + dd] = q[dd] - dpA;                            // (a reset replaced it in registers, like kpA)
         feat[o_qd + dd] = qd[dd];
         feat[o_a + dd] = act[dd];
-        feat[o_kp + dd] = kpA;                                   // D <= 32: lane dd owns dof dd in the prologue load and in the reset path alike
-        feat[o_kd + dd] = kdA;
+        if (!dr_on_b) {
+          feat[o_kp + dd] = kpA;                                 // D <= 32: lane dd owns dof dd in the prologue load and in the reset path alike
+          feat[o_kd + dd] = kdA;
+        }
       }
       if (lane == 0) {
         feat[c.feat_off[PBHC_F_DR_CTRL_DELAY]] = misc[M_DELAY];

@@ -454,6 +454,7 @@ struct PbhcEnv {
   double* d_glob;
   float* d_partials;
   float* d_skc;
+  float* d_skj;              // per-body rows of the pointer-jumping chain (fk_jump_wave: skj_word)
   int nblocks;
   int lds_stride;
   size_t lds_bytes;
@@ -665,6 +666,12 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
     for (int i = 0; i < SKC_WORDS; ++i) img[i] = i < Bx * SKC_W ? skel_word(cfg->skel, i) : 0.0f;
     HIP_CHECK(hipMemcpy(e->d_skc, img, sizeof(img), hipMemcpyHostToDevice));
   }
+  if (hipMalloc(&e->d_skj, PBHC_MAX_BODIES * SKJ_W * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); (void)hipFree(e->d_partials); (void)hipFree(e->d_skc); delete e; return PBHC_ENOMEM; }
+  {
+    float img[PBHC_MAX_BODIES * SKJ_W];
+    for (int i = 0; i < PBHC_MAX_BODIES * SKJ_W; ++i) img[i] = i < Bx * SKJ_W ? skj_word(cfg->skel, i) : 0.0f;
+    HIP_CHECK(hipMemcpy(e->d_skj, img, sizeof(img), hipMemcpyHostToDevice));
+  }
   HIP_CHECK(hipMemcpy(e->d_cfg, &e->cfg, sizeof(PbhcEnvConfig), hipMemcpyHostToDevice));
   if (e->lds_bytes > 64 * 1024)
     HIP_CHECK(hipFuncSetAttribute(cfg->tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
@@ -735,6 +742,7 @@ void pbhc_env_destroy(PbhcEnv* e) {
   (void)hipFree(e->d_cfg);
   (void)hipFree(e->d_partials);
   (void)hipFree(e->d_skc);
+  (void)hipFree(e->d_skj);
   delete e;
 }
 
@@ -822,6 +830,7 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   const double* a_glob = e->d_glob;
   const float* a_skc = e->d_skc;
   const uint32_t* a_map = e->cfg.map_image;
+  const float* a_skj = e->d_skj;
   PbhcStepIO a_io = *io;
   a_io.obs_wide = 1;
   for (int g = 0; g < e->cfg.num_groups; ++g) {
@@ -830,7 +839,7 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   }
   int a_stride = e->spec_fn ? e->spec_lds_stride : e->lds_stride;
   const size_t a_lds = e->spec_fn ? e->spec_lds_bytes : e->lds_bytes;
-  void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map};
+  void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map, (void*)&a_skj};
   const void* fn = e->spec_fn ? e->spec_fn : (e->cfg.tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>);
   if (e->profile) HIP_CHECK(hipExtLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st, pe0, pe1, 0));
   else HIP_CHECK(hipLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st));

@@ -180,6 +180,21 @@ __device__ __forceinline__ f4 fk_mul_unit(f4 a, f4 b) {
   return mk4(x * r, y * r, z * r, w * r);
 }
 // a + s b, a + b x c
+// the pieces of the pointer-jumping chain (fk_jump_wave): Hamilton product without the renormalisation (done once, after the last round),
+// and ONE quaternion turned into its rotation matrix for the three vectors a composition rotates by it (15 + 3 x 9 instead of 3 x 18)
+__device__ __forceinline__ f4 fk_mul(f4 a, f4 b) {
+  return mk4(a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+             a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
+}
+struct fkm33 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };
+__device__ __forceinline__ fkm33 fk_matrix(f4 q) {
+  const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  const float xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+  return fkm33{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+}
+__device__ __forceinline__ f3 fk_mv(const fkm33& m, f3 v) {
+  return mk3(m.m00 * v.x + m.m01 * v.y + m.m02 * v.z, m.m10 * v.x + m.m11 * v.y + m.m12 * v.z, m.m20 * v.x + m.m21 * v.y + m.m22 * v.z);
+}
 __device__ __forceinline__ f3 fk_axpy(f3 a, float s, f3 b) { return mk3(a.x + s * b.x, a.y + s * b.y, a.z + s * b.z); }
 __device__ __forceinline__ f3 fk_add_cross(f3 a, f3 b, f3 c) {
   return mk3(a.x + (b.y * c.z - b.z * c.y), a.y + (b.z * c.x - b.x * c.z), a.z + (b.x * c.y - b.y * c.x));

@@ -86,6 +86,15 @@ class StepExtras(dict):
     def get(self, k, default=None):
         return self[k] if k in self else default
 
+    def __iter__(self):
+        # (an overridden __iter__ takes `dict(extras)` / `{**extras}` / `other.update(extras)` off CPython's storage-level fast path: they
+        # then read through keys() + __getitem__, i.e. they see the lazy members materialised, not None)
+        return iter(list(dict.keys(self)))
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(dict.items(self)),))
+
     def items(self):
         self._fill()
         return dict.items(self)
@@ -457,6 +466,10 @@ class LeggedRobotMotionTracking:
             return
         self.wait_finalize()
         pdist.allreduce_mean_(self.globals, group=self._stat_group)
+        # the step counter (the kernels' Philox counter, read as (uint32_t)) is the same integer on every rank; a mean formed as
+        # sum(x / n) may come back one ulp short for world sizes that are not powers of two — truncation would then replay a counter
+        c = K["PBHC_G_STEP_COUNTER"]
+        self.globals[c:c + 1].round_()
 
     def set_finalize_stream(self, stream):
         """Run every step's one-workgroup reduction (`pbhc_env_step_finish`: sigma EMA, curricula, log means, step counter) on `stream`

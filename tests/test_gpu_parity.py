@@ -579,8 +579,10 @@ def test_lazy_simulator_surface_and_reference_bodies_equal_the_stored_ones():
     """The fused step stores neither the simulator surface's rigid-body state / contact forces nor extras['ref_body_*_extend'] unless asked
     (PbhcStepIO: NULL); read afterwards they are re-derived from the replay frame / the step's reference time.  Both forms of the same
     step: the kernel's own stores (set_eager_outputs) against the lazy tensors — bit for bit where both sides run the same un-fused
-    arithmetic (reference lerp / slerp, contact copy), to 2e-6 for the rigid-body chain, whose fused multiply-adds (pbhc_math.h, fk_*) the
-    compiler may pair differently in the stand-alone FK kernel and in the step kernel."""
+    arithmetic (reference lerp / slerp, contact copy); the rigid-body chain to 2e-6 for poses and 1e-5 for twists: the stand-alone FK
+    kernel WALKS every body's chain (renormalising the rotation at every joint), the specialised step kernel composes the same chain by
+    pointer jumping (csrc/pbhc_env_step.h: fk_jump_wave — another association order, one renormalisation at the end), and a joint
+    turning at 10 rad/s carries those few ulps into its angular velocity."""
     cfg, env = build_hip_env("v1_g1_23dof_walk.yaml", 96)
     obs = env.reset_all()
     import bench
@@ -594,7 +596,8 @@ def test_lazy_simulator_surface_and_reference_bodies_equal_the_stored_ones():
         obs, rew, reset, extras = env.step({"actions": 0.3 * torch.randn(96, env.num_dof, device=DEV, generator=gen)})
         torch.cuda.synchronize()
         e = env._eager
-        close(env.simulator._rigid_body_state, e["rigid_body_state"], 2e-6, f"step {k} lazy rigid-body state", rtol=2e-6)
+        close(env.simulator._rigid_body_state[..., :7], e["rigid_body_state"][..., :7], 2e-6, f"step {k} lazy rigid-body pose", rtol=2e-6)
+        close(env.simulator._rigid_body_state[..., 7:], e["rigid_body_state"][..., 7:], 1e-5, f"step {k} lazy rigid-body twist", rtol=1e-5)
         assert torch.equal(env.simulator.contact_forces, e["contact_forces"]), k
         assert torch.equal(extras["ref_body_pos_extend"], e["ref_body_pos_extend"]), k
         assert torch.equal(extras["ref_body_rot_extend"], e["ref_body_rot_extend"]), k
