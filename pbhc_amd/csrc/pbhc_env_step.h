@@ -679,7 +679,7 @@ __host__ __device__ constexpr StepLds step_lds_plan(const PbhcEnvConfig& c, bool
 #ifdef PBHC_NO_HISTB          // (measurement aid: the round-3 LDS plan)
   const bool hb = false;
 #else
-  const bool hb = use_runs && all_b && hoff + c.hist_dim == c.feat_dim && c.hist_dim <= 13 * p && c.hist_dim <= (384 / PBHC_G) * PBHC_G;
+  const bool hb = use_runs && all_b && hoff + c.hist_dim == c.feat_dim && ((c.hist_dim + 3) & ~3) <= 13 * p && c.hist_dim <= (384 / PBHC_G) * PBHC_G;
 #endif
   const int feat_words = hb ? hoff : c.feat_dim;
   // (hist_in_bodies builds also compose their rows in a PBHC_SEG-float staging segment per env: obs_write_wide)
@@ -846,7 +846,17 @@ template <int MODE>
 #endif
 // (waves_per_eu pins the allocation target too: LDS admits no more than PBHC_MIN_WAVES waves per SIMD, so aiming at a higher occupancy
 // — the compiler stopped at 96 VGPRs and spilled — buys nothing)
-__global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_waves_per_eu(PBHC_MIN_WAVES, PBHC_MIN_WAVES))) void k_env_step(const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
+// The first eight parameters are the addresses (and two scalars) the first memory round trip of a workgroup hangs on — a copy of what `io`
+// and the config also hold — so that each role can request the episode clock / the replay frame first thing.  Measured and NOT adopted:
+// preloading them into SGPRs at wave launch (PBHC_KERNARG_PRELOAD=14 -> -mllvm -amdgpu-kernarg-preload-count): the reference waves then
+// enter their role 395 cycles into the launch instead of 1 525 and issue these loads at once — and the data is back at the same 6 k cycles:
+// with every workgroup of the chip in its prologue the first round trip is the HBM burst itself (12.7 MB at ~5 TB/s), not the issue time
+// (profiles/round4_k_env_step_prologue.txt).
+__global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_waves_per_eu(PBHC_MIN_WAVES, PBHC_MIN_WAVES))) void k_env_step(
+                                                              const long long* __restrict__ a_ep_len, const float* __restrict__ a_start, const float* __restrict__ a_frame_root,
+                                                              const float* __restrict__ a_frame_q, const float* __restrict__ a_frame_qd, const int32_t* __restrict__ a_cursor,
+                                                              int a_frame_index, int a_num_envs,
+                                                              const PbhcEnvConfig* __restrict__ cfgp, PbhcMotionTable tbl, PbhcStepIO io,
                                                               const double* __restrict__ glob, float* __restrict__ partials,
                                                               int lds_stride, const float* __restrict__ skc_img, const uint32_t* __restrict__ map_img,
                                                               const float* __restrict__ skj_img) {
@@ -869,7 +879,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   ConstCfg& c = rt;
 #endif
   const auto& sk = c.skel;
-  const int N = rt.num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
+  const int N = a_num_envs, D = sk.num_dof, B = sk.num_bodies, Bx = sk.num_bodies_ext, NF = c.num_feet;
   const int lane = threadIdx.x & (PBHC_G - 1);
   const int wave = threadIdx.x >> 6;
   const bool roleB = wave >= 2;                                            // wave-uniform (alternating the roles' waves between co-resident
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   float *rp = S + lo.rp, *rq = S + lo.rq, *rv = S + lo.rv, *rw = S + lo.rw;
   float *red = S + lo.red, *feat = S + lo.feat;
   // replay frame of this step: named by the host, or read from the device-side cursor
-  const size_t fk = (size_t)(io.frame_index >= 0 ? io.frame_index : io.frame_cursor[0] % io.num_frames) * (size_t)N;
+  const size_t fk = (size_t)(a_frame_index >= 0 ? a_frame_index : a_cursor[0] % io.num_frames) * (size_t)N;
   // Addressing: every per-env tensor is indexed as <uniform 64-bit base> + <32-bit unsigned lane offset> (`at`), which the compiler emits
   // as the SGPR-base form of global_load / global_store (pbhc_env_create / pbhc_env_step check that num_envs x row pitch < 2^30 elements).
   const uint32_t step_ctr = (uint32_t)glob[PBHC_G_STEP_COUNTER];                 // RNG counter: advanced by k_env_finalize
@@ -978,9 +988,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     m_len = tbl.motion_len[mid]; m_nf = tbl.num_frames[mid]; m_dt = tbl.motion_dt[mid]; m_row0 = tbl.length_starts[mid]; \
   }
 #define LOAD_CLIP_META() LOAD_CLIP_ID() LOAD_CLIP_META_OF_ID()
-  const long long ep1 = io.episode_length_buf[envc] + 1;
-  const float start = io.motion_start_times[envc];
 
+  long long ep1 = 0;                                          // role B: the episode clock of this step (loaded first thing in its prologue)
+  float start = 0.0f;
   // role-A registers that live across phases
   uint32_t psrc0 = 0, psrc1 = 0;                              // sources of this lane's two partial-sum columns (kPartTab)
   float sumrow = 0.0f, pf_tscale = 0.0f, pf_sigma = 1.0f, pf_pen_scale = 1.0f, pf_far_thr = 0.0f, kpA = 1.0f, kdA = 1.0f, dpA = 0.0f, etr_old = 0.0f;
@@ -991,6 +1001,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   float tref = 0.0f;
   float qold[PBHC_MAX_QUEUE];
   float hreg[PBHC_HREG];                                      // role B: the env's history row, requested before bar1, copied to LDS after it
+  // ... hist_b builds: the same row 16 bytes per lane (3 load instructions instead of 10: at 4096 envs every workgroup of the chip is in its
+  // prologue at once and the CU's address unit, one wave-instruction at a time whatever its width, is what the load burst queues behind)
+#define PBHC_HREG4 ((384 / 4 + PBHC_G - 1) / PBHC_G)
+  float4 hreg4[PBHC_HREG4];
   // Philox quads computed ahead of their use, while the wave waits for its loads: the first quad of every group's noise list (both roles;
   // role A needs role B's rows too after a reset), and role A's reset draws
   uint32_t nzb[4];
@@ -1012,14 +1026,16 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // The skeleton constants are staged by the reference waves (bar0 below): round 3 had EACH dynamics wave load the whole 2.5 KB image
     // for itself — 10 of its 25 load instructions and 9 % of the bytes a workgroup pulls through the CU's vector-memory pipeline, which
     // is what bounds the launch at large env counts (profiles/round4_k_env_step_memory_pipeline.txt).
+    // the replay frame first: its addresses are in SGPRs since the wave was launched
+    const float fq = at(a_frame_q + fk * D, eDc + dc), fqd = at(a_frame_qd + fk * D, eDc + dc);
+    const float froot = at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
+    __builtin_amdgcn_sched_barrier(0);
     float4 kr[5];                                              // fk_jump: this lane's body constants, straight into registers
     if (fk_jump) {
       const float4* __restrict__ row = reinterpret_cast<const float4*>(skj_img + SKJ_W * min(lane, Bx - 1));
 #pragma unroll
       for (int u = 0; u < 5; ++u) kr[u] = row[u];
     }
-    const float fq = at(io.frame_dof_pos + fk * D, eDc + dc), fqd = at(io.frame_dof_vel + fk * D, eDc + dc);
-    const float froot = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
     {
       const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
       pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tsrc = c.term_src[tl_];
@@ -1088,6 +1104,12 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     WAVE_LDS_FENCE();
     STAMP(2);
   } else {
+    STAMPB(9);
+    // the episode clock first: its addresses are in SGPRs since the wave was launched, and the reference rows' addresses hang on it
+    ep1 = a_ep_len[envc] + 1;
+    start = a_start[envc];
+    const float frootB = at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
+    __builtin_amdgcn_sched_barrier(0);
     // the skeleton constants for the dynamics waves' FK: ONE copy per workgroup, the first thing these two waves request (an L2 hit)
 #define SKC_REGSB ((SKC_WORDS + 2 * 64 - 1) / (2 * 64))
     float skregB[SKC_REGSB];
@@ -1097,6 +1119,16 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       for (int u = 0; u < SKC_REGSB; ++u) skregB[u] = skc_img[min(wl + u * 128, n - 1)];
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef PBHC_PTR_BURST
+    // (measurement aid, neutral: the ~30 tensor addresses of this prologue fetched from the argument segment as ONE burst of scalar loads
+    // instead of one or two at a time in front of their first use)
+    asm volatile("" ::"s"(io.episode_length_buf), "s"(io.motion_start_times), "s"(io.motion_ids), "s"(io.env_origins), "s"(io.frame_root), "s"(io.feet_air_time),
+                 "s"(io.last_contacts), "s"(io.frame_contact), "s"(io.action_queue), "s"(io.actions_in), "s"(io.dof_state), "s"(io.kp_scale), "s"(io.kd_scale),
+                 "s"(io.rfi_lim_scale));
+    asm volatile("" ::"s"(io.rao_scale), "s"(io.u_rfi), "s"(io.last_actions), "s"(io.last_dof_vel), "s"(io.action_delay_idx), "s"(io.motion_len), "s"(io.dr_base_com),
+                 "s"(io.dr_friction), "s"(io.dr_link_mass), "s"(tbl.frames));
+#endif
+    STAMPB(10);
     LOAD_CLIP_ID();
     // =============== role B, interval 0: every other load of the step.  ORDER (loads return in issue order): (1) the env scalars the
     // reference rows' addresses hang on — episode length, start time, clip id: issued above; (2) every load that depends on nothing but
@@ -1104,14 +1136,17 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // two table rows.  Round 3 issued (2) BEHIND (3), i.e. after the first round trip had come back: two full trips to memory (6.5 k cycles
     // to this role's first stamp) where one and an L2 hit do.  Then _pre_physics_step (motion_tracking.py:749-768) and the torques from the
     // pre-step state (legged_robot_base.py:795-838).
-    const float frootB = at(io.frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
     const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
-    float creg[128 / PBHC_G];
+    // the frame's contact forces (3 B floats per env): whole quads 16 bytes per lane + the remainder, two load instructions instead of four
+    float4 creg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cregr = 0.0f;
     {
       const float* __restrict__ csrc = io.frame_contact + fk * (size_t)(B * 3);
       const u32 cbase = (u32)envc * (u32)(B * 3);
-#pragma unroll
-      for (int u = 0; u < 128 / PBHC_G; ++u) creg[u] = at(csrc, cbase + (u32)min(lane + u * PBHC_G, B * 3 - 1));
+      const int nq = (B * 3) >> 2;
+      const float* qa = &at(csrc, cbase + 4u * (u32)min(lane, nq - 1));
+      creg4 = make_float4(qa[0], qa[1], qa[2], qa[3]);               // (4-byte aligned rows: the compiler's own dwordx4, as for the table rows)
+      if ((B * 3) & 3) cregr = at(csrc, cbase + (u32)min(4 * nq + lane, B * 3 - 1));
     }
     // operands of the pre-physics step / torques / joint-space sums: consumed after bar1
 #pragma unroll
@@ -1132,6 +1167,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     combias = at(io.dr_base_com, (u32)envc * 3u + (u32)min(lane, 2));
     fric = io.dr_friction[envc];
     __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks (2) below the wait for (1))
+    STAMPB(6);
     if (!fk_jump) {
       const int n = Bx * SKC_W, wl = threadIdx.x & 127;
 #pragma unroll
@@ -1162,13 +1198,18 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       rc0 = r0[2 * D + lc]; rc1 = r1[2 * D + lc];
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMPB(7);
 #ifndef PBHC_ABL_RNG
     if (c.randomize_torque_rfi) u_rfi = io.u_rfi ? 0.5f : rng_uniform(rt.seed, env, step_ctr, 1, d);     // in-kernel draw: computed while the loads fly
 #endif
+    STAMPB(8);
     if (valid) {
       // contact forces and the previous contacts
-#pragma unroll
-      for (int u = 0; u < 128 / PBHC_G; ++u) { const int i = lane + u * PBHC_G; if (i < B * 3) cf[i] = creg[u]; }
+      {
+        const int nq = (B * 3) >> 2;
+        if (lane < nq) *reinterpret_cast<float4*>(cf + 4 * lane) = creg4;
+        if (lane < ((B * 3) & 3)) cf[4 * nq + lane] = cregr;
+      }
       if (lane < NF) { misc[M_FAT0 + lane] = fat; misc[M_LASTC0 + lane] = lastc; }
       if (lane == 0 && NF < 2) { misc[M_FAT1] = 0.0f; misc[M_LASTC1] = 0.0f; }
     }
@@ -1231,9 +1272,19 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const int hlast = c.hist_dim - 1;
 #pragma unroll
 #ifndef PBHC_ABL_HIST
-      for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+      for (int u = 0; u < PBHC_HREG; ++u)
+        if (!hist_b) hreg[u] = at(io.hist, hbase + (u32)min(lane + u * PBHC_G, hlast));
+      if (hist_b) {
+        // (rows are 16-byte aligned with a pitch that is a multiple of 4 — checked by the host: hist_wide — so the last quad may reach into
+        // the row's padding; quads past it repeat the last one)
+        const int nq = (c.hist_dim + 3) >> 2;
+#pragma unroll
+        for (int u = 0; u < PBHC_HREG4; ++u)
+          if (u * PBHC_G < nq) hreg4[u] = *reinterpret_cast<const float4*>(&at(io.hist, hbase + 4u * (u32)min(lane + u * PBHC_G, nq - 1)));
+      }
 #else
       for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = 0.0f;
+      for (int u = 0; u < PBHC_HREG4; ++u) hreg4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
     }
     // per-dof constants of the config: one batch of loads at the head of the interval
@@ -1594,8 +1645,14 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // every row that holds history is written by these waves, so the hand-over is wave-local
     if (roleB && valid) {
       const bool z = misc[M_RESET] != 0.0f || gateB;
+      {
+        const int nq = (c.hist_dim + 3) >> 2;
 #pragma unroll
-      for (int u = 0; u < PBHC_HREG; ++u) { const int i = lane + u * PBHC_G; if (i < c.hist_dim) histl[i] = z ? 0.0f : hreg[u]; }
+        for (int u = 0; u < PBHC_HREG4; ++u) {
+          const int qd_ = lane + u * PBHC_G;
+          if (u * PBHC_G < nq && qd_ < nq) *reinterpret_cast<float4*>(histl + 4 * qd_) = z ? make_float4(0.f, 0.f, 0.f, 0.f) : hreg4[u];
+        }
+      }
     }
     WAVE_LDS_FENCE();
   } else if (valid && (misc[M_RESET] != 0.0f || (roleB && gateB))) {
@@ -1716,7 +1773,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     if (valid && lane < PBHC_NUM_SIGMA) {
       const float e = red[R_ERR0 + lane];
 #ifndef PBHC_ABL_F
-      red[R_EXP0 + lane] = expf(-e / pf_sigma);
+      // exp(-err / sigma) (motion_tracking.py:1154-1290) as 2^(-err log2(e) / sigma) with the hardware reciprocal and 2^x (1 ulp each; the
+      // library's expf + a correctly rounded division are ~35 instructions of the reward chain): relative error <= ~(2 + |x|) 6e-8, i.e.
+      // < 2e-6 for the arguments the tracking terms see — inside the 3e-5 / 1e-4 the reward columns are held to
+      red[R_EXP0 + lane] = __builtin_amdgcn_exp2f((-e * __builtin_amdgcn_rcpf(pf_sigma)) * 1.44269504088896341f);
 #else
       red[R_EXP0 + lane] = e * pf_sigma;
 #endif

@@ -35,6 +35,8 @@ const void* pbhc_spec_kernel(void) { return (const void*)k_env_step<PBHC_SPEC_MO
 // this build's LDS plan (step_lds_plan: no compact maps when the rows are unrolled runs, the history block out of the feature row)
 int pbhc_spec_lds_stride(void) { return step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).stride; }
 int pbhc_spec_lds_bytes(void) { return step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).bytes; }
+// 1: this build reads the history rows 16 bytes per lane (the launch then requires them 16-byte aligned with a pitch that is a multiple of 4 floats)
+int pbhc_spec_hist_wide(void) { return step_lds_plan(kStaticCfg, obs_runs_complete(kStaticCfg)).hist_in_bodies; }
 #ifdef PBHC_STAMPS          // diagnostic builds only (PBHC_SPEC_DEFINES=-DPBHC_STAMPS, tools/kernel_probe.py): this object's own stamp buffers
 int pbhc_spec_read_stamps(unsigned long long* out, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return PBHC_EHIP;

@@ -466,6 +466,7 @@ struct PbhcEnv {
   void* spec_dl;
   int spec_lds_stride;       // ... and its own LDS plan (step_lds_plan)
   size_t spec_lds_bytes;
+  int spec_hist_wide;        // ... which may read the history rows 16 bytes per lane
 };
 
 extern "C" {
@@ -658,6 +659,7 @@ int pbhc_env_create(const PbhcEnvConfig* cfg, const PbhcMotionTable* tbl, double
   e->spec_dl = nullptr;
   e->spec_lds_stride = 0;
   e->spec_lds_bytes = 0;
+  e->spec_hist_wide = 0;
   if (hipMalloc(&e->d_cfg, sizeof(PbhcEnvConfig)) != hipSuccess) { delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_partials, (size_t)e->nblocks * 2 * PBHC_NP * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); delete e; return PBHC_ENOMEM; }
   if (hipMalloc(&e->d_skc, SKC_WORDS * sizeof(float)) != hipSuccess) { (void)hipFree(e->d_cfg); (void)hipFree(e->d_partials); delete e; return PBHC_ENOMEM; }
@@ -706,8 +708,8 @@ int pbhc_env_attach_specialised(PbhcEnv* e, const char* so_path) {
   fn_i abi = (fn_i)dlsym(dl, "pbhc_spec_abi_version"), mode = (fn_i)dlsym(dl, "pbhc_spec_mode");
   fn_c cfgf = (fn_c)dlsym(dl, "pbhc_spec_config");
   fn_k kern = (fn_k)dlsym(dl, "pbhc_spec_kernel");
-  fn_i lds_stride = (fn_i)dlsym(dl, "pbhc_spec_lds_stride"), lds_bytes = (fn_i)dlsym(dl, "pbhc_spec_lds_bytes");
-  if (!abi || !mode || !cfgf || !kern || !lds_stride || !lds_bytes || abi() != PBHC_ABI_VERSION) {
+  fn_i lds_stride = (fn_i)dlsym(dl, "pbhc_spec_lds_stride"), lds_bytes = (fn_i)dlsym(dl, "pbhc_spec_lds_bytes"), hist_wide = (fn_i)dlsym(dl, "pbhc_spec_hist_wide");
+  if (!abi || !mode || !cfgf || !kern || !lds_stride || !lds_bytes || !hist_wide || abi() != PBHC_ABI_VERSION) {
     dlclose(dl);
     snprintf(g_err, sizeof(g_err), "pbhc_env_attach_specialised: %s is not a specialised step kernel of this ABI version", so_path);
     return PBHC_EINVAL;
@@ -728,6 +730,7 @@ int pbhc_env_attach_specialised(PbhcEnv* e, const char* so_path) {
   const void* fn = kern();
   e->spec_lds_stride = lds_stride();
   e->spec_lds_bytes = (size_t)lds_bytes();
+  e->spec_hist_wide = hist_wide();
   if (e->spec_lds_bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->spec_lds_bytes));
   e->spec_fn = fn;
   e->spec_dl = dl;
@@ -831,6 +834,14 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   const float* a_skc = e->d_skc;
   const uint32_t* a_map = e->cfg.map_image;
   const float* a_skj = e->d_skj;
+  if (e->spec_fn && e->spec_hist_wide) {
+    const int hp = io->hist_pitch ? io->hist_pitch : e->cfg.hist_dim;
+    if (((uintptr_t)io->hist & 15) != 0 || (hp & 3) != 0 || hp < ((e->cfg.hist_dim + 3) & ~3)) {
+      snprintf(g_err, sizeof(g_err), "pbhc_env_step: the specialised kernel reads history rows 16 bytes per lane: io.hist must be 16-byte aligned with a pitch that is a "
+                                     "multiple of 4 floats >= hist_dim rounded up to 4 (pad the rows, or detach the specialised kernel)");
+      return PBHC_EINVAL;
+    }
+  }
   PbhcStepIO a_io = *io;
   a_io.obs_wide = 1;
   for (int g = 0; g < e->cfg.num_groups; ++g) {
@@ -839,7 +850,12 @@ int pbhc_env_step_launch(PbhcEnv* e, const PbhcStepIO* io, void* stream) {
   }
   int a_stride = e->spec_fn ? e->spec_lds_stride : e->lds_stride;
   const size_t a_lds = e->spec_fn ? e->spec_lds_bytes : e->lds_bytes;
-  void* args[] = {(void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map, (void*)&a_skj};
+  const long long* a_ep = (const long long*)io->episode_length_buf;
+  const float* a_st = io->motion_start_times;
+  const float *a_fr = io->frame_root, *a_fq = io->frame_dof_pos, *a_fqd = io->frame_dof_vel;
+  const int32_t* a_cur = io->frame_cursor;
+  int a_fi = io->frame_index, a_n = e->cfg.num_envs;
+  void* args[] = {(void*)&a_ep, (void*)&a_st, (void*)&a_fr, (void*)&a_fq, (void*)&a_fqd, (void*)&a_cur, (void*)&a_fi, (void*)&a_n, (void*)&a_cfg, (void*)&e->tbl, (void*)&a_io, (void*)&a_glob, (void*)&e->d_partials, (void*)&a_stride, (void*)&a_skc, (void*)&a_map, (void*)&a_skj};
   const void* fn = e->spec_fn ? e->spec_fn : (e->cfg.tracking_mode ? (const void*)k_env_step<1> : (const void*)k_env_step<0>);
   if (e->profile) HIP_CHECK(hipExtLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st, pe0, pe1, 0));
   else HIP_CHECK(hipLaunchKernel(fn, dim3(e->nblocks), dim3(PBHC_TPB), args, a_lds, st));

@@ -71,6 +71,10 @@ if hasattr(dbg, "pbhc_debug_read_stamps"):
         dd = st[32 + i + 1] - refs[i]
         print(f"    {n:40s} ends {st[32 + i + 1] - st[0]:8d} cyc after start  (+{dd})")
 
+    if st[32 + 6]:
+        print(f"  role B prologue detail (cycles after start): wave entered its role {st[32 + 9] - st[0]}, tensor addresses in SGPRs {st[32 + 10] - st[0]}, independent loads issued {st[32 + 6] - st[0]}, env scalars back + rows issued {st[32 + 7] - st[0]}, "
+              f"torque-noise Philox done {st[32 + 8] - st[0]}, contacts in LDS (all prologue loads back) {st[32 + 1] - st[0]}")
+
 if hasattr(dbg, "pbhc_debug_read_wg_times"):
     nwg = (N + 3) // 4
     wt = (C.c_ulonglong * (2 * nwg))()
