@@ -426,6 +426,11 @@ int pbhc_motion_state(const PbhcMotionTable* tbl, int num_bodies_ext, int num_do
  * supplied in the reference (isaacgym.py:574-605).  out [N,B,13]. */
 int pbhc_sim_fk(const PbhcSkeleton* skel, const float* root_states, const float* dof_pos, const float* dof_vel,
                 int dof_stride, int n, float* out_body_state, void* stream);
+/* Test-only: the same chain for every body INCLUDING the extended ones (motion_tracking.py:619-643), out [N,Bx,13], by method 0 — the walk
+ * pbhc_sim_fk runs — or 1 — the pointer-jumping form the fused step runs for robots of <= 32 bodies (csrc/pbhc_env_step.h: fk_jump_wave).
+ * dof_pos / dof_vel [N,D] dense. */
+int pbhc_debug_fk(const PbhcSkeleton* skel, const float* root_states, const float* dof_pos, const float* dof_vel, int n, int method,
+                  float* out_body_state_ext, void* stream);
 
 /* Env object: owns the device copy of the config, the globals and the reduction scratch. */
 /* `globals`: caller-owned device double[PBHC_NUM_GLOBALS] (see enum PbhcGlobal), initialised by the caller. */

@@ -90,7 +90,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
            "pbhc_linear_act_fwd", "pbhc_env_config_lds_bytes", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_gather_rows", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
-           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule"]
+           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule", "pbhc_debug_fk"]
 
 
 class PbhcError(RuntimeError):
@@ -114,6 +114,7 @@ def _load():
     lib.pbhc_motion_build_batch.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp]
     lib.pbhc_motion_state.argtypes = [C.POINTER(PbhcMotionTable), i, i, vp, vp, vp, i, vp, vp]
     lib.pbhc_sim_fk.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp]
+    lib.pbhc_debug_fk.argtypes = [C.POINTER(PbhcSkeleton), vp, vp, vp, i, i, vp, vp]
     lib.pbhc_env_create.argtypes = [C.POINTER(PbhcEnvConfig), C.POINTER(PbhcMotionTable), vp, C.POINTER(vp)]
     lib.pbhc_env_destroy.argtypes = [vp]
     lib.pbhc_env_destroy.restype = None

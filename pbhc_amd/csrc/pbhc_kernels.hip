@@ -566,6 +566,56 @@ int pbhc_sim_fk(const PbhcSkeleton* skel, const float* root_states, const float*
   return PBHC_OK;
 }
 
+// Test-only: the rigid-body state of every body INCLUDING the extended ones by either form of the chain — method 0 the walk (fk_walk, what
+// pbhc_sim_fk runs), 1 pointer jumping (fk_jump_wave, what the step kernel runs for robots of <= 32 bodies) — on any skeleton: random trees of
+// every depth class (1..4 rounds) in tests/test_gpu_fk.py, where the envs' config-driven tests only reach the G1's three rounds.
+__global__ __launch_bounds__(PBHC_G* PBHC_EPB) void k_debug_fk(PbhcSkeleton sk, const float* __restrict__ root_states, const float* __restrict__ dof_pos,
+                                                              const float* __restrict__ dof_vel, int n, int method, float* __restrict__ out) {
+  __shared__ float sm[PBHC_EPB][16 + 64 + PBHC_MAX_BODIES * 17];
+  __shared__ float skc[SKC_WORDS];
+  const int lane = threadIdx.x & (PBHC_G - 1), le = threadIdx.x / PBHC_G, env = blockIdx.x * PBHC_EPB + le;
+  const bool valid = env < n;
+  float* root = sm[le];
+  float *q = root + 16, *qd = q + 32, *bp = qd + 32, *bq = bp + 3 * PBHC_MAX_BODIES, *bv = bq + 4 * PBHC_MAX_BODIES, *bw = bv + 3 * PBHC_MAX_BODIES;
+  float* relq = bw + 3 * PBHC_MAX_BODIES;
+  stage_skeleton(sk, skc);
+  if (valid) {
+    if (lane < 13) root[lane] = root_states[(size_t)env * 13 + lane];
+    for (int d = lane; d < sk.num_dof; d += PBHC_G) { q[d] = dof_pos[(size_t)env * sk.num_dof + d]; qd[d] = dof_vel[(size_t)env * sk.num_dof + d]; }
+  }
+  __syncthreads();
+  const int B = sk.num_bodies, Bx = sk.num_bodies_ext;
+  if (method == 0) {
+    fk_walk(skc, B, Bx, lane, valid, root, q, qd, relq, bp, bq, bv, bw);
+  } else {
+    float4 kr[5];
+    const int lb = min(lane, Bx - 1);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) kr[u] = make_float4(skj_word(sk, SKJ_W * lb + 4 * u), skj_word(sk, SKJ_W * lb + 4 * u + 1), skj_word(sk, SKJ_W * lb + 4 * u + 2), skj_word(sk, SKJ_W * lb + 4 * u + 3));
+    fk_jump_wave(kr, skel_fk_rounds(sk.max_depth), B, Bx, lane, valid, root, q, qd, bp, bq, bv, bw);
+    __syncthreads();
+  }
+  if (valid)
+    for (int b = lane; b < Bx; b += PBHC_G) {
+      float* o = out + ((size_t)env * Bx + b) * 13;
+      st3(o, ld3(bp + 3 * b)); st4(o + 3, ld4(bq + 4 * b)); st3(o + 7, ld3(bv + 3 * b)); st3(o + 10, ld3(bw + 3 * b));
+    }
+}
+extern "C" int pbhc_debug_fk(const PbhcSkeleton* skel, const float* root_states, const float* dof_pos, const float* dof_vel, int n, int method, float* out, void* stream) {
+  ARG_CHECK(skel);
+  int rc = check_skel(skel);
+  if (rc) return rc;
+  ARG_CHECK(root_states && dof_pos && dof_vel && out && n >= 0 && (method == 0 || method == 1));
+  if (method == 1 && !skel_fk_jump(skel->num_bodies_ext, skel->max_depth)) {
+    snprintf(g_err, sizeof(g_err), "pbhc_debug_fk: pointer jumping needs <= %d bodies and a chain of <= 15 joints", PBHC_G);
+    return PBHC_EINVAL;
+  }
+  if (n == 0) return PBHC_OK;
+  hipLaunchKernelGGL(k_debug_fk, dim3((n + PBHC_EPB - 1) / PBHC_EPB), dim3(PBHC_G * PBHC_EPB), 0, (hipStream_t)stream, *skel, root_states, dof_pos, dof_vel, n, method, out);
+  HIP_CHECK(hipGetLastError());
+  return PBHC_OK;
+}
+
 // Validation + the members pbhc_env_create derives (term_src, sum_col_term, whether the compact observation maps fit in LDS): host
 // arithmetic only, so that a specialised kernel can be generated for a config without a device at hand (pbhc_env_config_finalize).
 static int finalize_config(const PbhcEnvConfig* cfg, PbhcEnvConfig* fin, int* lds_stride, size_t* lds_bytes) {
