@@ -51,25 +51,26 @@ if hasattr(dbg, "pbhc_debug_read_stamps"):
     st = (C.c_ulonglong * 64)()
     dbg.pbhc_debug_read_stamps(st, 64)
     # role A (thread 0 of workgroup 0): stamps 0..12 at its phase boundaries; role B (thread 128): stamps 32+1..32+5
-    namesA = ["loads + constants -> LDS", "FK chain", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features",
-              "obs rows of role 0 + wait bar3", "(late rows of a reset env)", "J writeback", "partials"]
+    namesA = ["loads issued (frame, constants)", "wait for the frame + rigid-body chain + root scalars", "wait bar1", "E body diffs + termination", "wait bar2", "F reward", "G reset", "H features + J write-back",
+              "rows of role 0 (none: hist_b) + wait bar3", "(late rows of a reset env)", "-", "partials"]
     tot = st[12] - st[0]
     print("  role A (dynamics chain):")
     for i, n in enumerate(namesA):
         dd = st[i + 1] - st[i]
-        print(f"    {n:28s} {dd:8d} cyc  {100.0 * dd / tot:5.1f}%")
+        print(f"    {n:56s} {dd:8d} cyc  {100.0 * dd / tot:5.1f}%")
     print(f"    total {tot} cycles")
     if st[20]:
-        print(f"    inside FK: relative joint quaternions (one sincos + quat_mul per lane) {st[20] - st[1]}, chain walk {st[21] - st[20]}, stores {st[22] - st[21]}, per-env scalars {st[2] - st[22]}")
+        print(f"    inside the chain: wait for the frame + segment of every body (one sincos + quaternion product per lane) {st[20] - st[1]}, pointer-jumping rounds (walk: the chain walk) {st[21] - st[20]}, "
+              f"extended bodies + stores {st[22] - st[21]}, root-state scalars + the Philox noise base {st[2] - st[22]}")
         print(f"    inside E: body loop {st[23] - st[3]}, reductions {st[24] - st[23]}, lane-0 means + termination {st[4] - st[24]}")
         print(f"    inside F: exps {st[25] - st[5]}, term values {st[26] - st[25]}, episode sums {st[27] - st[26]}, reward row + err {st[6] - st[27]}")
-    namesB = ["C scalars (from the start)", "D reference frame", "history -> LDS (then bar1)", "torques + joint-space sums + maps (from bar1)",
-              "outputs + obs rows of role 1 (from bar2)"]
+    namesB = ["prologue: every load back, contacts in LDS", "D reference frame (lerp / slerp of the two rows)", "history request, pre-physics step + torques, reference time (then bar1)",
+              "joint-space sums, foot norms, no-reset features (from bar1)", "history -> LDS, reset draws, every observation row (from bar2)"]
     refs = [st[0], st[32 + 1], st[32 + 2], st[3], st[5]]
     print("  role B (reference / observations):")
     for i, n in enumerate(namesB):
         dd = st[32 + i + 1] - refs[i]
-        print(f"    {n:40s} ends {st[32 + i + 1] - st[0]:8d} cyc after start  (+{dd})")
+        print(f"    {n:80s} ends {st[32 + i + 1] - st[0]:8d} cyc after start  (+{dd})")
 
     if st[32 + 6]:
         print(f"  role B prologue detail (cycles after start): wave entered its role {st[32 + 9] - st[0]}, tensor addresses in SGPRs {st[32 + 10] - st[0]}, independent loads issued {st[32 + 6] - st[0]}, env scalars back + rows issued {st[32 + 7] - st[0]}, "
