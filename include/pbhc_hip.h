@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 9
+#define PBHC_ABI_VERSION 10
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -597,6 +597,19 @@ typedef struct PbhcMlpSample {
 } PbhcMlpSample;
 int pbhc_mlp_fwd_sample(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, int M,
                         const PbhcMlpSample* sample, void* stream);
+/* pbhc_mlp_fwd_cat: the same stack on input rows given as up to PBHC_MLP_MAX_SEGS column segments laid side by side — `module(torch.cat([obs,
+ * motion_embedding, latent], -1))` of the general-tracking actor (agent_modules.py:75-84 of the reference) without materialising the concatenation;
+ * sum(width) == dims[0], ld[i] >= width[i] (floats).  y may be NULL when `sample` is given (then the sampling epilogue of pbhc_mlp_fwd_sample runs);
+ * both may be given.  16-byte loads are used when every segment allows them (16-byte aligned base, ld % 4 == 0, inner widths % 4 == 0). */
+#define PBHC_MLP_MAX_SEGS 3
+typedef struct PbhcMlpInput {
+  const float* x[PBHC_MLP_MAX_SEGS];
+  int32_t ld[PBHC_MLP_MAX_SEGS];
+  int32_t width[PBHC_MLP_MAX_SEGS];
+  int32_t nseg;
+} PbhcMlpInput;
+int pbhc_mlp_fwd_cat(const PbhcMlpInput* in, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                     int M, const PbhcMlpSample* sample, void* stream);
 size_t pbhc_mlp_packed_floats(int N, int K);
 int pbhc_mlp_pack(const float* w, int N, int K, float* packed, void* stream);
 size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers);

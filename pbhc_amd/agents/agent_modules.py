@@ -239,11 +239,80 @@ class ConvEncoder(nn.Module):
         self._strides = strides
         self.unfold_gemm = None        # None: unfolded-window GEMMs on the GPU, nn.Conv1d on the CPU (what the deploy exporters trace)
 
-    def forward(self, x):
+    # ---- no-grad forward on the GPU (the rollout: 4 096 rows per control step, inside a captured graph) ------------------------------------
+    def _infer_ok(self, x):
+        from . import fused_mlp
+
+        act_id = fused_mlp._ACT_ID.get(type(self._act), 0)
+        return (fused_mlp.FUSED_GEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and self.input_dim >= 4
+                and act_id in (1, 2, 3) and not (act_id == 1 and self._act.alpha != 1.0)
+                and all(self.conv_module[2 * i].bias is not None for i in range(len(self._strides))) and self.encoder[0].bias is not None)
+
+    def _layout_weights(self):
+        """the conv weights as [O, (k, C)] (a window of the time-major activations is k*C contiguous floats) and the output layer's columns in
+        (l, c) order (it then reads the last conv layer's [B, L, O] rows as they lie, no transpose pass)"""
+        ws = [self.conv_module[2 * i].weight.permute(0, 2, 1).reshape(self.conv_module[2 * i].out_channels, -1) for i in range(len(self._strides))]
+        O = self.conv_module[2 * (len(self._strides) - 1)].out_channels
+        wo = self.output_layer.weight
+        ws.append(wo.view(wo.shape[0], O, wo.shape[1] // O).permute(0, 2, 1).reshape(wo.shape[0], -1))
+        return ws
+
+    def prepare_inference(self):
+        """refresh the re-laid-out weight copies IN PLACE (fixed addresses: the rollout's captured graph reads them) — the weights are constant
+        over a rollout, so the agent calls this once before its loop and `release_inference()` after it; without it every forward re-lays them out"""
+        with torch.no_grad():
+            ws = self._layout_weights()
+            cache = self.__dict__.get("_infer_w")
+            if cache is None or any(c.shape != w.shape or c.device != w.device for c, w in zip(cache, ws)):
+                self._infer_w = [w.contiguous().clone() for w in ws]
+            else:
+                for c, w in zip(cache, ws):
+                    c.copy_(w)
+        self._infer_ready = True
+
+    def release_inference(self):
+        self._infer_ready = False
+
+    def _forward_infer(self, x, B, out=None):
+        """per-step Linear + ReLU as ONE strided-batched launch over the T time steps straight from the (row-padded) observation slab, each
+        Conv1d layer as one strided-batched launch with bias + activation in its epilogue, the output Linear on the [B, L*O] rows as they lie:
+        4 launches (the generic no-grad path: slab copy, GEMM, unfold copy, GEMM, activation, ... 12)"""
+        from .. import _lib
+        from . import fused_mlp
+
+        lib, st = _lib.lib(), _lib.current_stream()
+        T, d, H = self.time_steps, self.input_dim, self.hidden_dim
+        lin = self.encoder[0]
+        ws = self._infer_w if self.__dict__.get("_infer_ready", False) else [w.contiguous() for w in self._layout_weights()]
+        h = torch.empty(B, T, H, device=x.device)
+        _lib.check(lib.pbhc_linear_act_fwd_strided(x.data_ptr(), x.stride(0), d, lin.weight.data_ptr(), lin.bias.data_ptr(), h.data_ptr(), None, T * H, H, T,
+                                                   B, H, d, 3, st), "pbhc_linear_act_fwd_strided")
+        act_id = fused_mlp._ACT_ID[type(self._act)]
+        for i, s in enumerate(self._strides):
+            conv = self.conv_module[2 * i]
+            k, Tc, Cin, O = conv.kernel_size[0], h.shape[1], h.shape[2], conv.out_channels
+            L = (Tc - k) // s + 1
+            nxt = torch.empty(B, L, O, device=x.device)
+            _lib.check(lib.pbhc_linear_act_fwd_strided(h.data_ptr(), Tc * Cin, s * Cin, ws[i].data_ptr(), conv.bias.data_ptr(), nxt.data_ptr(), None, L * O, O, L,
+                                                       B, O, k * Cin, act_id, st), "pbhc_linear_act_fwd_strided")
+            h = nxt
+        if out is not None:
+            return torch.addmm(self.output_layer.bias, h.view(B, -1), ws[-1].t(), out=out)
+        return F.linear(h.view(B, -1), ws[-1], self.output_layer.bias)
+
+    def forward(self, x, out=None):
+        """out (no-grad callers only): a [B, output_dim] tensor the result is written to (the rollout keeps every step's motion embedding)"""
+        if out is not None:
+            assert not torch.is_grad_enabled()
+            if not (x.is_cuda and self._infer_ok(x)):
+                return out.copy_(self.forward(x))
+            return self._forward_infer(x, x.shape[0], out)
         B = x.shape[0] if x.dim() == 2 else x.numel() // (self.input_dim * self.time_steps)
         if not (x.is_cuda if self.unfold_gemm is None else self.unfold_gemm):
             h = self.encoder(x.reshape(-1, self.input_dim)).view(B, self.time_steps, self.hidden_dim).permute(0, 2, 1)
             return self.output_layer(self.conv_module(h).flatten(start_dim=1))
+        if not torch.is_grad_enabled() and self._infer_ok(x):
+            return self._forward_infer(x, B)
         x = _linear_relu(x.reshape(-1, self.input_dim), self.encoder[0]).view(B, self.time_steps, self.hidden_dim)   # [B, T, H]: x.view(-1, input_dim) chunks, sic
         for i, s in enumerate(self._strides):
             conv = self.conv_module[2 * i]

@@ -420,6 +420,38 @@ def forward_sample(seq, x, std, seed, counter, counter_offset, actions, action_m
     return True
 
 
+def forward_cat_inference(seq, xs, sample=None):
+    """No-grad forward of a packed stack on `torch.cat(xs, -1)` WITHOUT the concatenation (`pbhc_mlp_fwd_cat`: the stack kernel stages its 16
+    input rows from up to three column segments — observation slab | encoder outputs), optionally with the rollout's sampling in the last
+    layer's epilogue (`sample`: dict(std, seed, counter, counter_offset, actions, action_mean, action_sigma, logp), as forward_sample).
+    Returns the output [B, out] (None with `sample`: the mean lands in action_mean), or False — nothing launched — where it does not apply."""
+    c = getattr(seq, "_pbhc_stack", None)
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    B = xs[0].shape[0]
+    if not (c is not None and c["valid"] and B <= _STACK_MAX_ROWS and 1 <= len(xs) <= _lib.K["PBHC_MLP_MAX_SEGS"]
+            and all(x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == B and x.dtype == torch.float32 and x.is_cuda for x in xs)
+            and sum(x.shape[1] for x in xs) == lin[0].in_features):
+        return False
+    if sample is not None and not (lin[-1].out_features <= 32 and all(sample[k].is_contiguous() for k in ("actions", "action_mean", "action_sigma", "logp"))):
+        return False
+    inp = _lib.PbhcMlpInput()
+    for i, x in enumerate(xs):
+        inp.x[i], inp.ld[i], inp.width[i] = x.data_ptr(), x.stride(0), x.shape[1]
+    inp.nseg = len(xs)
+    act = _ACT_ID[type(seq[1])] if len(lin) > 1 else 0
+    smp_ref, out = None, None
+    if sample is not None:
+        smp = _lib.PbhcMlpSample()
+        smp.std, smp.counter, smp.seed, smp.counter_offset = sample["std"].data_ptr(), sample["counter"], int(sample["seed"]), int(sample["counter_offset"])
+        smp.actions, smp.action_mean, smp.action_sigma, smp.logp = (sample[k].data_ptr() for k in ("actions", "action_mean", "action_sigma", "logp"))
+        smp_ref = C.byref(smp)
+    else:
+        out = torch.empty(B, lin[-1].out_features, device=xs[0].device)
+    _lib.check(_lib.lib().pbhc_mlp_fwd_cat(C.byref(inp), c["w"], c["b"], c["dims"], len(lin), act, None if out is None else out.data_ptr(),
+                                           0 if out is None else out.stride(0), B, smp_ref, _lib.current_stream()), "pbhc_mlp_fwd_cat")
+    return out if sample is None else None
+
+
 def forward(seq, x):
     """seq: nn.Sequential of Linear / activation; x [B, in]."""
     params = []

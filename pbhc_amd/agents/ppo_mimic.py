@@ -275,7 +275,7 @@ class PPO:
         for k, d in self.algo_obs_dim_dict.items():
             w = d * S if k in ("future_motion_targets", "teacher_future_motion_targets") else d      # ppo_mimic.py:206-216
             self._obs_width[k] = w
-            st.register_key(k, shape=(w,), dtype=torch.float, pad_rows=True)
+            st.register_key(k, shape=(w,), dtype=torch.float, pad_rows=True, tail_slab=True)
         st.register_key("actions", shape=(self.num_act,), dtype=torch.float)
         st.register_key("rewards", shape=(self.num_rew_fn,), dtype=torch.float)
         st.register_key("dones", shape=(1,), dtype=torch.bool)
@@ -289,7 +289,7 @@ class PPO:
             st.register_key("teacher_actions", shape=(self.num_act,), dtype=torch.float)
         T, N = self.num_steps_per_env, self.env.num_envs
         self._gae_stats = torch.zeros(2 * ((T * N + 255) // 256) + 4, dtype=torch.float64, device=self.device)
-        self._last_obs = {k: torch.zeros(N, _lib.padded_width(w), device=self.device)[:, :w] for k, w in self._obs_width.items()}
+        self._last_obs = {k: st.with_tail(k)[T] for k in self._obs_width}      # the observations after the last step: slab T of the same buffers
         self._sample_seed = pdist.rank_seed(int(torch.randint(0, 2**62, (1,)).item()))
         if not hasattr(self.env, "globals") or not hasattr(self.env, "set_obs_outputs"):
             raise _lib.PbhcError("pbhc_amd PPO drives the fused pbhc_amd env (needs env.globals / env.set_obs_outputs)")
@@ -461,14 +461,55 @@ class PPO:
                 getattr(st, k)[0].copy_(obs_dict[k])
             mode = bool(self.hist_encoding)                    # the captured forward depends on the latent source
             a = self.alg.actor
-            stacks = [m.module for m in (a.actor_module, self.alg.critic, a.priv_encoder) if m is not None and isinstance(m, BaseModule) and m._fused]
+            split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
+            # The critic's values feed only the time-out bootstrap and GAE, both after the rollout: evaluated ONCE over all T + 1 slabs
+            # (whole-chip GEMM tiles) on the motion embeddings the per-step forwards left in `_emb_buf`, as MHPPO does (PBHC_CRITIC_BATCHED=0:
+            # the critic stack inside every control step)
+            batched = split and os.environ.get("PBHC_CRITIC_BATCHED", "1") != "0"
+            nets = (a.actor_module, a.priv_encoder) if batched else (a.actor_module, self.alg.critic, a.priv_encoder)
+            stacks = [m.module for m in nets if m is not None and isinstance(m, BaseModule) and m._fused]
             stacks = [q for q in stacks if os.environ.get("PBHC_STACK_NETS_V2", "1") != "0" and fused_mlp.pack_stack(q)]
+            encoders = [e for e in (a.motion_encoder, a.history_encoder if mode else None) if e is not None and hasattr(e, "prepare_inference")]
+            for e in encoders:
+                e.prepare_inference()                          # weights re-laid-out once per rollout, in place (the captured graph reads them)
+            if batched:
+                E = a.motion_encoder.output_dim
+                if self.__dict__.get("_emb_buf") is None or self._emb_buf.shape != (T + 1, N, E):
+                    self._emb_buf = torch.zeros(T + 1, N, E, device=self.device)
+                    self._time_outs = torch.zeros(T, N, 1, dtype=torch.bool, device=self.device)
+            fuse_sample = False
             try:
-                eager_fwd = lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2]
+                if batched:
+                    # the actor stack reads [actor_obs | motion embedding | latent] as three column segments (no concatenated copy) and samples in
+                    # its last epilogue, keyed by a snapshot of the step counter + the step index: the keys pbhc_policy_sample forms from the live
+                    # counter, without waiting for the previous step's reduction (as MHPPO; PBHC_FUSED_SAMPLE=0: the separate sampling kernel)
+                    a_seq = a.actor_module.module if isinstance(a.actor_module, BaseModule) else None
+                    cat_ok = a_seq is not None and any(q is a_seq for q in stacks)
+                    fuse_sample = cat_ok and os.environ.get("PBHC_FUSED_SAMPLE", "1") != "0"
+                    if fuse_sample:
+                        if self.__dict__.get("_ctr0") is None:
+                            self._ctr0 = torch.zeros(1, dtype=torch.float64, device=self.device)
+                        env.wait_finalize()
+                        self._ctr0.copy_(env.globals[K["PBHC_G_STEP_COUNTER"]:K["PBHC_G_STEP_COUNTER"] + 1])
+
+                    def eager_fwd(t):
+                        b = {k: getattr(st, k)[t] for k in keys}
+                        emb = a.motion_encoder(b["future_motion_targets"], out=self._emb_buf[t])
+                        latent = a.history_encoding(b["prop_history"]) if mode else a.priv_encoding(b["priv_obs"])
+                        xs = [b["actor_obs"], emb, latent]
+                        if fuse_sample:
+                            smp = dict(std=sigma, seed=self._sample_seed, counter=self._ctr0.data_ptr(), counter_offset=t, actions=st.actions[t],
+                                       action_mean=st.action_mean[t], action_sigma=st.action_sigma[t], logp=st.actions_log_prob[t])
+                            if fused_mlp.forward_cat_inference(a_seq, xs, sample=smp) is False:
+                                raise _lib.PbhcError("pbhc_mlp_fwd_cat does not apply to this policy (PBHC_FUSED_SAMPLE=0)")
+                            return st.action_mean[t], None
+                        mu = fused_mlp.forward_cat_inference(a_seq, xs) if cat_ok else False
+                        return (a.actor_module(torch.cat(xs, dim=-1)) if mu is False else mu), None
+                else:
+                    eager_fwd = lambda t: self._forward({k: getattr(st, k)[t] for k in keys}, mode)[:2]
                 # the dependent chain of a control step is env step -> policy forward -> sampling -> env step; the env step's one-workgroup
                 # reduction and the bootstrap / episode-statistics kernel run next to the policy forward on a branch stream (joined before the
                 # sampling kernel, which reads the step counter the reduction advances)
-                split = os.environ.get("PBHC_ROLLOUT_SPLIT", "1") != "0" and hasattr(env, "set_finalize_stream")
                 cur = torch.cuda.current_stream()
                 br = None
                 if split:
@@ -477,11 +518,12 @@ class PPO:
                     env.set_finalize_stream(br)
                 post_done = [self.__dict__.setdefault("_post_done", torch.cuda.Event())]
                 sc = self.__dict__.get("_step_ptrs")
-                if sc is None or sc[0] is not st:
+                if sc is None or sc[0] is not st or sc[2] != batched:
                     P = lambda x: x.data_ptr()
-                    sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t]), P(st.values[t])),
-                                    post=(P(st.rewards[t]), P(st.dones[t])), values=P(st.values[t]), act={"actions": st.actions[t]},
-                                    obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)])
+                    sc = (st, [dict(sample=(P(st.actions[t]), P(st.action_mean[t]), P(st.action_sigma[t]), P(st.actions_log_prob[t]), None if batched else P(st.values[t])),
+                                    post=(P(st.rewards[t]), P(st.dones[t])), values=None if batched else P(st.values[t]),
+                                    tout=P(self._time_outs[t]) if batched else None, act={"actions": st.actions[t]},
+                                    obs_out={k: getattr(st, k)[t + 1] for k in keys} if t + 1 < T else self._last_obs) for t in range(T)], batched)
                     self._step_ptrs = sc
                 steps = sc[1]
                 sum_p, len_p, stat_p, gamma = self.cur_reward_sum.data_ptr(), self.cur_episode_length.data_ptr(), self._ep_stats.data_ptr(), float(self.gamma)
@@ -496,13 +538,15 @@ class PPO:
                         if split and t > 0:
                             cur.wait_event(post_done[0])
                             env.finalize_joined()
-                        _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), value.data_ptr(), N, A, R, self._sample_seed, counter, *sp["sample"], stream),
-                                   "pbhc_policy_sample")
+                        if not fuse_sample:
+                            _lib.check(lib.pbhc_policy_sample(mu.data_ptr(), sigma.data_ptr(), None if batched else value.data_ptr(), N, A, R, self._sample_seed, counter,
+                                                              *sp["sample"], stream), "pbhc_policy_sample")
                         env.set_obs_outputs(sp["obs_out"])
                         nxt, rewards, dones, infos = env.step(sp["act"])
                         ps = br.cuda_stream if split else stream
-                        _lib.check(lib.pbhc_rollout_post(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R, gamma, *sp["post"],
-                                                         sum_p, len_p, stat_p, ps), "pbhc_rollout_post")
+                        # (batched critic: values == NULL — the time-out bootstrap is added after the loop — and the step's time-out flags are kept)
+                        _lib.check(lib.pbhc_rollout_post2(rewards.data_ptr(), sp["values"], dones.data_ptr(), infos["time_outs"].data_ptr(), N, R, gamma, *sp["post"],
+                                                          sum_p, len_p, stat_p, sp["tout"], ps), "pbhc_rollout_post2")
                         if split:
                             post_done[0].record(br)
                     if split:
@@ -513,7 +557,7 @@ class PPO:
                 ran = False
                 if graph_ok:
                     env.simulator.use_device_cursor()
-                    key = (id(st), env._io_epoch, env.simulator.replay_version, bool(getattr(env, "is_specialised", False)), N, T, mode, bool(stacks))
+                    key = (id(st), env._io_epoch, env.simulator.replay_version, bool(getattr(env, "is_specialised", False)), N, T, mode, bool(stacks), batched, fuse_sample)
                     gc = self.__dict__.get("_rollout_graph")
                     if gc is None or gc[0] != key:
                         gc = MHPPO._capture_rollout(self, key, run_loop, eager_fwd, env, post_done, T)
@@ -523,24 +567,38 @@ class PPO:
                         ran = True
                 self._rollout_used_graph = ran
                 if not ran:
-                    run_loop(cur, policy_forward_graphs(self, eager_fwd, key=(mode, bool(stacks))))      # (one captured forward per step)
+                    run_loop(cur, policy_forward_graphs(self, eager_fwd, key=(mode, bool(stacks), batched, fuse_sample)))      # (one captured forward per step)
                 if split:
                     env.set_finalize_stream(None)
             finally:
                 for q in stacks:
                     fused_mlp.release_stack(q)
+                for e in encoders:
+                    e.release_inference()
+            last_values = None
+            if batched:
+                # ppo_mimic.py:384-386, 425-431 for all steps at once: values of every slab + the bootstrap values of GAE (slab T: the
+                # observations after the last step) from one launch set, then rewards += gamma * values * time_outs
+                self._emb_buf[T].copy_(a.motion_encoding(self._last_obs["future_motion_targets"]))
+                rows = lambda k: st.with_tail(k).flatten(0, 1)
+                vals = self.alg.critic(torch.cat([rows("actor_obs"), rows("priv_obs"), self._emb_buf.flatten(0, 1)], dim=-1)).view(T + 1, N, R)
+                st.values.copy_(vals[:T])
+                st.rewards.addcmul_(st.values, self._time_outs.to(torch.float32), value=float(self.gamma))
+                last_values = vals[T]
             st.step = T
             self._rollouts_done = self.__dict__.get("_rollouts_done", 0) + 1
             if self._dp and self._stat_mode == "rollout":
                 self.env.sync_globals()                # sigma / curricula / log means: the mean over the ranks, once per rollout
             self._timer.split()
-            self._compute_returns(self._last_obs)
+            self._compute_returns(self._last_obs, last_values=last_values)
         return self._last_obs
 
-    def _compute_returns(self, last_obs_dict):
+    def _compute_returns(self, last_obs_dict, last_values=None):
         """ppo_mimic.py:443-491 in one HIP pass (scalar reward: R = 1, normalisation over all [T,N] entries)."""
         st = self.storage
-        last_values = self.alg.evaluate(last_obs_dict).detach().contiguous()
+        if last_values is None:
+            last_values = self.alg.evaluate(last_obs_dict).detach()
+        last_values = last_values.contiguous()
         T, N, R = self.num_steps_per_env, self.env.num_envs, self.num_rew_fn
         adv = st.advantages
         _lib.check(_lib.lib().pbhc_gae(st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(), last_values.data_ptr(), T, N, R,

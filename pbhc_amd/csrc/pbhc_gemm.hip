@@ -283,6 +283,15 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
   Cout += (size_t)blockIdx.y * c_batch;
   if (Pre) Pre += (size_t)blockIdx.y * c_batch;
   const long long dbg_c0 = (dbg & 8) ? clock64() : 0, dbg_w0 = (dbg & 8) ? wall_clock64() : 0;
+  if (dbg & 0xE0) {
+    // diagnosis (tools/gemm_ablation.py): de-phase the co-resident workgroups of the first round — the second / third workgroup of a CU starts
+    // 1 x / 2 x ((dbg >> 5) * 4 us) late — to see what the launch pays for every tile's epilogue falling into the same moment
+    const int type = (blockIdx.x >> 8) % 3;
+    if (blockIdx.x < 768 && type) {
+      const long long t0 = wall_clock64(), d = (long long)type * ((dbg >> 5) & 7) * 400;      // wall clock: 100 MHz
+      while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   static_assert(WM * WN == 4, "four waves");
   static_assert(BK == 16 || BK == 32, "BK");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(act, sv[p][q]);
       }
-      if (ok) {
+      if (ok && !((dbg & 2) && v[0] != 12345.678f)) {      // (dbg 2: the epilogue without its global stores)
         float* cp = Cout + (size_t)row * ldc + col;
         if (vec) reinterpret_cast<F4U*>(cp)->v = v;
         else {

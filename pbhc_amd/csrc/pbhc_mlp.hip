@@ -47,8 +47,11 @@ struct MlpArgs {
   const float* w[PBHC_MLP_MAX_LAYERS];
   const float* b[PBHC_MLP_MAX_LAYERS];
   int dim[PBHC_MLP_MAX_LAYERS + 1];
-  int nl, act, M, ldx, ldy, pitch0, pitch1;                // pitch0 / pitch1: row pitch (floats) of the even / odd activation image
-  const float* x;
+  int nl, act, M, ldy, pitch0, pitch1;                     // pitch0 / pitch1: row pitch (floats) of the even / odd activation image
+  // the input rows: up to three column segments laid side by side (`torch.cat([...], -1)` without the copy: observation slab | encoder outputs)
+  const float* xs[PBHC_MLP_MAX_SEGS];
+  int xw[PBHC_MLP_MAX_SEGS], xld[PBHC_MLP_MAX_SEGS];
+  int nseg, vec;                                           // vec: every segment can be read in 16-byte pieces (checked on the host)
   float* y;
   // optional sampling epilogue of the last layer (the rollout's policy: a ~ Normal(mu, std), pbhc_policy_sample's arithmetic and Philox keys)
   const float* std;
@@ -166,14 +169,25 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs a) {
   {
     // the 16 input rows -> image 0, zero-padded to the 16-wide k-step (rows past M: the last row again, never stored)
     const int K = a.dim[0], P = a.pitch0, Kp = (K + 15) & ~15;
-    const bool vec = (a.ldx & 3) == 0 && (((uintptr_t)a.x) & 15) == 0 && a.ldx >= ((K + 3) & ~3);
-    if (vec) {
+    // column c of the concatenated row -> (segment, column inside it); segments before the last are whole 16-byte pieces on the vector path
+    auto seg_of = [&](int c, int& cc) {
+      int sg = 0;
+      cc = c;
+      if (a.nseg > 1 && cc >= a.xw[0]) { cc -= a.xw[0]; sg = 1; }
+      if (a.nseg > 2 && sg == 1 && cc >= a.xw[1]) { cc -= a.xw[1]; sg = 2; }
+      return sg;
+    };
+    if (a.vec) {
       const int cpr = Kp >> 2;                             // 16-byte chunks per row
       for (int i = threadIdx.x; i < MLP_ROWS * cpr; i += MLP_T) {
         const int r = i / cpr, c = (i - r * cpr) << 2;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < K) {
-          v = *reinterpret_cast<const f32x4*>(a.x + (size_t)min(row0 + r, a.M - 1) * a.ldx + c);      // may cover row padding: masked below
+          int cc;
+          const int sg = seg_of(c, cc);
+          const float* base = sg == 0 ? a.xs[0] : sg == 1 ? a.xs[1] : a.xs[2];
+          const int ld = sg == 0 ? a.xld[0] : sg == 1 ? a.xld[1] : a.xld[2];
+          v = *reinterpret_cast<const f32x4*>(base + (size_t)min(row0 + r, a.M - 1) * ld + cc);      // may cover row padding: masked below
           if (c + 1 >= K) v[1] = 0.f;
           if (c + 2 >= K) v[2] = 0.f;
           if (c + 3 >= K) v[3] = 0.f;
@@ -183,7 +197,15 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs a) {
     } else {
       for (int i = threadIdx.x; i < MLP_ROWS * Kp; i += MLP_T) {
         const int r = i / Kp, c = i - r * Kp;
-        img0[r * P + c] = c < K ? a.x[(size_t)min(row0 + r, a.M - 1) * a.ldx + c] : 0.0f;
+        float v = 0.0f;
+        if (c < K) {
+          int cc;
+          const int sg = seg_of(c, cc);
+          const float* base = sg == 0 ? a.xs[0] : sg == 1 ? a.xs[1] : a.xs[2];
+          const int ld = sg == 0 ? a.xld[0] : sg == 1 ? a.xld[1] : a.xld[2];
+          v = base[(size_t)min(row0 + r, a.M - 1) * ld + cc];
+        }
+        img0[r * P + c] = v;
       }
     }
   }
@@ -255,11 +277,28 @@ size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers) {
   return (size_t)MLP_ROWS * (size_t)(p0 + p1) * sizeof(float);
 }
 
-static int mlp_launch(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+static int mlp_launch(const PbhcMlpInput* in, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
                       int M, const PbhcMlpSample* smp, void* stream) {
-  MLP_ARG(x && weights && biases && dims && (y || smp) && M >= 1 && num_layers >= 1 && num_layers <= PBHC_MLP_MAX_LAYERS && act >= 0 && act <= 3);
-  MLP_ARG(ldx >= dims[0] && (!y || ldy >= dims[num_layers]) && (((uintptr_t)x) & 3) == 0);
+  MLP_ARG(in && weights && biases && dims && (y || smp) && M >= 1 && num_layers >= 1 && num_layers <= PBHC_MLP_MAX_LAYERS && act >= 0 && act <= 3);
+  MLP_ARG(in->nseg >= 1 && in->nseg <= PBHC_MLP_MAX_SEGS && (!y || ldy >= dims[num_layers]));
   MlpArgs a;
+  {
+    int total = 0;
+    a.vec = 1;
+    for (int sgi = 0; sgi < PBHC_MLP_MAX_SEGS; ++sgi) {
+      const bool used = sgi < in->nseg;
+      a.xs[sgi] = used ? in->x[sgi] : in->x[0];
+      a.xw[sgi] = used ? in->width[sgi] : 0;
+      a.xld[sgi] = used ? in->ld[sgi] : 0;
+      if (!used) continue;
+      MLP_ARG(in->x[sgi] && in->width[sgi] >= 1 && in->ld[sgi] >= in->width[sgi] && (((uintptr_t)in->x[sgi]) & 3) == 0);
+      total += in->width[sgi];
+      // 16-byte pieces: aligned base and pitch, the piece that straddles the segment's end stays inside its row, inner segments end on a piece
+      if ((in->ld[sgi] & 3) || (((uintptr_t)in->x[sgi]) & 15) || in->ld[sgi] < ((in->width[sgi] + 3) & ~3) || (sgi + 1 < in->nseg && (in->width[sgi] & 3))) a.vec = 0;
+    }
+    MLP_ARG(total == dims[0]);
+    a.nseg = in->nseg;
+  }
   a.std = nullptr; a.counter = nullptr; a.seed = 0; a.counter_offset = 0;
   a.actions = a.action_mean = a.action_sigma = a.logp = nullptr;
   if (smp) {
@@ -267,7 +306,7 @@ static int mlp_launch(const float* x, int ldx, const float* const* weights, cons
     a.std = smp->std; a.counter = smp->counter; a.seed = smp->seed; a.counter_offset = smp->counter_offset;
     a.actions = smp->actions; a.action_mean = smp->action_mean; a.action_sigma = smp->action_sigma; a.logp = smp->logp;
   }
-  a.nl = num_layers; a.act = act; a.M = M; a.ldx = ldx; a.ldy = ldy; a.x = x; a.y = y;
+  a.nl = num_layers; a.act = act; a.M = M; a.ldy = ldy; a.y = y;
   a.pitch0 = a.pitch1 = 0;
   for (int l = 0; l <= num_layers; ++l) {
     MLP_ARG(dims[l] >= 1 && dims[l] <= 4096);
@@ -299,16 +338,30 @@ static int mlp_launch(const float* x, int ldx, const float* const* weights, cons
   return PBHC_OK;
 }
 
+static PbhcMlpInput one_segment(const float* x, int ldx, const int* dims) {
+  PbhcMlpInput in;
+  for (int i = 0; i < PBHC_MLP_MAX_SEGS; ++i) { in.x[i] = nullptr; in.ld[i] = 0; in.width[i] = 0; }
+  in.x[0] = x; in.ld[0] = ldx; in.width[0] = dims ? dims[0] : 0; in.nseg = 1;
+  return in;
+}
+
 int pbhc_mlp_fwd(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
                  int M, void* stream) {
-  MLP_ARG(y);
-  return mlp_launch(x, ldx, weights, biases, dims, num_layers, act, y, ldy, M, nullptr, stream);
+  MLP_ARG(y && dims);
+  const PbhcMlpInput in = one_segment(x, ldx, dims);
+  return mlp_launch(&in, weights, biases, dims, num_layers, act, y, ldy, M, nullptr, stream);
 }
 
 int pbhc_mlp_fwd_sample(const float* x, int ldx, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, int M,
                         const PbhcMlpSample* sample, void* stream) {
-  MLP_ARG(sample);
-  return mlp_launch(x, ldx, weights, biases, dims, num_layers, act, nullptr, 0, M, sample, stream);
+  MLP_ARG(sample && dims);
+  const PbhcMlpInput in = one_segment(x, ldx, dims);
+  return mlp_launch(&in, weights, biases, dims, num_layers, act, nullptr, 0, M, sample, stream);
+}
+
+int pbhc_mlp_fwd_cat(const PbhcMlpInput* in, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
+                     int M, const PbhcMlpSample* sample, void* stream) {
+  return mlp_launch(in, weights, biases, dims, num_layers, act, y, ldy, M, sample, stream);
 }
 
 }  // extern "C"

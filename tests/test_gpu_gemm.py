@@ -178,6 +178,39 @@ def test_window_conv_strided_batch_matches_conv1d(cfg, act_cls):
         assert a.shape == b.shape and (a - b).abs().max().item() < 3e-5 * max(1.0, a.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [(4096, 20, 58, 60, 128, "SiLU"), (257, 10, 46, 30, 64, "SiLU"), (100, 5, 13, 20, 16, "ReLU"), (33, 20, 7, 60, 32, "ELU")])
+def test_conv_encoder_no_grad_path_matches_conv1d(cfg):
+    """agents/agent_modules.ConvEncoder under no_grad on the GPU (the rollout: per-step Linear as one strided-batched launch straight from the
+    row-padded observation slab, each Conv1d as one launch with its activation, the output Linear on the rows as they lie; with and without
+    the re-laid-out weights prepared) against the module's nn.Conv1d form (encoder_modules.py:22-107) in float64."""
+    from pbhc_amd.agents import agent_modules as am
+
+    B, T, d, H, E, act = cfg
+    torch.manual_seed(B + T + d)
+    enc = am.ConvEncoder({"x": d}, {"input_dim": ["x"], "hidden_dim": H, "output_dim": E, "layer_config": {"type": "Conv1d", "activation": act}}, T).cuda()
+    w = T * d
+    slab = torch.randn(B, (w + 31) // 32 * 32 + 32, device="cuda")
+    x = slab[:, :w]
+    ref = am.ConvEncoder({"x": d}, {"input_dim": ["x"], "hidden_dim": H, "output_dim": E, "layer_config": {"type": "Conv1d", "activation": act}}, T).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in enc.state_dict().items()})
+    ref.unfold_gemm = False
+    want = ref(x.double().cpu())
+    with torch.no_grad():
+        assert enc._infer_ok(x)
+        got = enc(x)
+        enc.prepare_inference()
+        got2 = enc(x)
+        enc.release_inference()
+        into = torch.zeros(3, B, E, device="cuda")
+        assert enc(x, out=into[1]) is not None and torch.equal(into[1], got) and not into[0].any() and not into[2].any()
+    assert torch.equal(got, got2)
+    scale = max(1.0, want.abs().max().item())
+    assert (got.double().cpu() - want).abs().max().item() < 2e-5 * scale
+    with torch.enable_grad():                          # ... and the training path on the same input
+        tr = enc(x.contiguous())
+    assert (tr.detach().double().cpu() - want).abs().max().item() < 2e-5 * scale
+
+
 # whole-stack forward (`pbhc_mlp_fwd`, csrc/pbhc_mlp.hip): (rows, layer widths, x row pitch or 0 for contiguous).  The rollout's actor and
 # critic on padded slabs, ragged rows (tail workgroup), widths that are not multiples of 16 / 4 (k tails, ragged output tiles), one layer
 STACKS = [(4096, [380, 512, 256, 128, 23], 384), (4096, [630, 768, 512, 128, 21], 640), (1000, [380, 512, 256, 128, 23], 0), (37, [630, 768, 512, 128, 21], 0),
@@ -215,6 +248,46 @@ def test_mlp_stack_forward_matches_fp64(stack, act):
     err = (y[:, :dims[-1]].double() - h).abs().max().item()
     assert err < TOL, err
     assert torch.all(y[:, dims[-1]:] == 7.0)
+
+
+@pytest.mark.parametrize("case", [(4096, [272, 128, 64], [288, 128, 64], [464, 768, 512, 256, 29], 2), (100, [13, 7], [13, 9], [20, 33, 5], 1),
+                                  (37, [8, 5, 6], [8, 8, 6], [19, 64, 3], 3), (64, [40], [48], [40, 16, 4], 2)])
+def test_mlp_stack_forward_on_column_segments_equals_the_concatenated_input(case):
+    """`pbhc_mlp_fwd_cat` (the general-tracking actor on [actor_obs | motion embedding | latent], agent_modules.py:75-84 of the reference, without
+    the torch.cat copy): bit-identical to `pbhc_mlp_fwd` on the concatenated rows — on the 16-byte path (aligned segments) and the element path
+    (odd widths / pitches) — and with the sampling epilogue to `pbhc_mlp_fwd_sample`."""
+    from pbhc_amd import _lib
+    from pbhc_amd.agents import fused_mlp
+
+    M, widths, pitches, dims, act = case
+    torch.manual_seed(M + sum(widths))
+    act_mod = {1: nn.ELU, 2: nn.SiLU, 3: nn.ReLU}[act]
+    layers = []
+    for i in range(len(dims) - 1):
+        layers += [nn.Linear(dims[i], dims[i + 1])] + ([act_mod()] if i < len(dims) - 2 else [])
+    seq = nn.Sequential(*layers).cuda()
+    xs = [torch.randn(M, p, device="cuda")[:, :w] for w, p in zip(widths, pitches)]
+    xcat = torch.cat(xs, dim=-1)
+    with torch.no_grad():
+        assert fused_mlp.pack_stack(seq)
+        want = fused_mlp.forward_inference(seq, xcat)
+        got = fused_mlp.forward_cat_inference(seq, xs)
+        assert got is not False and torch.equal(got, want)
+        A = dims[-1]
+        std = torch.rand(A, device="cuda") + 0.1
+        ctr = torch.tensor([41.0], dtype=torch.float64, device="cuda")
+        outs = []
+        for fn in (lambda kw: fused_mlp.forward_sample(seq, xcat, std, 1234567, ctr.data_ptr(), 3, kw["actions"], kw["action_mean"], kw["action_sigma"], kw["logp"]),
+                   lambda kw: fused_mlp.forward_cat_inference(seq, xs, sample=dict(std=std, seed=1234567, counter=ctr.data_ptr(), counter_offset=3, **kw)) is None):
+            kw = dict(actions=torch.zeros(M, A, device="cuda"), action_mean=torch.zeros(M, A, device="cuda"), action_sigma=torch.zeros(M, A, device="cuda"),
+                      logp=torch.zeros(M, 1, device="cuda"))
+            assert fn(kw)
+            outs.append(kw)
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0]["action_mean"], want)
+        fused_mlp.release_stack(seq)
+        assert fused_mlp.forward_cat_inference(seq, xs) is False          # released: nothing launched
 
 
 def test_module_inference_forward_uses_the_stack_kernel_and_matches_layers():

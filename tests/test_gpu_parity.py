@@ -784,9 +784,9 @@ def test_rollout_as_one_graph_equals_the_eager_loop(agent):
     bootstrap kernel; frame index from the device-side cursor): a schedule, not arithmetic — after five rollouts (eager, capture + replay,
     three replays) every buffer, the env's globals / episode sums, the episode statistics, the step counter and the replay cursor are
     bit-identical to the step-by-step loop (mh_ppo.py:270-342, ppo_mimic.py:369-440)."""
-    v1 = agent == "v1"
-    a = _rollouts_with_split(True, agent, batched=v1, fused_sample=True, rollout_graph=True, rollouts=5)
-    b = _rollouts_with_split(True, agent, batched=v1, fused_sample=True, rollout_graph=False, rollouts=5)
+    a = _rollouts_with_split(True, agent, batched=True, fused_sample=True, rollout_graph=True, rollouts=5)
+    b = _rollouts_with_split(True, agent, batched=True, fused_sample=True, rollout_graph=False, rollouts=5)
+    a.pop("_time_outs_seen"); b.pop("_time_outs_seen")
     assert bool(a.pop("_used_graph")) and not bool(b.pop("_used_graph"))
     assert a.pop("_used_graph_each").tolist() == [False, True, True, True, True] and not b.pop("_used_graph_each").any()
     for k in a:
@@ -800,11 +800,12 @@ def test_graph_rollout_update_graph_replay_equals_the_eager_loop(agent):
     pass leaves the gradient buffer zeroed) -> replay of the SAME graph -> ...  Four iterations against the step-by-step loop with the same
     per-iteration permutation: every rollout-buffer key, the flat parameters, both Adam moments, the learning rates, the step counts, the
     env's globals / episode sums and the episode statistics are bit-identical."""
-    kw = dict(batched=agent == "v1", fused_sample=True, rollouts=4, train_between=True)
+    kw = dict(batched=True, fused_sample=True, rollouts=4, train_between=True)
     a = _rollouts_with_split(True, agent, rollout_graph=True, **kw)
     b = _rollouts_with_split(True, agent, rollout_graph=False, **kw)
     assert a.pop("_used_graph_each").tolist() == [False, True, True, True] and not b.pop("_used_graph_each").any()
     a.pop("_used_graph"); b.pop("_used_graph")
+    a.pop("_time_outs_seen"); b.pop("_time_outs_seen")
     assert not torch.equal(a["_pflat"], a["_pflat_start"])           # (the weights do move under the graph)
     for k in a:
         assert torch.equal(a[k], b[k]), k
@@ -824,12 +825,14 @@ def test_graph_rollout_is_recaptured_after_a_new_replay_window():
         assert torch.equal(a[k], b[k]), k
 
 
-def test_rollout_fused_sampling_equals_sampling_kernel():
-    """MHPPO's default rollout samples in the policy kernel's last epilogue (`pbhc_mlp_fwd_sample`, keyed by a snapshot of the step counter +
-    the step index) instead of launching `pbhc_policy_sample` on the live counter: the same Philox keys and arithmetic, so every action — and
-    with it every observation, reward and env state of three rollouts — is bit-identical; the log-prob sums its columns in another order."""
-    a = _rollouts_with_split(True, "v1", batched=True, fused_sample=True)
-    b = _rollouts_with_split(True, "v1", batched=True, fused_sample=False)
+@pytest.mark.parametrize("agent", ["v1", "v2"])
+def test_rollout_fused_sampling_equals_sampling_kernel(agent):
+    """The agents' default rollout samples in the policy kernel's last epilogue (`pbhc_mlp_fwd_sample` / `pbhc_mlp_fwd_cat`, keyed by a snapshot
+    of the step counter + the step index) instead of launching `pbhc_policy_sample` on the live counter: the same Philox keys and arithmetic, so
+    every action — and with it every observation, reward and env state of three rollouts — is bit-identical; the log-prob sums its columns in
+    another order."""
+    a = _rollouts_with_split(True, agent, batched=True, fused_sample=True)
+    b = _rollouts_with_split(True, agent, batched=True, fused_sample=False)
     a.pop("_time_outs_seen"); b.pop("_time_outs_seen")
     for k in a:
         if k == "actions_log_prob":
@@ -838,14 +841,19 @@ def test_rollout_fused_sampling_equals_sampling_kernel():
             assert torch.equal(a[k], b[k]), k
 
 
-def test_rollout_batched_critic_equals_per_step_critic():
-    """MHPPO's default rollout evaluates the critic ONCE over all T slabs after the loop and adds the time-out bootstrap
-    (rewards += gamma * values * time_outs, mh_ppo.py:300-305) then; against the per-step critic everything the critic does not feed is
-    bit-identical, and values / rewards / returns / advantages agree to GEMM rounding (different tile shapes at 98 304 rows)."""
-    a = _rollouts_with_split(True, "v1", batched=True)
-    b = _rollouts_with_split(True, "v1", batched=False)
+@pytest.mark.parametrize("agent", ["v1", "v2"])
+def test_rollout_batched_critic_equals_per_step_critic(agent):
+    """The agents' default rollout evaluates the critic ONCE over all T slabs after the loop and adds the time-out bootstrap
+    (rewards += gamma * values * time_outs, mh_ppo.py:300-305, ppo_mimic.py:425-431) then — ppo_mimic.PPO on the motion embeddings the per-step
+    forwards stored; against the per-step critic everything the critic does not feed is bit-identical, and values / rewards / returns /
+    advantages agree to GEMM rounding (different tile shapes at 98 304 rows)."""
+    a = _rollouts_with_split(True, agent, batched=True)
+    b = _rollouts_with_split(True, agent, batched=False)
     soft = {"values": 2e-5, "rewards": 2e-5, "returns": 1e-4, "advantages": 2e-4}
-    assert bool(a.pop("_time_outs_seen"))            # envs reach the end of the clip inside the rollout: the bootstrap term is exercised
+    seen = bool(a.pop("_time_outs_seen"))
+    assert seen or agent == "v2"                     # v1: envs reach the end of the clip inside the rollout, the bootstrap term is exercised
+    if agent == "v2":
+        soft["actions_log_prob"] = 2e-5              # (its per-step-critic loop samples in pbhc_policy_sample: the log-prob sums its columns in another order)
     for k in a:
         if k in soft:
             close(a[k], b[k], soft[k], "batched critic " + k, rtol=1e-5)

@@ -32,7 +32,10 @@ for N, K in [(512, 768), (768, 630), (128, 512)]:
     y = torch.empty(M, N, device="cuda")
     st = _lib.current_stream()
     for shape in (2, 1):
-        for dbg, name in [(0, "full"), (1, "no LDS-DMA in the loop"), (16, "no epilogue"), (17, "no DMA, no epilogue")]:
+        cases = [(0, "full"), (1, "no LDS-DMA in the loop"), (16, "no epilogue"), (17, "no DMA, no epilogue"), (2, "epilogue without global stores")]
+        if shape == 2:
+            cases += [(d << 5, f"co-resident workgroups de-phased by {4 * d} us") for d in (2, 4, 5, 7)]
+        for dbg, name in cases:
             lib.pbhc_gemm_debug_force_shape(shape | (dbg << 8) | (VARIANT << 16))
             t = timeit(lambda: lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st))
             lib.pbhc_gemm_debug_force_shape(shape | ((dbg | 8) << 8) | (VARIANT << 16))
