@@ -731,13 +731,17 @@ __device__ __forceinline__ void obs_write_noisy(const uint32_t* mg, int k0, int 
 // feature, 2 the ones that do.  Same arithmetic per element as the map paths: (x + noise) * scale, clip.
 // `fhist`: where feature indices >= `hoff` (the HISTORY block) live, as a base for the same index (feat itself unless the block is staged
 // elsewhere: step_lds_plan); the table builder never lets a run straddle `hoff`
-template <int WHICH>
+// WHO (round 4, builds whose rows all belong to the reference waves): 0 every run; 1 all but the runs the host marked for the DYNAMICS waves
+// (PbhcObsRun.late bit 1: runs that read no history — those waves idle after their reward / reset phases while the reference waves write
+// 1 010 elements per env, the longer path after bar2), 2 only those.
+template <int WHICH, int WHO = 0>
 __device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t stream, int lane, const float* feat, const float* fhist, int hoff, float* __restrict__ outg,
                                                unsigned int ob, float clipobs, float noise_cur, const uint32_t* pre) {
 #pragma unroll
   for (int r = 0; r < m.num_runs; ++r) {
     const PbhcObsRun& R = m.runs[r];
-    if ((WHICH == 1 && R.late) || (WHICH == 2 && !R.late)) continue;
+    if ((WHICH == 1 && (R.late & 1)) || (WHICH == 2 && !(R.late & 1))) continue;
+    if ((WHO == 1 && (R.late & 2)) || (WHO == 2 && !(R.late & 2))) continue;
 #pragma unroll
     for (int i0 = 0; i0 < R.len; i0 += PBHC_G) {
       // lanes past the run's end repeat its last element (the same value to the same address): no exec-mask region per partial
@@ -795,7 +799,7 @@ __device__ __forceinline__ void wide_flush(const PbhcOutMap& m, int s0, int lane
 }
 constexpr bool seg_has_late(const PbhcOutMap& m, int s0) {
   for (int r = 0; r < m.num_runs; ++r)
-    if (m.runs[r].late && m.runs[r].dst < s0 + PBHC_SEG && m.runs[r].dst + m.runs[r].len > s0) return true;
+    if ((m.runs[r].late & 1) && m.runs[r].dst < s0 + PBHC_SEG && m.runs[r].dst + m.runs[r].len > s0) return true;
   return false;
 }
 template <int PASS>
@@ -945,6 +949,13 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
   // kp / kd features and idle at bar3 in exactly the workgroups that finish last (the ones with a terminated env), while the dynamics
   // waves still have the reward phase and the rest of the reset in front of them
   const bool dr_on_b = hist_b;
+  // ... and the runs the host marked (PbhcObsRun.late bit 1) are written by the dynamics waves after their phase H (OBS_GROUPS_HELP_RUNS)
+#if defined(PBHC_STATIC_CFG) && !defined(PBHC_WIDE_ROWS) && !defined(PBHC_NO_ROW_HELP)
+  constexpr bool row_help = hist_b;
+#else
+  constexpr bool row_help = false;
+#endif
+  constexpr int RUN_WHO = row_help ? 1 : 0;
   float* const histl = hist_b ? bp : feat + hoff;
   const float* const fhist = histl - hoff;
 #ifdef PBHC_STATIC_CFG
@@ -1702,8 +1713,16 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
     float* __restrict__ const outg = io.obs[g];                                                                                     \
     const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
-    if (LATE_TOO) obs_write_runs<0>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);               \
-    else obs_write_runs<1>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);                        \
+    if (LATE_TOO) obs_write_runs<0, RUN_WHO>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);      \
+    else obs_write_runs<1, RUN_WHO>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);               \
+  }
+#define OBS_GROUPS_HELP_RUNS()                                                                                                      \
+  _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
+    if (g >= c.num_groups || c.groups[g].role != 1) continue;                                                                       \
+    const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
+    float* __restrict__ const outg = io.obs[g];                                                                                     \
+    const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
+    obs_write_runs<0, 2>(c.groups[g], 16 + g, lane, feat, feat, hoff, outg, ob, clipobs, noise_cur, nzb);                           \
   }
 #define OBS_GROUPS_LATE_RUNS(ROLE)                                                                                                  \
   _Pragma("unroll") for (int g = 0; g < PBHC_MAX_GROUPS; ++g) {                                                                     \
@@ -1711,7 +1730,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     const int pitch_g = io.obs_pitch[g] ? io.obs_pitch[g] : c.groups[g].pitch;                                                      \
     float* __restrict__ const outg = io.obs[g];                                                                                     \
     const u32 ob = (u32)env * (u32)pitch_g;                                                                                         \
-    obs_write_runs<2>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);                             \
+    obs_write_runs<2, RUN_WHO>(c.groups[g], 16 + g, lane, feat, fhist, hoff, outg, ob, clipobs, noise_cur, nzb);                    \
   }
 #endif
 #define OBS_GROUPS_MAP(ROLE, LATE_TOO)                                                                                              \
@@ -2064,6 +2083,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     STAMP(8);
 #ifndef PBHC_ABL_WB
     if (hist_b && valid) { STATE_WRITEBACK(); }                  // phase J on THIS role (see interval 3)
+#endif
+#if defined(PBHC_STATIC_CFG) && !defined(PBHC_ABL_OBS) && !defined(PBHC_ABL_OBSX4)
+    // ... and its share of the reference waves' rows: every source is final for this role (its own phase H included), history excluded
+    if (row_help && valid && obs_by_role) { OBS_GROUPS_HELP_RUNS() }
 #endif
     // ---------------- observation rows of the groups assigned to this role (helpers.py:128-152, legged_robot_base.py:787-793,326-331,
     // history_handler.py:40-44): every source is final for THIS role now (its own phase H included)

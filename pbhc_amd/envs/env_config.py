@@ -619,6 +619,23 @@ def build(cfg, skel, motion_lib, num_envs, device, sim_link_mass_dim, seed=0, mo
         c.groups[i].role = r_
         load[r_] += len(maps[i][2])
     L.group_roles = [int(c.groups[i].role) for i in range(len(maps))]
+    # ... of which the dynamics waves take the share that balances the two roles after bar2 (they idle for ~2.3 k cycles after their reward /
+    # reset phases while the reference waves write 1 010 elements): whole runs that read no history (that block is staged by the reference
+    # waves), largest first, marked in PbhcObsRun.late bit 1.  The specialised kernel honours the marks in the builds whose history block
+    # lives outside the feature row (step_lds_plan); every other build lets the reference waves write all runs.
+    # Measured (profiles/round4_k_env_step_variants.txt (h)): shares of 0.15 / 0.23 / 0.32 give 18.3-18.6 us against 18.2 at 4096 envs and nothing
+    # at 32 768 — the launch's tail is the chip-wide store drain, not the reference waves' instruction stream — so the default share is 0.
+    share = float(_os.environ.get("PBHC_ROW_HELP_SHARE", "0"))
+    if mode == 0 and share > 0.0 and all(r_ == 1 for r_ in L.group_roles) and all(c.groups[i].num_runs > 0 for i in range(len(maps))):
+        hoff_ = feat_off["HISTORY"]
+        cand = sorted(((int(c.groups[i].runs[r_].len), i, r_) for i in range(len(maps)) for r_ in range(c.groups[i].num_runs)
+                       if c.groups[i].runs[r_].src + c.groups[i].runs[r_].len <= hoff_), reverse=True)
+        budget = share * sum(len(m[2]) for m in maps)
+        for n_, i, r_ in cand:
+            if n_ <= budget:
+                c.groups[i].runs[r_].late |= 2
+                budget -= n_
+    L.helper_elements = sum(int(c.groups[i].runs[r_].len) for i in range(len(maps)) for r_ in range(max(int(c.groups[i].num_runs), 0)) if c.groups[i].runs[r_].late & 2)
     c.map_lds_words = lds_off if compact else 0
     if compact:
         L.map_image = torch.from_numpy(np.concatenate(image).view(np.int32).copy()).to(device)
