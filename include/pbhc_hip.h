@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define PBHC_ABI_VERSION 10
+#define PBHC_ABI_VERSION 11
 
 #define PBHC_OK 0
 #define PBHC_EINVAL (-22)   /* bad argument / size over a compile-time maximum */
@@ -610,6 +610,23 @@ typedef struct PbhcMlpInput {
 } PbhcMlpInput;
 int pbhc_mlp_fwd_cat(const PbhcMlpInput* in, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,
                      int M, const PbhcMlpSample* sample, void* stream);
+/* pbhc_conv_encoder_fwd: the general-tracking `ConvEncoder` (agents/modules/encoder_modules.py:22-107 of the reference: Linear(d -> H) + ReLU
+ * per time step, Conv1d(H -> O1, k1, s1) + act, Conv1d(O1 -> O2, k2, s2) + act, Linear(L2 * O2 -> E)) under no_grad in ONE launch, 16 rows per
+ * workgroup through all four layers (the rollout: 4 096 rows per control step).  x [M, T * d] with row pitch ldx >= (T - 1) * d + ceil16(d)
+ * (a rollout slab's padded rows), y [M, E].  Weights packed by pbhc_mlp_pack from row-major matrices: w1 [H, d]; wc1 [O1, k1 * H] and wc2
+ * [O2, k2 * O1] with the kernel tap OUTER (conv.weight.permute(0, 2, 1)); wo [E, L2 * O2] with its columns in (position, channel) order.
+ * act: 1 ELU, 2 SiLU, 3 ReLU (the conv layers; layer 1 is ReLU, the output layer linear).  pbhc_conv_encoder_lds_bytes: the launch's LDS need
+ * (<= 160 KB; the caller falls back to the per-layer kernels otherwise). */
+typedef struct PbhcConvEncoder {
+  const float* w1; const float* b1;
+  const float* wc1; const float* bc1;
+  const float* wc2; const float* bc2;
+  const float* wo; const float* bo;
+  int32_t T, d, H, O1, k1, s1, O2, k2, s2, E, act;
+  int32_t pad_;
+} PbhcConvEncoder;
+size_t pbhc_conv_encoder_lds_bytes(const PbhcConvEncoder* e);
+int pbhc_conv_encoder_fwd(const float* x, int ldx, const PbhcConvEncoder* e, float* y, int ldy, int M, void* stream);
 size_t pbhc_mlp_packed_floats(int N, int K);
 int pbhc_mlp_pack(const float* w, int N, int K, float* packed, void* stream);
 size_t pbhc_mlp_fwd_lds_bytes(const int* dims, int num_layers);

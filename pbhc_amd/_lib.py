@@ -84,6 +84,7 @@ PbhcMotionTable = _S["PbhcMotionTable"]
 PbhcStepIO = _S["PbhcStepIO"]
 PbhcMlpSample = _S["PbhcMlpSample"]
 PbhcMlpInput = _S["PbhcMlpInput"]
+PbhcConvEncoder = _S["PbhcConvEncoder"]
 
 EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbhc_sizeof_step_io", "pbhc_motion_build",
            "pbhc_motion_state", "pbhc_sim_fk", "pbhc_env_create", "pbhc_env_destroy", "pbhc_env_step", "pbhc_gae",
@@ -91,7 +92,7 @@ EXPORTS = ["pbhc_abi_version", "pbhc_last_error", "pbhc_sizeof_env_config", "pbh
            "pbhc_policy_sample", "pbhc_rollout_post", "pbhc_act_bwd_bias", "pbhc_env_finalize", "pbhc_act_bwd_partials", "pbhc_colsum_final", "pbhc_adam_clip2", "pbhc_debug_rotations", "pbhc_motion_build_batch",
            "pbhc_linear_act_fwd", "pbhc_env_config_lds_bytes", "pbhc_linear_act_fwd_out", "pbhc_debug_out_bwd_variant", "pbhc_gather_rows", "pbhc_linear_dgrad_act", "pbhc_gemm_debug_force_shape", "pbhc_linear_wgrad", "pbhc_linear_wgrad_parts", "pbhc_linear_act_fwd_strided",
            "pbhc_env_step_launch", "pbhc_env_step_finish", "pbhc_mlp_fwd", "pbhc_mlp_fwd_lds_bytes", "pbhc_mlp_pack", "pbhc_mlp_packed_floats", "pbhc_rollout_post2", "pbhc_mlp_fwd_sample", "pbhc_linear_out_bwd",
-           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule", "pbhc_debug_fk", "pbhc_mlp_fwd_cat"]
+           "pbhc_env_get_config", "pbhc_env_attach_specialised", "pbhc_env_is_specialised", "pbhc_env_config_finalize", "pbhc_kl_lr_rule", "pbhc_debug_fk", "pbhc_mlp_fwd_cat", "pbhc_conv_encoder_fwd", "pbhc_conv_encoder_lds_bytes"]
 
 
 class PbhcError(RuntimeError):
@@ -150,6 +151,9 @@ def _load():
     lib.pbhc_linear_wgrad.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.pbhc_mlp_fwd.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, vp, i, i, vp]
     lib.pbhc_mlp_fwd_sample.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, i, C.POINTER(PbhcMlpSample), vp]
+    lib.pbhc_conv_encoder_lds_bytes.argtypes = [C.POINTER(PbhcConvEncoder)]
+    lib.pbhc_conv_encoder_lds_bytes.restype = C.c_size_t
+    lib.pbhc_conv_encoder_fwd.argtypes = [vp, i, C.POINTER(PbhcConvEncoder), vp, i, i, vp]
     lib.pbhc_mlp_fwd_cat.argtypes = [C.POINTER(PbhcMlpInput), C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, i, vp, i, i, C.POINTER(PbhcMlpSample), vp]
     lib.pbhc_mlp_fwd_lds_bytes.argtypes = [C.POINTER(i), i]
     lib.pbhc_mlp_fwd_lds_bytes.restype = C.c_size_t

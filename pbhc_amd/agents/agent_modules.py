@@ -201,6 +201,9 @@ class _WindowConv1dAct(torch.autograd.Function):
         return dx, dw, gb, None, None, None
 
 
+import os as _os
+
+ONE_LAUNCH_ENCODER = _os.environ.get("PBHC_ENCODER_ONE_LAUNCH", "1") != "0"      # (0: the four per-layer launches; measurement aid)
 _CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
 
 
@@ -268,7 +271,39 @@ class ConvEncoder(nn.Module):
             else:
                 for c, w in zip(cache, ws):
                     c.copy_(w)
+            self._pack_encoder()
         self._infer_ready = True
+
+    def _pack_encoder(self):
+        """the four weight matrices in the operand layout of the one-launch encoder (`pbhc_conv_encoder_fwd`), refreshed in place"""
+        import ctypes as C
+
+        from .. import _lib
+        from . import fused_mlp
+
+        self._enc_c = None
+        lin, out = self.encoder[0], self.output_layer
+        convs = [self.conv_module[2 * i] for i in range(len(self._strides))]
+        if not (len(convs) == 2 and self.input_dim <= 128 and lin.weight.is_cuda and lin.weight.is_contiguous() and fused_mlp.FUSED_GEMM and fused_mlp.FUSED_STACK):
+            return
+        lib, st = _lib.lib(), _lib.current_stream()
+        mats = [lin.weight] + list(self._infer_w)
+        sizes = [int(lib.pbhc_mlp_packed_floats(m.shape[0], m.shape[1])) for m in mats]
+        bufs = self.__dict__.get("_enc_bufs")
+        if bufs is None or [b.numel() for b in bufs] != sizes or bufs[0].device != lin.weight.device:
+            bufs = self._enc_bufs = [torch.empty(n, device=lin.weight.device) for n in sizes]
+        for m, b in zip(mats, bufs):
+            _lib.check(lib.pbhc_mlp_pack(m.data_ptr(), m.shape[0], m.shape[1], b.data_ptr(), st), "pbhc_mlp_pack")
+        e = _lib.PbhcConvEncoder()
+        e.w1, e.wc1, e.wc2, e.wo = (b.data_ptr() for b in bufs)
+        e.b1, e.bc1, e.bc2, e.bo = lin.bias.data_ptr(), convs[0].bias.data_ptr(), convs[1].bias.data_ptr(), out.bias.data_ptr()
+        e.T, e.d, e.H, e.E = self.time_steps, self.input_dim, self.hidden_dim, out.out_features
+        e.O1, e.k1, e.s1 = convs[0].out_channels, convs[0].kernel_size[0], self._strides[0]
+        e.O2, e.k2, e.s2 = convs[1].out_channels, convs[1].kernel_size[0], self._strides[1]
+        e.act = fused_mlp._ACT_ID[type(self._act)]
+        if (e.s1 * e.H) % 4 or (e.s2 * e.O1) % 4 or int(lib.pbhc_conv_encoder_lds_bytes(C.byref(e))) > 160 * 1024:
+            return
+        self._enc_c = e
 
     def release_inference(self):
         self._infer_ready = False
@@ -283,7 +318,17 @@ class ConvEncoder(nn.Module):
         lib, st = _lib.lib(), _lib.current_stream()
         T, d, H = self.time_steps, self.input_dim, self.hidden_dim
         lin = self.encoder[0]
-        ws = self._infer_w if self.__dict__.get("_infer_ready", False) else [w.contiguous() for w in self._layout_weights()]
+        ready = self.__dict__.get("_infer_ready", False)
+        e = self.__dict__.get("_enc_c") if ready else None
+        if (e is not None and ONE_LAUNCH_ENCODER and B <= 16384 and x.stride(0) >= (T - 1) * d + (d + 15) // 16 * 16
+                and (out is None or (out.dim() == 2 and out.stride(1) == 1))):
+            # the whole encoder as ONE launch (pbhc_conv_encoder_fwd: 16 rows per workgroup through the four layers, activations in LDS)
+            import ctypes as C
+
+            y = out if out is not None else torch.empty(B, e.E, device=x.device)
+            _lib.check(lib.pbhc_conv_encoder_fwd(x.data_ptr(), x.stride(0), C.byref(e), y.data_ptr(), y.stride(0), B, st), "pbhc_conv_encoder_fwd")
+            return y
+        ws = self._infer_w if ready else [w.contiguous() for w in self._layout_weights()]
         h = torch.empty(B, T, H, device=x.device)
         _lib.check(lib.pbhc_linear_act_fwd_strided(x.data_ptr(), x.stride(0), d, lin.weight.data_ptr(), lin.bias.data_ptr(), h.data_ptr(), None, T * H, H, T,
                                                    B, H, d, 3, st), "pbhc_linear_act_fwd_strided")

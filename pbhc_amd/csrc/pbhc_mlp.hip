@@ -236,6 +236,111 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The general-tracking ConvEncoder (reference: agents/modules/encoder_modules.py:22-107 — Linear + ReLU per time step, two Conv1d + activation
+// over the time axis that leave 3 positions, a Linear on the flattened result) under no_grad as ONE launch: the rollout evaluates it for
+// 4 096 rows per control step, where its four layers as separate GEMM launches are 62 us of launch / tile overhead for 1.8 GFLOP.
+// A workgroup owns 16 envs and carries them through all four layers with the tile routine of the stack kernel above (packed weights straight
+// from L2 into the MFMA's B registers):
+//   layer 1  rows = the 16 envs at ONE time step: the A fragments come straight from the observation slab (global, 16 bytes per lane; the
+//            columns a k-step reads past the step's `d` are the next step's values against zero weights) -> image h [env][t * H + c];
+//   conv 1/2 output position l reads k consecutive time steps = ONE contiguous run of k * C floats of the image below: A = image + l * s * C,
+//            same row pitch -> images c1 [env][l * O1 + c], c2 [env][l * O2 + c];
+//   output   Linear on c2's rows as they lie (its columns re-ordered to (l, c) by the caller) -> global [env][E].
+// Every image row ends in zeroed padding that covers the last k-step's over-read.  Jobs (position x pair of 16-column tiles) go round-robin
+// over the 8 waves.  Rounding differs from the layer-by-layer path by summation order only.
+struct EncArgs {
+  const float* x; int ldx;
+  const float *w1, *b1, *wc1, *bc1, *wc2, *bc2, *wo, *bo;      // packed weights (pbhc_mlp_pack), biases
+  float* y; int ldy;
+  int M, T, d, H, O1, k1, s1, L1, O2, k2, s2, L2, E, act;
+  int ph, pc1, pc2;                                        // row pitches (floats) of the three LDS images
+};
+
+struct EncTrue { static constexpr bool value = true; };
+struct EncFalse { static constexpr bool value = false; };
+// one job: acc[t] = A[16, K] . Wp[tile_t]^T for two column tiles; A either an LDS image (row pitch P) or, GLOBAL_A, global rows `ga` (per-lane
+// pointer to row j, column 4 g of the first k-step; <= 8 k-steps, fetched up front)
+template <bool GLOBAL_A>
+__device__ __forceinline__ void enc_job(const float* __restrict__ Wp, int nks, const int (&tile)[2], const float* __restrict__ A, int P, const float* __restrict__ ga,
+                                        f32x4 (&acc)[2]) {
+  if (!GLOBAL_A) {
+    mlp_tiles<2>(Wp, nks, tile, A, P, acc);
+  } else {
+    const int lane = threadIdx.x & 63;
+    f32x4 areg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) areg[k] = reinterpret_cast<const MlpF4U*>(ga + 16 * min(k, nks - 1))->v;
+    unsigned int woff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) woff[t] = ((unsigned int)(tile[t] * nks) * 64u + (unsigned int)lane) * 16u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < nks) {
+        f32x4 b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const f32x4*>((const char*)Wp + woff[t] + 1024u * (unsigned int)k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[k][q], b[t][q], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MLP_T) void k_conv_encoder_fwd(EncArgs a) {
+  extern __shared__ float mlp_smem[];
+  float* const himg = mlp_smem;
+  float* const c1 = himg + MLP_ROWS * a.ph;
+  float* const c2 = c1 + MLP_ROWS * a.pc1;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  // zero the padding behind every image row (read by the last k-step of the layer above, against zero weights: it has to be finite)
+  {
+    const int wh = a.T * a.H, w1 = a.L1 * a.O1, w2 = a.L2 * a.O2;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.ph - wh); i += MLP_T) himg[(i / (a.ph - wh)) * a.ph + wh + i % (a.ph - wh)] = 0.0f;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc1 - w1); i += MLP_T) c1[(i / (a.pc1 - w1)) * a.pc1 + w1 + i % (a.pc1 - w1)] = 0.0f;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc2 - w2); i += MLP_T) c2[(i / (a.pc2 - w2)) * a.pc2 + w2 + i % (a.pc2 - w2)] = 0.0f;
+  }
+  // stage: `npos` positions x pairs of column tiles; out(r, pos, n, v) stores one element
+  auto stage = [&](auto global_a, const float* Wp, const float* bias, int K, int N, int npos, int act, const float* Aimg, int P, int astep, float* O, int PO, int ostep,
+                   bool to_global) {
+    constexpr bool GA = decltype(global_a)::value;
+    const int nks = (K + 15) >> 4, ntiles = (N + 15) >> 4, npairs = (ntiles + 1) >> 1;
+    for (int job = wave; job < npos * npairs; job += MLP_WAVES) {
+      const int pos = job / npairs, pr = job - pos * npairs;
+      const int tile[2] = {2 * pr, min(2 * pr + 1, ntiles - 1)};
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const float* ga = GA ? a.x + (size_t)min(row0 + j, a.M - 1) * a.ldx + pos * astep + 4 * g : nullptr;
+      enc_job<GA>(Wp, nks, tile, GA ? nullptr : Aimg + pos * astep, P, ga, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && 2 * pr + 1 >= ntiles) continue;           // (a clamped duplicate of the last tile)
+        const int n = 16 * tile[t] + j;
+        const float bv = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 4 * g + v;
+          const float val = mlp_act(act, acc[t][v] + bv);
+          if (n < N) {
+            if (!to_global) O[r * PO + pos * ostep + n] = val;
+            else if (row0 + r < a.M) a.y[(size_t)(row0 + r) * a.ldy + n] = val;
+          }
+        }
+      }
+    }
+  };
+  stage(EncTrue{}, a.w1, a.b1, a.d, a.H, a.T, 3, nullptr, 0, a.d, himg, a.ph, a.H, false);
+  __syncthreads();
+  stage(EncFalse{}, a.wc1, a.bc1, a.k1 * a.H, a.O1, a.L1, a.act, himg, a.ph, a.s1 * a.H, c1, a.pc1, a.O1, false);
+  __syncthreads();
+  stage(EncFalse{}, a.wc2, a.bc2, a.k2 * a.O1, a.O2, a.L2, a.act, c1, a.pc1, a.s2 * a.O1, c2, a.pc2, a.O2, false);
+  __syncthreads();
+  stage(EncFalse{}, a.wo, a.bo, a.L2 * a.O2, a.E, 1, 0, c2, a.pc2, 0, nullptr, 0, 0, true);
+}
+
 // nn.Linear.weight [N, K] -> [ceil(N/16)][ceil(K/16)][64 lanes][4]: lane (j = l % 16, g = l / 16) of (tile, k-step) holds
 // W[16 tile + j][16 kstep + 4 g .. + 3], zeros outside the matrix
 __global__ void k_mlp_pack(const float* __restrict__ w, int N, int K, float* __restrict__ out, int nks, size_t total4) {
@@ -357,6 +462,53 @@ int pbhc_mlp_fwd_sample(const float* x, int ldx, const float* const* weights, co
   MLP_ARG(sample && dims);
   const PbhcMlpInput in = one_segment(x, ldx, dims);
   return mlp_launch(&in, weights, biases, dims, num_layers, act, nullptr, 0, M, sample, stream);
+}
+
+// image row pitch: the row + 16 floats of zeroed over-read room, rounded up to 4 mod 8 words... to a multiple of 4 that is 4, 12, 20 or 28 mod 32
+// (16-byte aligned rows whose ds_read_b128 fragments of 8 consecutive rows fall into different banks)
+static int enc_pitch(int w) {
+  int p = ((w + 16 + 3) & ~3);
+  while ((p & 7) != 4) p += 4;
+  return p;
+}
+
+size_t pbhc_conv_encoder_lds_bytes(const PbhcConvEncoder* e) {
+  if (!e) return 0;
+  const int L1 = (e->T - e->k1) / e->s1 + 1, L2 = (L1 - e->k2) / e->s2 + 1;
+  return (size_t)MLP_ROWS * (size_t)(enc_pitch(e->T * e->H) + enc_pitch(L1 * e->O1) + enc_pitch(L2 * e->O2)) * sizeof(float);
+}
+
+int pbhc_conv_encoder_fwd(const float* x, int ldx, const PbhcConvEncoder* e, float* y, int ldy, int M, void* stream) {
+  MLP_ARG(x && e && y && M >= 1 && e->w1 && e->wc1 && e->wc2 && e->wo && e->act >= 0 && e->act <= 3);
+  MLP_ARG(e->T >= 1 && e->d >= 1 && e->d <= 128 && e->H >= 1 && e->O1 >= 1 && e->O2 >= 1 && e->E >= 1 && e->k1 >= 1 && e->s1 >= 1 && e->k2 >= 1 && e->s2 >= 1);
+  const int L1 = (e->T - e->k1) / e->s1 + 1, L2 = e->T >= e->k1 ? (L1 - e->k2) / e->s2 + 1 : 0;
+  MLP_ARG(e->T >= e->k1 && L1 >= e->k2 && L2 >= 1 && ldy >= e->E);
+  // layer 1 reads whole k-steps of 16 floats from the slab: the last step's over-read has to stay inside the row's pitch (and the allocation)
+  MLP_ARG(ldx >= (e->T - 1) * e->d + ((e->d + 15) & ~15) && (((uintptr_t)x) & 3) == 0);
+  // the conv windows are read as 16-byte LDS fragments: their starts have to be 16-byte aligned
+  MLP_ARG(((e->s1 * e->H) & 3) == 0 && ((e->s2 * e->O1) & 3) == 0);
+  for (const float* w : {e->w1, e->wc1, e->wc2, e->wo}) MLP_ARG((((uintptr_t)w) & 15) == 0);
+  MLP_ARG(pbhc_mlp_packed_floats(e->O1, e->k1 * e->H) < (1u << 28) && pbhc_mlp_packed_floats(e->E, L2 * e->O2) < (1u << 28));
+  EncArgs a;
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M;
+  a.w1 = e->w1; a.b1 = e->b1; a.wc1 = e->wc1; a.bc1 = e->bc1; a.wc2 = e->wc2; a.bc2 = e->bc2; a.wo = e->wo; a.bo = e->bo;
+  a.T = e->T; a.d = e->d; a.H = e->H; a.O1 = e->O1; a.k1 = e->k1; a.s1 = e->s1; a.L1 = L1; a.O2 = e->O2; a.k2 = e->k2; a.s2 = e->s2; a.L2 = L2; a.E = e->E; a.act = e->act;
+  a.ph = enc_pitch(e->T * e->H); a.pc1 = enc_pitch(L1 * e->O1); a.pc2 = enc_pitch(L2 * e->O2);
+  const size_t lds = pbhc_conv_encoder_lds_bytes(e);
+  MLP_ARG(lds <= 160 * 1024);
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    MLP_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+      MLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_encoder_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL(k_conv_encoder_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_T), lds, (hipStream_t)stream, a);
+  MLP_HIP(hipGetLastError());
+  return PBHC_OK;
 }
 
 int pbhc_mlp_fwd_cat(const PbhcMlpInput* in, const float* const* weights, const float* const* biases, const int* dims, int num_layers, int act, float* y, int ldy,

@@ -199,13 +199,23 @@ def test_conv_encoder_no_grad_path_matches_conv1d(cfg):
         assert enc._infer_ok(x)
         got = enc(x)
         enc.prepare_inference()
-        got2 = enc(x)
+        got2 = enc(x)                                   # (prepared: the one-launch encoder, pbhc_conv_encoder_fwd)
+        assert enc._enc_c is not None
+        am.ONE_LAUNCH_ENCODER = False
+        try:
+            got3 = enc(x)                               # prepared weights, per-layer launches
+        finally:
+            am.ONE_LAUNCH_ENCODER = True
+        assert torch.equal(got, got3)
+        into2 = torch.zeros(3, B, E, device="cuda")
+        enc(x, out=into2[1])
+        assert torch.equal(into2[1], got2) and not into2[0].any() and not into2[2].any()
         enc.release_inference()
         into = torch.zeros(3, B, E, device="cuda")
         assert enc(x, out=into[1]) is not None and torch.equal(into[1], got) and not into[0].any() and not into[2].any()
-    assert torch.equal(got, got2)
     scale = max(1.0, want.abs().max().item())
     assert (got.double().cpu() - want).abs().max().item() < 2e-5 * scale
+    assert (got2.double().cpu() - want).abs().max().item() < 2e-5 * scale
     with torch.enable_grad():                          # ... and the training path on the same input
         tr = enc(x.contiguous())
     assert (tr.detach().double().cpu() - want).abs().max().item() < 2e-5 * scale
