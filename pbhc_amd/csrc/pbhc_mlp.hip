@@ -290,7 +290,11 @@ __device__ __forceinline__ void enc_job(const float* __restrict__ Wp, int nks, c
   }
 }
 
-__global__ __launch_bounds__(MLP_T) void k_conv_encoder_fwd(EncArgs a) {
+#ifndef ENC_WAVES
+#define ENC_WAVES 16                                       // the layers are chains of dependent k-steps fed from L2: more waves per workgroup hide more of it (8: 44.7 us)
+#endif
+#define ENC_T (64 * ENC_WAVES)
+__global__ __launch_bounds__(ENC_T) void k_conv_encoder_fwd(EncArgs a) {
   extern __shared__ float mlp_smem[];
   float* const himg = mlp_smem;
   float* const c1 = himg + MLP_ROWS * a.ph;
@@ -300,16 +304,16 @@ __global__ __launch_bounds__(MLP_T) void k_conv_encoder_fwd(EncArgs a) {
   // zero the padding behind every image row (read by the last k-step of the layer above, against zero weights: it has to be finite)
   {
     const int wh = a.T * a.H, w1 = a.L1 * a.O1, w2 = a.L2 * a.O2;
-    for (int i = threadIdx.x; i < MLP_ROWS * (a.ph - wh); i += MLP_T) himg[(i / (a.ph - wh)) * a.ph + wh + i % (a.ph - wh)] = 0.0f;
-    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc1 - w1); i += MLP_T) c1[(i / (a.pc1 - w1)) * a.pc1 + w1 + i % (a.pc1 - w1)] = 0.0f;
-    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc2 - w2); i += MLP_T) c2[(i / (a.pc2 - w2)) * a.pc2 + w2 + i % (a.pc2 - w2)] = 0.0f;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.ph - wh); i += ENC_T) himg[(i / (a.ph - wh)) * a.ph + wh + i % (a.ph - wh)] = 0.0f;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc1 - w1); i += ENC_T) c1[(i / (a.pc1 - w1)) * a.pc1 + w1 + i % (a.pc1 - w1)] = 0.0f;
+    for (int i = threadIdx.x; i < MLP_ROWS * (a.pc2 - w2); i += ENC_T) c2[(i / (a.pc2 - w2)) * a.pc2 + w2 + i % (a.pc2 - w2)] = 0.0f;
   }
   // stage: `npos` positions x pairs of column tiles; out(r, pos, n, v) stores one element
   auto stage = [&](auto global_a, const float* Wp, const float* bias, int K, int N, int npos, int act, const float* Aimg, int P, int astep, float* O, int PO, int ostep,
                    bool to_global) {
     constexpr bool GA = decltype(global_a)::value;
     const int nks = (K + 15) >> 4, ntiles = (N + 15) >> 4, npairs = (ntiles + 1) >> 1;
-    for (int job = wave; job < npos * npairs; job += MLP_WAVES) {
+    for (int job = wave; job < npos * npairs; job += ENC_WAVES) {
       const int pos = job / npairs, pr = job - pos * npairs;
       const int tile[2] = {2 * pr, min(2 * pr + 1, ntiles - 1)};
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -506,7 +510,7 @@ int pbhc_conv_encoder_fwd(const float* x, int ldx, const PbhcConvEncoder* e, flo
       raised.fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(k_conv_encoder_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_T), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_conv_encoder_fwd, dim3((M + MLP_ROWS - 1) / MLP_ROWS), dim3(ENC_T), lds, (hipStream_t)stream, a);
   MLP_HIP(hipGetLastError());
   return PBHC_OK;
 }
