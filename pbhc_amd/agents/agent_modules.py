@@ -8,6 +8,8 @@ the parameters keep nn.Conv1d's shapes and names.
 """
 from __future__ import annotations
 
+import os as _os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -116,6 +118,51 @@ def _conv_window_grads(x, dz, wp, k, s, need_dx):
     return dx, part.sum(0)
 
 
+# 1: a Conv1d layer's input gradient as one strided-batched GEMM per stride phase (_conv_dgrad_phases) instead of the per-window accumulation
+# loop.  Measured in the general-tracking update (tools/probes/conv_bwd_probe.py, bench.py): 2 launches of 75 us (K = 120: five rounds of short
+# tiles) + a 15 us padded copy against 8 x 21 us + a 16 us fill — 70.4 against 68.9 ms per update — so the loop stays the default.
+CONV_DGRAD_PHASES = _os.environ.get("PBHC_CONV_DGRAD_PHASES", "0") != "0"
+_DZ_PAD_CACHE = {}
+
+
+def _padded_dz(B, L, O, J, T, s, device):
+    """[B, Lp, O] with the L real windows behind J - 1 zero windows (and enough zero windows after them): allocated once per shape — the
+    interior is rewritten by every backward, the pad windows stay zero; consumers are stream-ordered inside that backward"""
+    pad = J - 1
+    Lp = max(L + 2 * pad, (T - 1) // s + J)
+    key = (B, L, O, J, Lp, str(device))
+    buf = _DZ_PAD_CACHE.get(key)
+    if buf is None:
+        if len(_DZ_PAD_CACHE) > 16:
+            _DZ_PAD_CACHE.clear()
+        buf = _DZ_PAD_CACHE[key] = torch.zeros(B, Lp, O, device=device)
+    return buf, pad, Lp
+
+
+def _conv_dgrad_phases(dzp, pad, w, k, s, T):
+    """Input gradient of nn.Conv1d(C -> O, k, s | k) on time-major activations as ONE strided-batched GEMM per stride phase: time step
+    t = m s + p receives dz[:, l, :] . W[:, :, t - l s] from the J = k / s windows l = m - J + 1 .. m, which are J * O CONTIGUOUS floats of
+    the zero-padded gradient `dzp` [B, Lp, O] (window l at index l + pad) — so dx[:, m s + p, :] = dzp[:, m : m + J, :] . B_p with
+    B_p [J O, C] the phase's taps stacked, batched over m (A advances by O floats, the output by s C): every element of dx is written once
+    (the accumulation loop: L launches reading and re-writing overlapping slices of a zero-filled dx, 168 us for the motion encoder's first
+    conv layer at 24 576 rows against 2 launches)"""
+    from .. import _lib
+
+    B, Lp, O = dzp.shape
+    Cin = w.shape[1]
+    J = k // s
+    lib, st = _lib.lib(), _lib.current_stream()
+    dx = torch.empty(B, T, Cin, device=dzp.device)
+    wt = w.permute(1, 2, 0)                                             # [C, k, O]
+    for p in range(s):
+        taps = [(J - 1 - jj) * s + p for jj in range(J)]                  # window l = m - (J - 1) + jj reads tap t - l s
+        bpt = wt[:, taps, :].reshape(Cin, J * O)                          # [N = C, K = (jj, o)]: the "weight" of an NT GEMM
+        nm = (T - 1 - p) // s + 1
+        _lib.check(lib.pbhc_linear_act_fwd_strided(dzp.data_ptr(), Lp * O, O, bpt.data_ptr(), None, dx.data_ptr() + 4 * p * Cin, None, T * Cin, s * Cin, nm,
+                                                   B, Cin, J * O, 0, st), "pbhc_linear_act_fwd_strided")
+    return dx
+
+
 class _WindowConv1d(torch.autograd.Function):
     """nn.Conv1d(C -> O, kernel k, stride s, no padding) on x [B, T, C] (time-major rows, the layout the per-step Linear produces) -> [B, L, O].
 
@@ -190,18 +237,25 @@ class _WindowConv1dAct(torch.autograd.Function):
         O = w.shape[0]
         L = dy.shape[1]
         dy = dy.contiguous()
+        wp = w.permute(0, 2, 1).reshape(O, k * Cin)
         dz = torch.empty_like(dy)
         gb = torch.empty(O, device=dy.device)
         scratch = torch.empty(_lib.K["PBHC_ACT_MAX_BLOCKS"] * O, device=dy.device)
         _lib.check(_lib.lib().pbhc_act_bwd_bias(dy.data_ptr(), saved.data_ptr(), B * L, O, ctx.act, dz.data_ptr(), gb.data_ptr(), scratch.data_ptr(),
                                                 _lib.current_stream()), "pbhc_act_bwd_bias")
-        wp = w.permute(0, 2, 1).reshape(O, k * Cin)
-        dx, dwp = _conv_window_grads(x, dz, wp, k, s, ctx.needs_input_grad[0])
+        # (opt-in, see CONV_DGRAD_PHASES: the input gradient as one GEMM launch per stride phase on a zero-padded copy of dz; the weight gradient
+        # keeps reading the CONTIGUOUS dz — its batched-GEMM shapes are the ones the shipped GEMM selections were made for)
+        phases = CONV_DGRAD_PHASES and ctx.needs_input_grad[0] and k % s == 0 and (k // s) * O >= 4 and L >= 6 and T * Cin * B < (1 << 30)
+        if phases:
+            dzp, pad, Lp = _padded_dz(B, L, O, k // s, T, s, dy.device)
+            dzp[:, pad:pad + L, :].copy_(dz)
+            dx = _conv_dgrad_phases(dzp, pad, w, k, s, T)
+        _, dwp = _conv_window_grads(x, dz, wp, k, s, False) if phases else (None, None)
+        if not phases:
+            dx, dwp = _conv_window_grads(x, dz, wp, k, s, ctx.needs_input_grad[0])
         dw = dwp.view(O, k, Cin).permute(0, 2, 1)
         return dx, dw, gb, None, None, None
 
-
-import os as _os
 
 ONE_LAUNCH_ENCODER = _os.environ.get("PBHC_ENCODER_ONE_LAUNCH", "1") != "0"      # (0: the four per-layer launches; measurement aid)
 _CONV_TABLE = {5: ([20, 10], [2, 2], [1, 1]), 10: ([20, 10], [4, 2], [2, 1]), 20: ([40, 20], [6, 4], [2, 2])}     # encoder_modules.py:60-77
