@@ -1159,14 +1159,20 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       creg4 = make_float4(qa[0], qa[1], qa[2], qa[3]);               // (4-byte aligned rows: the compiler's own dwordx4, as for the table rows)
       if ((B * 3) & 3) cregr = at(csrc, cbase + (u32)min(4 * nq + lane, B * 3 - 1));
     }
-    // operands of the pre-physics step / torques / joint-space sums: consumed after bar1
-#pragma unroll
-    for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));
-    a_in = at(io.actions_in, eDc + dc);
-    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);
-    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc);
-    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);
+    // operands of the pre-physics step / torques / joint-space sums: consumed after bar1 — requested behind phase D, where the reference rows'
+    // 32 registers are free again: 13 registers off this prologue's peak (92 -> 76 VGPRs; 18.0 / 95.0 -> 18.0 / 92.0 us at 4096 / 32 768 envs,
+    // profiles/round4_k_env_step_variants.txt (i); -DPBHC_EARLY_OPERANDS: with the prologue's other loads, as before).  A sixth workgroup per CU,
+    // which 76 registers admit (-DPBHC_MIN_WAVES=6: resident by hipOccupancyMaxActiveBlocksPerMultiprocessor), measured no further gain.
+#define LOAD_STEP_OPERANDS()                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));       \
+    a_in = at(io.actions_in, eDc + dc);                                                                                               \
+    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);                                               \
+    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc); \
+    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);                                                                        \
     pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
+#ifdef PBHC_EARLY_OPERANDS
+    LOAD_STEP_OPERANDS()
+#endif
     adelayB = io.action_delay_idx[envc];
     const float mlenB = io.motion_len[envc];
     didx = c.randomize_ctrl_delay ? (int)adelayB : 0;
@@ -1275,6 +1281,9 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       }
     }
     STAMPB(2);
+#ifndef PBHC_EARLY_OPERANDS
+    LOAD_STEP_OPERANDS()
+#endif
     // ---- the history row (40 % of this role's loaded bytes, read by nobody before bar2) is REQUESTED here, behind the loads that bar1 waits
     // for — issued with them it sat in the same in-order queue and the burst of all workgroups' prologues landed ~2 k cycles later —
     // and copied to the feature row after bar1
