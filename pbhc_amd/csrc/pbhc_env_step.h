@@ -171,6 +171,14 @@ __device__ __forceinline__ float group_max(float v) {
 // element `i` of a tensor at a UNIFORM base pointer with the byte offset formed in 32 bits: the compiler emits the SGPR-base form of
 // global_load / global_store (one 32-bit offset VGPR per access instead of a 64-bit address built in the VALU).  Callers keep
 // (elements x sizeof) below 2^32 (checked on the host at pbhc_env_create / pbhc_env_step).
+// Outputs of the step are STREAMING stores (round 4): nothing in this launch reads them back, and as ordinary stores their 27 MB per 4096 envs
+// allocate in — and wash out — the XCDs' L2 that also serves the launch's own reads: 18.0 -> 17.1 us at 4096 envs, 100 -> 89.6 us at 32 768 on
+// one box (profiles/round4_k_env_step_variants.txt (j)).  -DPBHC_NO_NT_STORES: ordinary stores.
+#ifndef PBHC_NO_NT_STORES
+#define NTST(lhs, v) __builtin_nontemporal_store((v), &(lhs))
+#else
+#define NTST(lhs, v) ((lhs) = (v))
+#endif
 template <class T> __device__ __forceinline__ T& at(T* p, unsigned int i) { return *(T*)((char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
 template <class T> __device__ __forceinline__ const T& at(const T* p, unsigned int i) { return *(const T*)((const char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -546,29 +554,29 @@ __device__ __forceinline__ void motion_lookup_meta(const PbhcMotionTable& tbl, i
 // one role need no barrier at all; the five workgroup barriers below are the points where the roles exchange data.
 #define STATE_WRITEBACK()                                                                                                          \
       for (int dd = lane; dd < D; dd += PBHC_G) {                                                                                                     \
-        at(io.actions, eD + dd) = act[dd];                                                                                                            \
-        at(io.last_actions, eD + dd) = act[dd];                                                                                                       \
-        at(io.actions_after_delay, eD + dd) = actd[dd];                                                                                               \
-        at(io.torques, eD + dd) = tau[dd];                                                                                                            \
-        at(io.dof_state, (eD + dd) * 2) = q[dd];                                                                                                      \
-        at(io.dof_state, (eD + dd) * 2 + 1) = qd[dd];                                                                                                 \
-        at(io.last_dof_pos, eD + dd) = q[dd];                                                                                                         \
-        at(io.last_dof_vel, eD + dd) = qd[dd];                                                                                                        \
+        NTST(at(io.actions, eD + dd), act[dd]);                                                                                                            \
+        NTST(at(io.last_actions, eD + dd), act[dd]);                                                                                                       \
+        NTST(at(io.actions_after_delay, eD + dd), actd[dd]);                                                                                               \
+        NTST(at(io.torques, eD + dd), tau[dd]);                                                                                                            \
+        NTST(at(io.dof_state, (eD + dd) * 2), q[dd]);                                                                                                      \
+        NTST(at(io.dof_state, (eD + dd) * 2 + 1), qd[dd]);                                                                                                 \
+        NTST(at(io.last_dof_pos, eD + dd), q[dd]);                                                                                                         \
+        NTST(at(io.last_dof_vel, eD + dd), qd[dd]);                                                                                                        \
       }                                                                                                                                               \
-      if (lane < 13) at(io.root_states, (u32)env * 13u + (u32)lane) = root[lane];                                                                     \
+      if (lane < 13) NTST(at(io.root_states, (u32)env * 13u + (u32)lane), root[lane]);                                                                     \
       if (lane < NF) {                                                                                                                                \
         const u32 fo = (u32)env * (u32)NF + (u32)lane;                                                                                                \
-        at(io.feet_air_time, fo) = misc[M_FAT0 + lane];                                                                                               \
-        at(io.contacts, fo) = misc[M_CONTACT0 + lane];                                                                                                \
-        at(io.contacts_filt, fo) = misc[M_CFILT0 + lane];                                                                                             \
-        at(io.last_contacts, fo) = misc[M_CONTACT0 + lane];                                                                                           \
-        at(io.last_contacts_filt, fo) = misc[M_CFILT0 + lane];                                                                                        \
+        NTST(at(io.feet_air_time, fo), misc[M_FAT0 + lane]);                                                                                               \
+        NTST(at(io.contacts, fo), misc[M_CONTACT0 + lane]);                                                                                                \
+        NTST(at(io.contacts_filt, fo), misc[M_CFILT0 + lane]);                                                                                             \
+        NTST(at(io.last_contacts, fo), misc[M_CONTACT0 + lane]);                                                                                           \
+        NTST(at(io.last_contacts_filt, fo), misc[M_CFILT0 + lane]);                                                                                        \
       }                                                                                                                                               \
       if (lane == 0) {                                                                                                                                \
-        io.episode_length_buf[env] = (long long)misc[M_EPLEN];                                                                                        \
-        io.last_episode_length_buf[env] = (long long)misc[M_LASTEP];                                                                                  \
-        io.reset_buf[env] = misc[M_RESET] != 0.0f ? 1 : 0;                                                                                            \
-        io.time_out_buf[env] = misc[M_TIMEOUT] != 0.0f ? 1 : 0;                                                                                       \
+        NTST(io.episode_length_buf[env], (long long)(misc[M_EPLEN]));                                                                                        \
+        NTST(io.last_episode_length_buf[env], (long long)(misc[M_LASTEP]));                                                                                  \
+        NTST(io.reset_buf[env], (long long)(misc[M_RESET] != 0.0f ? 1 : 0));                                                                                            \
+        NTST(io.time_out_buf[env], (unsigned char)(misc[M_TIMEOUT] != 0.0f ? 1 : 0));                                                                                       \
       }                                                                                                                                               
 extern __shared__ float smem[];
 
@@ -752,7 +760,7 @@ __device__ __forceinline__ void obs_write_runs(const PbhcOutMap& m, uint32_t str
       if (R.noise != 0.0f) x = x + (obs_noise_u(pre, stream, (uint32_t)(R.dst + i)) * 2.0f - 1.0f) * (R.noise * noise_cur);
       x = x * R.scale;
       if (m.clip) x = __builtin_amdgcn_fmed3f(x, -clipobs, clipobs);
-      at(outg, ob + (unsigned int)(R.dst + i)) = x;
+      NTST(at(outg, ob + (unsigned int)(R.dst + i)), x);
     }
   }
 }
@@ -1324,7 +1332,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
           for (int k = 0; k < PBHC_MAX_QUEUE; ++k)
             if (k < Q) {
               float nv = (k == 0) ? a : qold[k > 0 ? k - 1 : 0];
-              at(io.action_queue, qoff + (u32)(k * D)) = nv;
+              NTST(at(io.action_queue, qoff + (u32)(k * D)), nv);
               if (k == didx) delayed = nv;
             }
         }
@@ -1932,7 +1940,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
             float tr = (misc[M_RESET] != 0.0f && misc[M_TIMEOUT] == 0.0f ? 1.0f : 0.0f) * c.termination_scale;
             v += tr;
           }
-          at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane) = v;
+          NTST(at(io.rew_buf, (u32)env * (u32)c.num_rew_cols + (u32)lane), v);
           rew_total = v;
         }
         rew_total = group_sum(rew_total);
