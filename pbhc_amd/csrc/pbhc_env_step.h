@@ -179,6 +179,15 @@ __device__ __forceinline__ float group_max(float v) {
 #else
 #define NTST(lhs, v) ((lhs) = (v))
 #endif
+// ... and the per-env inputs (replay frame, env state, history: each read by exactly one lane of one launch) as streaming loads
+// (-DPBHC_NT_LOADS, measurement: see (k) in the variants file); the motion table's rows and the constant tables stay ordinary loads — those
+// are what the L2 is for
+#ifdef PBHC_NT_LOADS
+#define NTLD(expr) __builtin_nontemporal_load(&(expr))
+#else
+#define NTLD(expr) (expr)
+#endif
+typedef float pbhc_f32x4 __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T& at(T* p, unsigned int i) { return *(T*)((char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
 template <class T> __device__ __forceinline__ const T& at(const T* p, unsigned int i) { return *(const T*)((const char*)p + (size_t)(unsigned int)(i * (unsigned int)sizeof(T))); }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -1046,8 +1055,8 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // for itself — 10 of its 25 load instructions and 9 % of the bytes a workgroup pulls through the CU's vector-memory pipeline, which
     // is what bounds the launch at large env counts (profiles/round4_k_env_step_memory_pipeline.txt).
     // the replay frame first: its addresses are in SGPRs since the wave was launched
-    const float fq = at(a_frame_q + fk * D, eDc + dc), fqd = at(a_frame_qd + fk * D, eDc + dc);
-    const float froot = at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));
+    const float fq = NTLD(at(a_frame_q + fk * D, eDc + dc)), fqd = NTLD(at(a_frame_qd + fk * D, eDc + dc));
+    const float froot = NTLD(at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12)));
     __builtin_amdgcn_sched_barrier(0);
     float4 kr[5];                                              // fk_jump: this lane's body constants, straight into registers
     if (fk_jump) {
@@ -1059,10 +1068,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const int tl_ = min(lane, PBHC_MAX_TERMS - 1);
       pf_tid = c.term_id[tl_]; pf_tscale = c.term_scale[tl_]; pf_tpen = c.term_penalty[tl_]; pf_tsrc = c.term_src[tl_];
       pf_colterm = c.sum_col_term[lane];                     // lane i <-> episode_sums column i: the term that accumulates into it
-      sumrow = at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1));
+      sumrow = NTLD(at(io.episode_sums, (u32)envc * (u32)c.num_sum_cols + (u32)min(lane, c.num_sum_cols - 1)));
       pf_sigma = (float)glob[PBHC_G_SIGMA + min(lane, PBHC_NUM_SIGMA - 1)];
       pf_pen_scale = (float)glob[PBHC_G_PENALTY_SCALE]; pf_far_thr = (float)glob[PBHC_G_MOTION_FAR_THR];
-      kpA = at(io.kp_scale, eDc + dc); kdA = at(io.kd_scale, eDc + dc);                // phase H (a reset replaces them in registers)
+      kpA = NTLD(at(io.kp_scale, eDc + dc)); kdA = NTLD(at(io.kd_scale, eDc + dc));                // phase H (a reset replaces them in registers)
       dpA = io.default_dof_pos ? at(io.default_dof_pos, eDc + dc) : c.default_dof_pos[dc];
       adelay = io.action_delay_idx[envc];
       etr_old = io.end_time_ratio_buf[envc];
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // the episode clock first: its addresses are in SGPRs since the wave was launched, and the reference rows' addresses hang on it
     ep1 = a_ep_len[envc] + 1;
     start = a_start[envc];
-    const float frootB = at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12));      // phase C below
+    const float frootB = NTLD(at(a_frame_root + fk * 13, (u32)envc * 13u + (u32)min(lane, 12)));      // phase C below
     __builtin_amdgcn_sched_barrier(0);
     // the skeleton constants for the dynamics waves' FK: ONE copy per workgroup, the first thing these two waves request (an L2 hit)
 #define SKC_REGSB ((SKC_WORDS + 2 * 64 - 1) / (2 * 64))
@@ -1155,7 +1164,7 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
     // two table rows.  Round 3 issued (2) BEHIND (3), i.e. after the first round trip had come back: two full trips to memory (6.5 k cycles
     // to this role's first stamp) where one and an L2 hit do.  Then _pre_physics_step (motion_tracking.py:749-768) and the torques from the
     // pre-step state (legged_robot_base.py:795-838).
-    const float fat = at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)), lastc = at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1));
+    const float fat = NTLD(at(io.feet_air_time, (u32)envc * (u32)NF + (u32)min(lane, NF - 1))), lastc = NTLD(at(io.last_contacts, (u32)envc * (u32)NF + (u32)min(lane, NF - 1)));
     // the frame's contact forces (3 B floats per env): whole quads 16 bytes per lane + the remainder, two load instructions instead of four
     float4 creg4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float cregr = 0.0f;
@@ -1164,20 +1173,20 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
       const u32 cbase = (u32)envc * (u32)(B * 3);
       const int nq = (B * 3) >> 2;
       const float* qa = &at(csrc, cbase + 4u * (u32)min(lane, nq - 1));
-      creg4 = make_float4(qa[0], qa[1], qa[2], qa[3]);               // (4-byte aligned rows: the compiler's own dwordx4, as for the table rows)
-      if ((B * 3) & 3) cregr = at(csrc, cbase + (u32)min(4 * nq + lane, B * 3 - 1));
+      creg4 = make_float4(NTLD(qa[0]), NTLD(qa[1]), NTLD(qa[2]), NTLD(qa[3]));               // (4-byte aligned rows: the compiler's own dwordx4, as for the table rows)
+      if ((B * 3) & 3) cregr = NTLD(at(csrc, cbase + (u32)min(4 * nq + lane, B * 3 - 1)));
     }
     // operands of the pre-physics step / torques / joint-space sums: consumed after bar1 — requested behind phase D, where the reference rows'
     // 32 registers are free again: 13 registers off this prologue's peak (92 -> 76 VGPRs; 18.0 / 95.0 -> 18.0 / 92.0 us at 4096 / 32 768 envs,
     // profiles/round4_k_env_step_variants.txt (i); -DPBHC_EARLY_OPERANDS: with the prologue's other loads, as before).  A sixth workgroup per CU,
     // which 76 registers admit (-DPBHC_MIN_WAVES=6: resident by hipOccupancyMaxActiveBlocksPerMultiprocessor), measured no further gain.
 #define LOAD_STEP_OPERANDS()                                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D));       \
-    a_in = at(io.actions_in, eDc + dc);                                                                                               \
-    qp = at(io.dof_state, (eDc + dc) * 2); qv = at(io.dof_state, (eDc + dc) * 2 + 1);                                               \
-    kp = at(io.kp_scale, eDc + dc); kd = at(io.kd_scale, eDc + dc); rfs = at(io.rfi_lim_scale, eDc + dc); ras = at(io.rao_scale, eDc + dc); \
-    u_inj = at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc);                                                                        \
-    pf_last_act = at(io.last_actions, eDc + dc); pf_last_qd = at(io.last_dof_vel, eDc + dc);
+    _Pragma("unroll") for (int k = 0; k < PBHC_MAX_QUEUE; ++k) qold[k] = NTLD(at(io.action_queue, qoff + (u32)(min(k, Q - 1) * D)));       \
+    a_in = NTLD(at(io.actions_in, eDc + dc));                                                                                               \
+    qp = NTLD(at(io.dof_state, (eDc + dc) * 2)); qv = NTLD(at(io.dof_state, (eDc + dc) * 2 + 1));                                               \
+    kp = NTLD(at(io.kp_scale, eDc + dc)); kd = NTLD(at(io.kd_scale, eDc + dc)); rfs = NTLD(at(io.rfi_lim_scale, eDc + dc)); ras = NTLD(at(io.rao_scale, eDc + dc)); \
+    u_inj = NTLD(at(io.u_rfi ? io.u_rfi : io.actions_in, eDc + dc));                                                                        \
+    pf_last_act = NTLD(at(io.last_actions, eDc + dc)); pf_last_qd = NTLD(at(io.last_dof_vel, eDc + dc));
 #ifdef PBHC_EARLY_OPERANDS
     LOAD_STEP_OPERANDS()
 #endif
@@ -1308,7 +1317,10 @@ __global__ __launch_bounds__(PBHC_TPB, PBHC_MIN_WAVES) __attribute__((amdgpu_wav
         const int nq = (c.hist_dim + 3) >> 2;
 #pragma unroll
         for (int u = 0; u < PBHC_HREG4; ++u)
-          if (u * PBHC_G < nq) hreg4[u] = *reinterpret_cast<const float4*>(&at(io.hist, hbase + 4u * (u32)min(lane + u * PBHC_G, nq - 1)));
+          if (u * PBHC_G < nq) {
+            const pbhc_f32x4 hv = NTLD(*reinterpret_cast<const pbhc_f32x4*>(&at(io.hist, hbase + 4u * (u32)min(lane + u * PBHC_G, nq - 1))));
+            hreg4[u] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+          }
       }
 #else
       for (int u = 0; u < PBHC_HREG; ++u) hreg[u] = 0.0f;

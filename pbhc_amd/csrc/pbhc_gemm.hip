@@ -551,7 +551,8 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
       }
       if (ok && !((dbg & 2) && v[0] != 12345.678f)) {      // (dbg 2: the epilogue without its global stores)
         float* cp = Cout + (size_t)row * ldc + col;
-        if (vec) reinterpret_cast<F4U*>(cp)->v = v;
+        if (vec && (dbg & 4)) __builtin_nontemporal_store(v, &reinterpret_cast<F4U*>(cp)->v);      // (dbg 4: C as streaming stores — measurement)
+        else if (vec) reinterpret_cast<F4U*>(cp)->v = v;
         else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) if (col + q < N) cp[q] = v[q];

@@ -32,7 +32,7 @@ for N, K in [(512, 768), (768, 630), (128, 512)]:
     y = torch.empty(M, N, device="cuda")
     st = _lib.current_stream()
     for shape in (2, 1):
-        cases = [(0, "full"), (1, "no LDS-DMA in the loop"), (16, "no epilogue"), (17, "no DMA, no epilogue"), (2, "epilogue without global stores")]
+        cases = [(0, "full"), (1, "no LDS-DMA in the loop"), (16, "no epilogue"), (17, "no DMA, no epilogue"), (2, "epilogue without global stores"), (4, "C as streaming (nt) stores")]
         if shape == 2:
             cases += [(d << 5, f"co-resident workgroups de-phased by {4 * d} us") for d in (2, 4, 5, 7)]
         for dbg, name in cases:
