@@ -152,14 +152,17 @@ def test_linear_wgrad_parts_rejects_what_the_kernel_cannot_take():
     assert lib.pbhc_linear_wgrad_parts(24576, 768, 630) == 16 and lib.pbhc_linear_wgrad_parts(24576, 512, 768) == 21     # 512 resident slots / tiles; whole groups per XCD when cheap
 
 
-@pytest.mark.parametrize("cfg", [(257, 20, 60, 40, 6, 2), (300, 10, 30, 20, 4, 2), (64, 8, 40, 20, 4, 2), (130, 6, 20, 10, 2, 1)])
+@pytest.mark.parametrize("cfg", [(257, 20, 60, 40, 6, 2), (300, 10, 30, 20, 4, 2), (64, 8, 40, 20, 4, 2), (130, 6, 20, 10, 2, 1), (70, 21, 12, 8, 6, 2)])
 @pytest.mark.parametrize("act_cls", [nn.ReLU, nn.SiLU, nn.ELU])
-def test_window_conv_strided_batch_matches_conv1d(cfg, act_cls):
+@pytest.mark.parametrize("phases", [False, True])
+def test_window_conv_strided_batch_matches_conv1d(monkeypatch, cfg, act_cls, phases):
     """agents/agent_modules._WindowConv1dAct (one `pbhc_linear_act_fwd_strided` launch for the L output positions of an encoder Conv1d,
-    encoder_modules.py:60-107) against act(nn.Conv1d) under autograd: output, input gradient, weight and bias gradients."""
+    encoder_modules.py:60-107) against act(nn.Conv1d) under autograd: output, input gradient, weight and bias gradients — with the input
+    gradient as the per-window accumulation loop (default) and as one strided-batched GEMM per stride phase (PBHC_CONV_DGRAD_PHASES=1)."""
     from pbhc_amd.agents import agent_modules as am
     from pbhc_amd.agents import fused_mlp
 
+    monkeypatch.setattr(am, "CONV_DGRAD_PHASES", phases)
     B, T, C, O, k, s = cfg
     torch.manual_seed(B + T)
     conv = nn.Conv1d(C, O, k, s).cuda()
