@@ -63,9 +63,15 @@ struct MlpArgs {
 
 __host__ __device__ __forceinline__ int mlp_pitch(int k) { return ((k + 15) & ~15) + 4; }   // zero-padded to a whole k-step; 4 mod 32 words where it matters
 
+// (exp as in csrc/pbhc_gemm.hip: the hardware's 2^x on x log2 e, so that the rollout's stack and the update's layer kernels apply the same activation)
+#ifndef PBHC_GEMM_LIBM_EXP
+#define MLP_EXP(x) __builtin_amdgcn_exp2f((x) * 1.44269504088896341f)
+#else
+#define MLP_EXP(x) expf(x)
+#endif
 __device__ __forceinline__ float mlp_act(int act, float v) {
-  if (act == 1) return v > 0.0f ? v : expf(v) - 1.0f;       // ATen's GPU ELU: exp(x) - 1 in f32
-  if (act == 2) return v / (1.0f + expf(-v));             // SiLU as ATen computes it
+  if (act == 1) return v > 0.0f ? v : MLP_EXP(v) - 1.0f;    // ELU: exp(x) - 1 in f32
+  if (act == 2) return v / (1.0f + MLP_EXP(-v));          // SiLU: x / (1 + exp(-x))
   if (act == 3) return v > 0.0f ? v : 0.0f;
   return v;
 }
