@@ -31,18 +31,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // call (tools/probes/fast_exp_ab.sh).  The activations differ from ATen's by <= 1e-7 absolute (-DPBHC_GEMM_LIBM_EXP: the library expf).
 #ifndef PBHC_GEMM_LIBM_EXP
 #define GEMM_EXP(x) __builtin_amdgcn_exp2f((x) * 1.44269504088896341f)
+#define GEMM_RCP(x) __builtin_amdgcn_rcpf(x)                    // (SiLU's 1 / (1 + e^-x): v_rcp_f32, 1 ulp, for an IEEE division's ~10 instructions)
 #else
 #define GEMM_EXP(x) expf(x)
+#define GEMM_RCP(x) (1.0f / (x))
 #endif
 __device__ __forceinline__ float gemm_act(int act, float v) {
   if (act == 1) return v > 0.0f ? v : GEMM_EXP(v) - 1.0f;   // ATen's GPU ELU: exp(x) - 1 in f32 (ActivationEluKernel.cu)
-  if (act == 2) return v / (1.0f + GEMM_EXP(-v));         // SiLU as ATen computes it: x / (1 + exp(-x))
+  if (act == 2) return v * GEMM_RCP(1.0f + GEMM_EXP(-v));         // SiLU as ATen computes it: x / (1 + exp(-x))
   if (act == 3) return v > 0.0f ? v : 0.0f;
   return v;
 }
 __device__ __forceinline__ float gemm_act_grad(int act, float s) {      // ELU (alpha 1), ReLU: from the activation OUTPUT; SiLU: from the PRE-activation
   if (act == 1) return s > 0.0f ? 1.0f : s + 1.0f;
-  if (act == 2) { const float sg = 1.0f / (1.0f + GEMM_EXP(-s)); return sg * (1.0f + s * (1.0f - sg)); }
+  if (act == 2) { const float sg = GEMM_RCP(1.0f + GEMM_EXP(-s)); return sg * (1.0f + s * (1.0f - sg)); }
   if (act == 3) return s > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
 }

@@ -230,9 +230,17 @@ __global__ __launch_bounds__(RED_T) void k_ppo_reduce(const float* __restrict__ 
 // act: 0 none, 1 ELU(alpha 1) from the activation OUTPUT (elu' = y > 0 ? 1 : y + 1), 2 SiLU from the PRE-activation, 3 ReLU from the output.
 // Thread <-> column (coalesced rows), ACT_RPB row groups per block, fixed-order two-stage column sums.
 #define ACT_T 256
+// (the SiLU derivative's exp as in csrc/pbhc_gemm.hip: 2^(x log2 e) on v_exp_f32; -DPBHC_GEMM_LIBM_EXP: the library expf)
+#ifndef PBHC_GEMM_LIBM_EXP
+#define ACT_EXP(x) __builtin_amdgcn_exp2f((x) * 1.44269504088896341f)
+#define ACT_RCP(x) __builtin_amdgcn_rcpf(x)                    // (SiLU's 1 / (1 + e^-x): v_rcp_f32, 1 ulp, for an IEEE division's ~10 instructions)
+#else
+#define ACT_EXP(x) expf(x)
+#define ACT_RCP(x) (1.0f / (x))
+#endif
 __device__ __forceinline__ float act_grad(int act, float s) {
   if (act == 1) return s > 0.0f ? 1.0f : s + 1.0f;
-  if (act == 2) { const float sg = 1.0f / (1.0f + expf(-s)); return sg * (1.0f + s * (1.0f - sg)); }
+  if (act == 2) { const float sg = ACT_RCP(1.0f + ACT_EXP(-s)); return sg * (1.0f + s * (1.0f - sg)); }
   if (act == 3) return s > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
 }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(OUTB_T) void k_out_layer_bwd(const float* __restric
           const float s_ = sv[u];
           float gr = 1.0f;
           if (act == 1) gr = s_ > 0.0f ? 1.0f : s_ + 1.0f;                   // ELU' from the output, SiLU' from the pre-activation (as k_act_bwd_bias)
-          else if (act == 2) { const float sg = 1.0f / (1.0f + expf(-s_)); gr = sg * (1.0f + s_ * (1.0f - sg)); }
+          else if (act == 2) { const float sg = ACT_RCP(1.0f + ACT_EXP(-s_)); gr = sg * (1.0f + s_ * (1.0f - sg)); }
           else if (act == 3) gr = s_ > 0.0f ? 1.0f : 0.0f;
           g *= gr;
           dh[(size_t)(rt + rr) * K + c] = g;
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(2 * KT) void k_out_bwd_mfma(const float* __restrict
       const float hh = SAVED ? sv[e] : hv[e];
       float gr = 1.0f;
       if (act == 1) gr = hh > 0.0f ? 1.0f : hh + 1.0f;                    // ELU' / ReLU' from the output, SiLU' from the pre-activation (as k_act_bwd_bias)
-      else if (act == 2) { const float sg = 1.0f / (1.0f + expf(-hh)); gr = sg * (1.0f + hh * (1.0f - sg)); }
+      else if (act == 2) { const float sg = ACT_RCP(1.0f + ACT_EXP(-hh)); gr = sg * (1.0f + hh * (1.0f - sg)); }
       else if (act == 3) gr = hh > 0.0f ? 1.0f : 0.0f;
       const float g = acc[e] * gr;
       if (row < M) { dh[(size_t)row * KT + col] = g; cs += g; }
