@@ -537,6 +537,12 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         }
       }
     }
+    // The row pass with the activation and the store width as COMPILE-TIME constants (dispatched once below): with `act` / `vec` read per element
+    // the loop was a chain of scalar compares and branches around every group of four values (86 s_cmp + 270 branches in the epilogue of the
+    // 64 x 128 forward tile), which is latency the co-resident workgroups' MFMAs do not hide for this workgroup
+    auto row_pass = [&](auto act_c, auto vec_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool VEC = decltype(vec_c)::value != 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int row = row0 + p * RP + rr;
@@ -547,23 +553,23 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
         for (int q = 0; q < 4; ++q) v[q] += bv[q];
         if (Pre && ok) {
           float* pp = Pre + (size_t)row * ldc + col;
-          if (vec) reinterpret_cast<F4U*>(pp)->v = v;
+          if (VEC) reinterpret_cast<F4U*>(pp)->v = v;
           else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (col + q < N) pp[q] = v[q];
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = gemm_act(act, v[q]);
+        for (int q = 0; q < 4; ++q) v[q] = gemm_act(ACT, v[q]);
         if (CAN_FUSE_OUT && fuse_out) *reinterpret_cast<f32x4*>(&lds[(p * RP + rr) * CS + c4]) = v;   // the activated row stays for the output layer
-      } else if (act) {
+      } else if (ACT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(act, sv[p][q]);
+        for (int q = 0; q < 4; ++q) v[q] *= gemm_act_grad(ACT, sv[p][q]);
       }
       if (ok && !((dbg & 2) && v[0] != 12345.678f)) {      // (dbg 2: the epilogue without its global stores)
         float* cp = Cout + (size_t)row * ldc + col;
-        if (vec && (dbg & 4)) __builtin_nontemporal_store(v, &reinterpret_cast<F4U*>(cp)->v);      // (dbg 4: C as streaming stores — measurement)
-        else if (vec) reinterpret_cast<F4U*>(cp)->v = v;
+        if (VEC && (dbg & 4)) __builtin_nontemporal_store(v, &reinterpret_cast<F4U*>(cp)->v);      // (dbg 4: C as streaming stores — measurement)
+        else if (VEC) reinterpret_cast<F4U*>(cp)->v = v;
         else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) if (col + q < N) cp[q] = v[q];
@@ -573,6 +579,12 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
           for (int q = 0; q < 4; ++q) csum[q] += v[q];      // rows in the fixed order p = 0, 1, ...
         }
       }
+    }
+    };
+    if (vec) {
+      if (act == 1) row_pass(IC<1>{}, IC<1>{}); else if (act == 2) row_pass(IC<2>{}, IC<1>{}); else if (act == 3) row_pass(IC<3>{}, IC<1>{}); else row_pass(IC<0>{}, IC<1>{});
+    } else {
+      if (act == 1) row_pass(IC<1>{}, IC<0>{}); else if (act == 2) row_pass(IC<2>{}, IC<0>{}); else if (act == 3) row_pass(IC<3>{}, IC<0>{}); else row_pass(IC<0>{}, IC<0>{});
     }
     if ((dbg & 8) && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
       __builtin_amdgcn_s_waitcnt(0);
