@@ -911,8 +911,12 @@ int pbhc_linear_act_fwd_out(const float* x, const float* w, const float* bias, f
   GEMM_ARG(x && w && y && w_out && out && M >= 1 && N == 128 && K >= 4 && NO >= 1 && NO <= 32 && act >= 0 && act <= 3);
   GEMM_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 3) == 0 && ((uintptr_t)w_out & 3) == 0);
   GEMM_ARG((size_t)M * K < (1u << 30) && (size_t)N * K < (1u << 30));
-  GEMM_HIP((gemm2_launch<0, 1, 4, 1, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, (hipStream_t)stream, 0, 0, 0, 0, 1,
-                                               GemmOutLayer{w_out, b_out, out, NO})));
+  const GemmOutLayer fo{w_out, b_out, out, NO};
+  hipStream_t st = (hipStream_t)stream;
+  // (g_variant 2 / 3, measurement: BK 16 with a 3- / 4-deep ring for this short-K tile)
+  if (g_variant == 2) GEMM_HIP((gemm2_launch<0, 1, 4, 1, 1, 16, 3>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, 0, 0, 0, 0, 1, fo)));
+  else if (g_variant == 3) GEMM_HIP((gemm2_launch<0, 1, 4, 1, 1, 16, 4>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, 0, 0, 0, 0, 1, fo)));
+  else GEMM_HIP((gemm2_launch<0, 1, 4, 1, 1, 32, 2>(x, w, bias, nullptr, y, pre, nullptr, M, N, K, act, st, 0, 0, 0, 0, 1, fo)));
   return PBHC_OK;
 }
 
