@@ -388,13 +388,20 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     }
   };
 
+  // The accumulators start at the BIAS of their column (C/D map: lane (r, kk) holds column r of the tile in all 16 elements): the epilogue then has no
+  // bias add — every VALU instruction outside the K loop displaces ~12 cycles of the co-resident workgroups' MFMA issue (SQ counters of the 768 x 630
+  // forward: 543 non-MFMA VALU instructions per wave and tile against 84 % matrix-pipe utilisation) — and y = (b + sum_k x w), one rounding apart
+  // from (sum_k x w) + b
   f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int colj = col0 + (wn * TN + j) * 32 + r;
+    const float bj = (MODE == 0 && bias && colj < N) ? bias[colj] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = bj;
+  }
 
   // constant per-lane fragment indices (floats) inside a stage; tile rows start at multiples of 32, so the row swizzle depends on r only
   const int sw_r = BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7;
@@ -515,11 +522,6 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     const int col = col0 + c4;
     const bool vec = (N & 3) == 0;                         // whole 16-byte pieces inside the row (dword-aligned 16-byte accesses)
     const bool cok = vec ? col < N : col < N;              // first column inside
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 0 && bias) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (col + q < N) bv[q] = bias[col + q];
-    }
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 sv[NP];
     if (MODE == 1 && act) {                                // the lower layer's saved activations for all of this thread's rows, in flight together
@@ -542,15 +544,14 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
     // 64 x 128 forward tile), which is latency the co-resident workgroups' MFMAs do not hide for this workgroup
     auto row_pass = [&](auto act_c, auto vec_c) {
       constexpr int ACT = decltype(act_c)::value;
-      constexpr bool VEC = decltype(vec_c)::value != 0;
+      constexpr bool VEC = (decltype(vec_c)::value & 1) != 0;
+      constexpr bool INTERIOR = (decltype(vec_c)::value & 2) != 0;      // the whole tile lies inside the matrix: no row / column tests
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int row = row0 + p * RP + rr;
       f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(p * RP + rr) * CS + c4]);
-      const bool ok = row < M && cok;
+      const bool ok = INTERIOR || (row < M && cok);
       if (MODE == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv[q];
         if (Pre && ok) {
           float* pp = Pre + (size_t)row * ldc + col;
           if (VEC) reinterpret_cast<F4U*>(pp)->v = v;
@@ -581,7 +582,10 @@ __global__ __launch_bounds__(GEMM_T, 2) void k_gemm2(const float* __restrict__ A
       }
     }
     };
-    if (vec) {
+    const bool interior = row0 + BM <= M && col0 + BN <= N;
+    if (vec && interior) {
+      if (act == 1) row_pass(IC<1>{}, IC<3>{}); else if (act == 2) row_pass(IC<2>{}, IC<3>{}); else if (act == 3) row_pass(IC<3>{}, IC<3>{}); else row_pass(IC<0>{}, IC<3>{});
+    } else if (vec) {
       if (act == 1) row_pass(IC<1>{}, IC<1>{}); else if (act == 2) row_pass(IC<2>{}, IC<1>{}); else if (act == 3) row_pass(IC<3>{}, IC<1>{}); else row_pass(IC<0>{}, IC<1>{});
     } else {
       if (act == 1) row_pass(IC<1>{}, IC<0>{}); else if (act == 2) row_pass(IC<2>{}, IC<0>{}); else if (act == 3) row_pass(IC<3>{}, IC<0>{}); else row_pass(IC<0>{}, IC<0>{});
