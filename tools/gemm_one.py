@@ -16,7 +16,7 @@ w = torch.randn(N, K, device="cuda")
 b = torch.randn(N, device="cuda")
 y = torch.empty(M, N, device="cuda")
 st = _lib.current_stream()
-lib.pbhc_gemm_debug_force_shape((shape & 0xff) | (variant << 16))
+lib.pbhc_gemm_debug_force_shape((shape & 0xff) | (variant << 16) | (int(os.environ.get('GEMM_DBG', '0')) << 8))      # GEMM_DBG: tools/gemm_ablation.py's flags
 for _ in range(30):
     _lib.check(lib.pbhc_linear_act_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, M, N, K, 1, st), "fwd")
 torch.cuda.synchronize()
