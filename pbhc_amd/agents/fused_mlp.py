@@ -329,6 +329,33 @@ class _FusedMLPCat(torch.autograd.Function):
         return (None, dx, None, *flat)
 
 
+class _FusedMLPInto(torch.autograd.Function):
+    """_FusedMLPCat without the concatenation: `xfull` [B, in] already holds the constant (observation) columns [0, c0) — written once per
+    update, when the minibatch shuffle is done — and the gradient-carrying parts (encoder outputs) are copied into its columns [c0, in) here:
+    19 + 13 MB of copies per optimiser step of the general-tracking update where the two `torch.cat` moved 46 + 46 MB.  `xfull` is the first
+    layer's saved input: it must stay untouched until this application's backward has run (the agent rewrites a slice only when its minibatch
+    comes round again, an epoch later)."""
+
+    @staticmethod
+    def forward(ctx, xfull, c0, nparts, seq, *rest):
+        parts = rest[:nparts]
+        o = c0
+        for t in parts:
+            xfull[:, o:o + t.shape[1]].copy_(t)
+            o += t.shape[1]
+        assert o == xfull.shape[1]
+        ctx.grad_cols = c0
+        ctx.part_widths = [t.shape[1] for t in parts]
+        return _FusedMLP._fwd(ctx, xfull, seq)
+
+    @staticmethod
+    def backward(ctx, dout):
+        need = any(ctx.needs_input_grad[4:4 + len(ctx.part_widths)])
+        dx, flat = _FusedMLP._bwd(ctx, dout, need)
+        dparts = [None] * len(ctx.part_widths) if dx is None else list(torch.split(dx, ctx.part_widths, dim=1))
+        return (None, None, None, None, *dparts, *flat)
+
+
 OUT_BWD = os.environ.get("PBHC_FUSED_OUT_BWD", "1") != "0"
 FWD_OUT = os.environ.get("PBHC_FUSED_FWD_OUT", "1") != "0"
 FUSED_STACK = os.environ.get("PBHC_FUSED_STACK", "1") != "0"
@@ -450,6 +477,15 @@ def forward_cat_inference(seq, xs, sample=None):
     _lib.check(_lib.lib().pbhc_mlp_fwd_cat(C.byref(inp), c["w"], c["b"], c["dims"], len(lin), act, None if out is None else out.data_ptr(),
                                            0 if out is None else out.stride(0), B, smp_ref, _lib.current_stream()), "pbhc_mlp_fwd_cat")
     return out if sample is None else None
+
+
+def forward_into(seq, xfull, c0, parts):
+    """seq(xfull) after copying `parts` (tensors [B, w_i], the gradient-carrying inputs) into xfull[:, c0:] — see _FusedMLPInto"""
+    params = []
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            params += [m.weight, m.bias]
+    return _FusedMLPInto.apply(xfull, c0, len(parts), seq, *parts, *params)
 
 
 def forward(seq, x):

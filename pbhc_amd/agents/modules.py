@@ -76,6 +76,17 @@ def apply_cat(mod, x_const, x_grad):
     return mod(torch.cat([x_const, x_grad], dim=-1))
 
 
+def apply_into(mod, xfull, c0, parts):
+    """`mod(xfull)` for a BaseModule after copying `parts` into xfull[:, c0:] (the columns [0, c0) — observations — are in place already): the
+    fused training path without the `torch.cat` copy of the whole input (fused_mlp._FusedMLPInto); anything else: the concatenation"""
+    if (mod._fused and xfull.is_cuda and xfull.dim() == 2 and xfull.is_contiguous() and torch.is_grad_enabled() and not xfull.requires_grad
+            and sum(t.shape[1] for t in parts) == xfull.shape[1] - c0):
+        from . import fused_mlp
+
+        return fused_mlp.forward_into(mod.module, xfull, c0, list(parts))
+    return mod(torch.cat([xfull[:, :c0], *parts], dim=-1))
+
+
 class PPOActor(nn.Module):
     def __init__(self, obs_dim_dict, module_config_dict, num_actions, init_noise_std):
         super().__init__()
@@ -219,15 +230,18 @@ class RolloutStorage(nn.Module):
     def clear(self):
         self.step = 0
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8, keys=None, indices=None):
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8, keys=None, indices=None, on_gather=None):
         """One permutation per call, the same contiguous slices every epoch (data_utils.py:134-152).
-        `keys` restricts the gather to what the update reads (the reference gathers every key)."""
+        `keys` restricts the gather to what the update reads (the reference gathers every key).  `on_gather(shuffled)`: called once with the
+        shuffled [T * N, C] tensors — entries it adds are sliced into the minibatches like every other key."""
         batch_size = self.num_envs * self.num_transitions_per_env
         mb = batch_size // num_mini_batches
         if indices is None:
             indices = torch.randperm(batch_size, device=self.device)
         keys = self.stored_keys if keys is None else keys
         shuffled = self._gather(keys, indices)
+        if on_gather is not None:
+            on_gather(shuffled)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 yield {k: v[i * mb:(i + 1) * mb] for k, v in shuffled.items()}

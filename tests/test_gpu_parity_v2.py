@@ -95,6 +95,29 @@ def _v2_algo(N, overrides=None, noise_off=True):
     return cfg, env, algo
 
 
+def test_update_with_inputs_assembled_in_place_equals_the_concatenations(monkeypatch):
+    """ppo_mimic's update lays the stacks' observation columns out once per update and copies only the encoder outputs per optimiser step
+    (`_assemble_inputs`, fused_mlp._FusedMLPInto) instead of concatenating [observations | encoder outputs] every step (ppo_mimic.py:596-630 via
+    agent_modules.py:118-128): the GEMMs see the same operands — weights, Adam moments and learning rate after a rollout + update are bit-identical."""
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PBHC_ASSEMBLE_INPUTS", mode)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        cfg, env, algo = _v2_algo(512, noise_off=False)
+        algo._train_mode()
+        obs = env.reset_all()
+        algo.storage.clear()
+        algo._rollout_step(obs)
+        n = algo.storage.num_envs * algo.storage.num_transitions_per_env
+        algo._training_step(indices=torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(DEV))
+        torch.cuda.synchronize()
+        assert (algo.__dict__.get("_xin") is not None) == (mode == "1")
+        outs.append([algo._pflat.clone(), algo._lr.clone()] + [m.clone() for m in algo._mflat] + [v.clone() for v in algo._vflat])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_ppo_mimic_update_matches_reference():
     """One _training_step + one _training_step_dagger of pbhc_amd PPO on the reference's rollout buffer, initial weights and
     permutations reproduce the reference's updated weights, losses and learning rate (tests/golden/ppo_v2.npz)."""
